@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: Chebyshev recurrence steps/s on the 4N x 4N BdG Hamiltonian.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+Workload (BASELINE.json configs[2], the configuration the roofline target is
+quoted on): CubicLattice((1000,1000,1)), H_ii = 3σ0 - 0.05σ3, Δ_ii = -0.1 iσ2,
+bonds -σ0, open boundaries -> 4M x 4M complex128 BSR matrix (1.28 GB).  Every
+GPU holds the whole matrix and advances its own 8 stochastic-trace vectors
+(weak scaling); one "step" is one launch of the fused recurrence kernel
+t_{n+1} = (2/a) H t_n - t_{n-1} (+ both dot products) on those vectors.  The
+timed region is one whole moment calculation of 2K moments - start-vector
+generation, K launches, the dot reductions, and for N > 1 the RCCL all-reduce
+of the moment vector - with the matrix already resident in HBM.
+
+`value` = (N x vectors-per-GPU x K) / wall seconds = vector-steps per second.
+`roofline.achieved` = algorithmic bytes of one launch / mean launch time from
+HIP events on the library's stream.  `cpu_baseline` times the scipy.sparse
+restatement (oracle) on this host, single thread, on a bounded sample.
+
+For N > 1 the driver starts one process per GPU with torch.distributed.run;
+only its environment variables are used (RANK, LOCAL_RANK, WORLD_SIZE,
+MASTER_PORT) - the collective is RCCL through the C ABI, not torch.
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+def build_system(shape, zeeman=0.05, gap=0.1, mu=3.0):
+    import bodge_amd as ba
+
+    lattice = ba.CubicLattice(tuple(shape))
+    system = ba.Hamiltonian(lattice)
+    with system as (H, Δ):
+        H.set_sites(mu * ba.σ0 - zeeman * ba.σ3)
+        Δ.set_sites(-gap * ba.jσ2)
+        H.set_bonds(-1.0 * ba.σ0)
+    return system
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=256, help="recurrence launches in the timed call (2x moments)")
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--lattice", default="1000,1000,1")
+    ap.add_argument("--vectors-per-gpu", type=int, default=8)
+    ap.add_argument("--vector-kind", default="rademacher", choices=["rademacher", "z4"])
+    ap.add_argument("--lanes", type=int, default=0, help="override lanes per block row (tuning)")
+    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the cpu_baseline leg")
+    ap.add_argument("--temperature", type=float, default=0.5)
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+
+    from bodge_amd import backend, build, chebyshev
+    from bodge_amd.solver import VEC_RADEMACHER, VEC_Z4, Communicator, DeviceSolver
+
+    if rank == 0 and not os.path.exists(build.LIBRARY):
+        build.build_library()
+    backend.load()
+    backend.require_device()
+    comm = Communicator.from_environment()
+
+    shape = [int(v) for v in args.lattice.split(",")]
+    t0 = time.perf_counter()
+    system = build_system(shape)
+    indptr, indices, data = system.bsr_arrays()
+    scale = chebyshev.spectral_bound(indptr, data)
+    t_build = time.perf_counter() - t0
+    device = local % backend.device_count()
+    solver = DeviceSolver(indptr, indices, data, device=device)
+    if args.lanes:
+        solver.set_lanes_per_row(args.lanes)
+    kind = VEC_RADEMACHER if args.vector_kind == "rademacher" else VEC_Z4
+    r_local = args.vectors_per_gpu
+    first = rank * r_local
+
+    def run(steps):
+        return solver.moments_random(scale, 2 * steps, r_local, seed=0, first_id=first, kind=kind, comm=comm)
+
+    if args.warmup > 0:
+        run(args.warmup)
+    if comm is not None:
+        comm.barrier()
+    t0 = time.perf_counter()
+    mu = run(args.steps)
+    elapsed = time.perf_counter() - t0
+    if comm is not None:
+        elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
+    perf = solver.perf()
+
+    if rank != 0:
+        return
+
+    total_vectors = r_local * args.gpus
+    value = total_vectors * args.steps / elapsed
+    launch_ms = perf["kernel_ms"] / max(1, perf["launches"])
+    achieved = perf["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
+    free_energy = chebyshev.free_energy_series(mu / total_vectors, scale, args.temperature)
+
+    record = {
+        "metric": "Chebyshev SpMV vector-steps/s, 4Nx4N BdG H (BSR 4x4 complex128), fused recurrence + dots",
+        "value": value,
+        "unit": "steps/s",
+        "n_gpus": args.gpus,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "c128",
+        "data": "synthetic",
+        "config": {
+            "workload": f"CubicLattice({tuple(shape)}) s-wave+Zeeman, {2 * args.steps}-moment stochastic-trace "
+                        f"free_energy, {r_local} vectors/GPU, H replicated, vectors sharded",
+            "n_sites": int(system.lattice.size),
+            "nnzb": int(indices.size),
+            "moments": 2 * args.steps,
+            "vectors_per_gpu": r_local,
+            "vector_kind": args.vector_kind,
+            "spectral_scale": scale,
+            "parallelism": f"vectors x{args.gpus}",
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": None,
+            "kernel": f"cheb_step<{perf['lanes_per_row']}>",
+            "launch_ms": launch_ms,
+            "bytes_per_launch": perf["bytes_per_launch"],
+            "grid": perf["grid"],
+            "lds_bytes": perf["lds_bytes"],
+        },
+        "free_energy_wall_s": elapsed,
+        "free_energy_estimate": free_energy,
+        "host_assembly_s": t_build,
+    }
+
+    if args.cpu_seconds > 0 and args.gpus == 1:
+        from oracle import cheb_ref
+
+        bsr = system.matrix("bsr")
+        cpu_rate, cpu_steps = cheb_ref.time_recurrence(bsr, scale, r_local, seconds=args.cpu_seconds, kind=kind)
+        record["cpu_baseline"] = {
+            "value": cpu_rate,
+            "unit": "steps/s",
+            "cores": 1,
+            "kind": "port",
+            "sample": f"{cpu_steps} timed block-steps of the same {r_local} vectors on the same H "
+                      f"(scipy.sparse BSR matvec + numpy axpy/dots, host has {os.cpu_count()} logical cores)",
+        }
+    else:
+        record["cpu_baseline"] = None
+    print(json.dumps(record), flush=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,99 @@
+"""Host-side scalar work of the Chebyshev path (O(M) and O(nnz) numpy, no matvecs).
+
+The device produces moments μ_m = Tr-like sums of T_m(H/a); everything here is
+the bookkeeping around them:
+
+* `spectral_bound`      a ≥ ‖H‖ from Gershgorin discs over the BSR blocks
+* `free_energy_series`  F = Σ_m c_m μ_m with c_m the Chebyshev coefficients of
+                        f(ε) = -(T/2) ln(2 cosh(ε/2T)), whose sum over the full
+                        ±-symmetric spectrum is the reference's
+                        -½Σ_{ε>0}ε - TΣ_{ε>0}log(1+e^{-ε/T})  (ref hamiltonian.py:305-321)
+* `resolvent_series`    <e|(z-H)^{-1}|e> from per-vector moments (LDOS, ref :367-382)
+* `moments_for_*`       how many moments a requested accuracy needs
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def spectral_bound(indptr: np.ndarray, data: np.ndarray, pad: float = 1.01) -> float:
+    """max over scalar rows of Σ|H_rc|, times `pad` (> 1 keeps the spectrum strictly inside)."""
+    n_sites = len(indptr) - 1
+    if len(data) == 0:
+        return 1.0
+    per_block = np.abs(data).sum(axis=2)  # (nnzb, 4)
+    owner = np.repeat(np.arange(n_sites), np.diff(indptr))
+    radius = np.zeros((n_sites, 4))
+    np.add.at(radius, owner, per_block)
+    bound = float(radius.max())
+    return pad * bound if bound > 0 else 1.0
+
+
+def _f_density(eps: np.ndarray, temperature: float) -> np.ndarray:
+    mag = np.abs(eps)
+    if temperature == 0:
+        return -mag / 4
+    return -mag / 4 - (temperature / 2) * np.log1p(np.exp(-mag / temperature))
+
+
+def chebyshev_coefficients(func, n_moments: int, oversample: int = 4) -> np.ndarray:
+    """Coefficients c_m, m < M, of `func` on [-1, 1] (c_0 already halved)."""
+    nodes = oversample * n_moments
+    theta = np.pi * (np.arange(nodes) + 0.5) / nodes
+    values = func(np.cos(theta))
+    coeff = np.empty(n_moments)
+    # chunked cosine sums keep the temporary at a few MB even for M ~ 10^5
+    step = max(1, (1 << 22) // nodes)
+    for lo in range(0, n_moments, step):
+        m = np.arange(lo, min(n_moments, lo + step))[:, None]
+        coeff[lo : lo + step] = (2.0 / nodes) * (np.cos(m * theta[None, :]) @ values)
+    coeff[0] *= 0.5
+    return coeff
+
+
+def jackson_kernel(n_moments: int) -> np.ndarray:
+    m = np.arange(n_moments)
+    q = np.pi / (n_moments + 1)
+    return ((n_moments - m + 1) * np.cos(q * m) + np.sin(q * m) / np.tan(q)) / (n_moments + 1)
+
+
+def free_energy_series(mu_trace: np.ndarray, scale: float, temperature: float, damping: bool = False) -> float:
+    """F from trace moments μ_m ≈ Tr T_m(H/scale)."""
+    n = len(mu_trace)
+    coeff = chebyshev_coefficients(lambda x: _f_density(scale * x, temperature), n)
+    if damping:
+        coeff = coeff * jackson_kernel(n)
+    return float(np.dot(coeff, mu_trace))
+
+
+def moments_for_free_energy(scale: float, temperature: float, digits: float = 11.0) -> int:
+    """Even M for ~10^-digits truncation error of f on [-a, a].
+
+    f is analytic in the strip |Im ε| < πT, i.e. inside the Bernstein ellipse
+    with ρ = 1 + πT/a (small T/a), so the coefficients decay like ρ^-m.
+    T = 0 is only algebraic (|ε|); a fixed large default is returned.
+    """
+    if temperature <= 0:
+        return 4096
+    rate = np.log1p(np.pi * temperature / scale)
+    m = int(np.ceil(digits * np.log(10.0) / rate))
+    m = int(np.clip(m, 32, 1 << 17))
+    return m + (m & 1)
+
+
+def moments_for_resolvent(scale: float, gamma: float, digits: float = 12.0) -> int:
+    """Even M with exp(-M Γ/a) ≲ 10^-digits for the resolvent series at broadening Γ."""
+    m = int(np.ceil(digits * np.log(10.0) * scale / gamma))
+    m = int(np.clip(m, 64, 1 << 20))
+    return m + (m & 1)
+
+
+def resolvent_series(mu: np.ndarray, scale: float, z: complex) -> complex:
+    """<e|(z - H)^{-1}|e> given μ_n = <e|T_n(H/scale)|e>, for Im z > 0."""
+    zt = complex(z) / scale
+    angle = np.arccos(zt)
+    n = np.arange(len(mu))
+    weights = np.exp(-1j * n * angle)
+    weights[1:] *= 2.0
+    return complex(-1j / np.sqrt(1 - zt * zt) * np.dot(weights, mu) / scale)

@@ -1,0 +1,730 @@
+// Host side of libbodge_hip.so: the C ABI declared in include/bodge_hip.h.
+//
+// One `bdg_system` is one BSR Hamiltonian resident in the HBM of one GPU plus
+// the work buffers of the Chebyshev recurrence.  All launches go to a private
+// non-blocking HIP stream; timing uses HIP events recorded on that stream.
+// rocSOLVER (dense path) and RCCL (multi-GPU moments) are loaded with dlopen
+// on first use so that the core library has no load-time dependency on them.
+
+#include "bodge_hip.h"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+#include <rocsolver/rocsolver.h>
+
+#include <algorithm>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "kernels.hpp"
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t err__ = (expr);                                                      \
+        if (err__ != hipSuccess)                                                        \
+            return fail(err__ == hipErrorOutOfMemory ? BDG_ENOMEM : BDG_EDEVICE,        \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__),       \
+                        __FILE__, __LINE__);                                            \
+    } while (0)
+
+template <typename T>
+struct DeviceBuffer {
+    T* ptr = nullptr;
+    size_t count = 0;
+    int reserve(size_t n) {
+        if (n <= count) return BDG_OK;
+        release();
+        hipError_t err = hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
+        if (err != hipSuccess) {
+            ptr = nullptr;
+            return fail(BDG_ENOMEM, "hipMalloc of %zu bytes failed: %s", n * sizeof(T),
+                        hipGetErrorString(err));
+        }
+        count = n;
+        return BDG_OK;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+};
+
+int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+struct bdg_system {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    int64_t nb = 0, nnzb = 0;
+    int max_row_blocks = 0;
+    int num_cus = 0;
+    int lanes_override = 0;
+    DeviceBuffer<int> indptr, indices;
+    DeviceBuffer<double2> blocks;
+    DeviceBuffer<double2> vec_a, vec_b;
+    DeviceBuffer<double> partial, dots;
+    DeviceBuffer<int64_t> rows;
+    bdg_perf perf{};
+};
+
+struct bdg_comm {
+    int device = 0;
+    int n_ranks = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    DeviceBuffer<double> scratch;
+};
+
+namespace {
+
+// ------------------------------------------------------------ kernel dispatch
+using StepKernel = void (*)(bdg::StepArgs);
+
+StepKernel step_kernel(int rl) {
+    switch (rl) {
+        case 1: return bdg::cheb_step<1>;
+        case 2: return bdg::cheb_step<2>;
+        case 4: return bdg::cheb_step<4>;
+        case 8: return bdg::cheb_step<8>;
+        case 16: return bdg::cheb_step<16>;
+        case 32: return bdg::cheb_step<32>;
+        case 64: return bdg::cheb_step<64>;
+    }
+    return nullptr;
+}
+
+struct StepPlan {
+    int rl = 0;
+    int rows_per_tile = 0;
+    int n_tiles = 0;
+    int grid = 0;
+    size_t lds_bytes = 0;
+    StepKernel kernel = nullptr;
+};
+
+int make_plan(bdg_system* sys, int rl, StepPlan* plan) {
+    plan->rl = rl;
+    plan->kernel = step_kernel(rl);
+    if (!plan->kernel) return fail(BDG_EINVAL, "unsupported lanes-per-row %d", rl);
+    const int rows_per_wave = bdg::kWave / rl;
+    plan->rows_per_tile = rows_per_wave * bdg::kWavesPerBlock;
+    plan->n_tiles = (int)((sys->nb + plan->rows_per_tile - 1) / plan->rows_per_tile);
+    const size_t stage = (size_t)bdg::kWavesPerBlock * rows_per_wave * sys->max_row_blocks *
+                         bdg::kBlockSlots * sizeof(double2);
+    const size_t reduce = (size_t)bdg::kWavesPerBlock * rl * 2 * sizeof(double);
+    plan->lds_bytes = std::max(stage, reduce);
+    if (plan->lds_bytes > 160 * 1024)
+        return fail(BDG_EINVAL,
+                    "a block row with %d blocks needs %zu bytes of LDS per workgroup (limit 160 KiB)",
+                    sys->max_row_blocks, plan->lds_bytes);
+    if (plan->lds_bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan->kernel),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)plan->lds_bytes));
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
+        &per_cu, reinterpret_cast<const void*>(plan->kernel), bdg::kBlockThreads, plan->lds_bytes));
+    per_cu = std::max(1, std::min(per_cu, 8));
+    int grid = std::min(plan->n_tiles, per_cu * sys->num_cus);
+    plan->grid = std::max(8, (grid + 7) / 8 * 8);
+    return BDG_OK;
+}
+
+// Algorithmic HBM bytes of one recurrence launch: every stored block and index
+// once, and per (site, vector) one read of t_n, one read of t_{n-1}, one write
+// of t_{n+1} (260 nnzb + 4 (nb+1) + 192 R nb).
+double algorithmic_bytes(const bdg_system* sys, int vectors) {
+    return 260.0 * (double)sys->nnzb + 4.0 * (double)(sys->nb + 1) +
+           192.0 * (double)vectors * (double)sys->nb;
+}
+
+enum class StartKind { Random, Unit };
+
+struct StartSpec {
+    StartKind kind;
+    uint64_t seed = 0, first_id = 0;
+    int vec_kind = 0;
+    const int64_t* rows = nullptr;  // host
+};
+
+// Advance `n_active` (<= 64) vectors for n_steps; write d/e into columns
+// [col0, col0 + n_active) of the (n_steps x ld) host arrays.
+int run_batch(bdg_system* sys, double scale, int n_steps, int n_active, const StartSpec& start,
+              double* d_out, double* e_out, int ld, int col0, bool first_batch) {
+    int rl = next_pow2(n_active);
+    if (sys->lanes_override >= n_active)
+        rl = sys->lanes_override;
+    StepPlan plan;
+    if (int rc = make_plan(sys, rl, &plan)) return rc;
+
+    const size_t vec_count = (size_t)4 * sys->nb * rl;
+    if (int rc = sys->vec_a.reserve(vec_count)) return rc;
+    if (int rc = sys->vec_b.reserve(vec_count)) return rc;
+    const size_t width = (size_t)2 * rl;
+    // keep the partial buffer below 256 MiB by reducing in chunks of steps
+    const size_t per_step = (size_t)plan.grid * width;
+    int chunk = (int)std::max<size_t>(1, std::min<size_t>(n_steps, (32u << 20) / per_step));
+    if (int rc = sys->partial.reserve((size_t)chunk * per_step)) return rc;
+    if (int rc = sys->dots.reserve((size_t)n_steps * width)) return rc;
+
+    hipStream_t st = sys->stream;
+    const int fill_grid = (int)std::min<size_t>(4096, (vec_count + 255) / 256);
+    if (start.kind == StartKind::Random) {
+        bdg::fill_random<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, sys->nb, rl, n_active,
+                                                    start.seed, start.first_id, start.vec_kind);
+    } else {
+        if (int rc = sys->rows.reserve(64)) return rc;
+        HIP_TRY(hipMemcpyAsync(sys->rows.ptr, start.rows, sizeof(int64_t) * n_active,
+                               hipMemcpyHostToDevice, st));
+        bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, (int64_t)vec_count);
+        bdg::set_unit<<<1, 64, 0, st>>>(sys->vec_a.ptr, sys->nb, rl, n_active, sys->rows.ptr);
+    }
+    bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)vec_count);
+    HIP_TRY(hipGetLastError());
+
+    bdg::StepArgs args{};
+    args.indptr = sys->indptr.ptr;
+    args.indices = sys->indices.ptr;
+    args.blocks = sys->blocks.ptr;
+    args.nb = (int)sys->nb;
+    args.n_tiles = plan.n_tiles;
+    args.max_row_blocks = sys->max_row_blocks;
+
+    double2* cur = sys->vec_a.ptr;
+    double2* prev = sys->vec_b.ptr;
+    float total_ms = 0.f;
+    for (int s0 = 0; s0 < n_steps; s0 += chunk) {
+        const int s1 = std::min(n_steps, s0 + chunk);
+        HIP_TRY(hipEventRecord(sys->ev_start, st));
+        for (int n = s0; n < s1; ++n) {
+            args.cur = cur;
+            args.prev = prev;
+            args.coef = (n == 0 ? 1.0 : 2.0) / scale;
+            args.partial = sys->partial.ptr + (size_t)(n - s0) * per_step;
+            plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
+            std::swap(cur, prev);
+        }
+        HIP_TRY(hipEventRecord(sys->ev_stop, st));
+        bdg::reduce_partials<<<s1 - s0, (unsigned)std::max<size_t>(64, width), 0, st>>>(
+            sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, plan.grid, (int)width);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipEventSynchronize(sys->ev_stop));
+        float ms = 0.f;
+        HIP_TRY(hipEventElapsedTime(&ms, sys->ev_start, sys->ev_stop));
+        total_ms += ms;
+    }
+    std::vector<double> host((size_t)n_steps * width);
+    HIP_TRY(hipMemcpyAsync(host.data(), sys->dots.ptr, host.size() * sizeof(double),
+                           hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    for (int n = 0; n < n_steps; ++n)
+        for (int r = 0; r < n_active; ++r) {
+            d_out[(size_t)n * ld + col0 + r] = host[(size_t)n * width + 2 * r];
+            e_out[(size_t)n * ld + col0 + r] = host[(size_t)n * width + 2 * r + 1];
+        }
+
+    bdg_perf& p = sys->perf;
+    if (first_batch) p = bdg_perf{};
+    p.kernel_ms += total_ms;
+    p.launches += n_steps;
+    p.vector_steps += (int64_t)n_steps * n_active;
+    p.bytes_per_launch = algorithmic_bytes(sys, rl);
+    p.lanes_per_row = rl;
+    p.vectors_per_launch = rl;
+    p.grid = plan.grid;
+    p.lds_bytes = (int32_t)plan.lds_bytes;
+    return BDG_OK;
+}
+
+int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, StartSpec start,
+                   double* d_out, double* e_out) {
+    if (!sys) return fail(BDG_EINVAL, "null system handle");
+    if (!(scale > 0.0)) return fail(BDG_EINVAL, "scale must be positive");
+    if (n_steps < 1 || n_vectors < 1) return fail(BDG_EINVAL, "n_steps and n_vectors must be >= 1");
+    if (!d_out || !e_out) return fail(BDG_EINVAL, "null output buffer");
+    HIP_TRY(hipSetDevice(sys->device));
+    for (int col = 0; col < n_vectors; col += 64) {
+        const int n_active = std::min(64, n_vectors - col);
+        StartSpec batch = start;
+        if (start.kind == StartKind::Random) batch.first_id = start.first_id + col;
+        else batch.rows = start.rows + col;
+        if (int rc = run_batch(sys, scale, n_steps, n_active, batch, d_out, e_out, n_vectors, col,
+                               col == 0))
+            return rc;
+    }
+    return BDG_OK;
+}
+
+void dots_to_moments(const double* d, const double* e, int n_steps, int n_vectors, double* mu) {
+    // mu[m][r]; mu_2n = 2 d_n - mu_0, mu_2n+1 = 2 e_n - mu_1
+    for (int n = 0; n < n_steps; ++n)
+        for (int r = 0; r < n_vectors; ++r) {
+            const double d0 = d[r], e0 = e[r];
+            const double dn = d[(size_t)n * n_vectors + r], en = e[(size_t)n * n_vectors + r];
+            mu[(size_t)(2 * n) * n_vectors + r] = n == 0 ? d0 : 2.0 * dn - d0;
+            mu[(size_t)(2 * n + 1) * n_vectors + r] = n == 0 ? e0 : 2.0 * en - e0;
+        }
+}
+
+// ------------------------------------------------------------- lazy libraries
+struct SolverApi {
+    void* blas = nullptr;
+    void* solver = nullptr;
+    decltype(&rocblas_create_handle) create_handle = nullptr;
+    decltype(&rocblas_destroy_handle) destroy_handle = nullptr;
+    decltype(&rocblas_set_stream) set_stream = nullptr;
+    decltype(&rocsolver_zheevd) zheevd = nullptr;
+};
+
+int load_solver(SolverApi** out) {
+    static SolverApi api;
+    static bool tried = false, ok = false;
+    if (!tried) {
+        tried = true;
+        api.blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!api.blas) api.blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+        api.solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!api.solver) api.solver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        if (api.blas && api.solver) {
+            api.create_handle =
+                reinterpret_cast<decltype(api.create_handle)>(dlsym(api.blas, "rocblas_create_handle"));
+            api.destroy_handle =
+                reinterpret_cast<decltype(api.destroy_handle)>(dlsym(api.blas, "rocblas_destroy_handle"));
+            api.set_stream =
+                reinterpret_cast<decltype(api.set_stream)>(dlsym(api.blas, "rocblas_set_stream"));
+            api.zheevd = reinterpret_cast<decltype(api.zheevd)>(dlsym(api.solver, "rocsolver_zheevd"));
+            ok = api.create_handle && api.destroy_handle && api.set_stream && api.zheevd;
+        }
+    }
+    if (!ok) return fail(BDG_ELIBRARY, "rocSOLVER/rocBLAS could not be loaded: %s", dlerror());
+    *out = &api;
+    return BDG_OK;
+}
+
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+};
+
+int load_rccl(RcclApi** out) {
+    static RcclApi api;
+    static bool tried = false, ok = false;
+    if (!tried) {
+        tried = true;
+        api.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!api.lib) api.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!api.lib) api.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) {
+            api.get_unique_id =
+                reinterpret_cast<decltype(api.get_unique_id)>(dlsym(api.lib, "ncclGetUniqueId"));
+            api.comm_init_rank =
+                reinterpret_cast<decltype(api.comm_init_rank)>(dlsym(api.lib, "ncclCommInitRank"));
+            api.all_reduce = reinterpret_cast<decltype(api.all_reduce)>(dlsym(api.lib, "ncclAllReduce"));
+            api.comm_destroy =
+                reinterpret_cast<decltype(api.comm_destroy)>(dlsym(api.lib, "ncclCommDestroy"));
+            api.error_string =
+                reinterpret_cast<decltype(api.error_string)>(dlsym(api.lib, "ncclGetErrorString"));
+            ok = api.get_unique_id && api.comm_init_rank && api.all_reduce && api.comm_destroy &&
+                 api.error_string;
+        }
+    }
+    if (!ok) return fail(BDG_ELIBRARY, "RCCL could not be loaded: %s", dlerror());
+    *out = &api;
+    return BDG_OK;
+}
+
+#define NCCL_TRY(api, expr)                                                                  \
+    do {                                                                                     \
+        ncclResult_t res__ = (expr);                                                         \
+        if (res__ != ncclSuccess)                                                            \
+            return fail(BDG_ELIBRARY, "%s failed: %s", #expr, (api)->error_string(res__));   \
+    } while (0)
+
+int comm_allreduce(bdg_comm* comm, double* buf, int64_t count, ncclRedOp_t op) {
+    if (!comm || !buf || count < 0) return fail(BDG_EINVAL, "bad all-reduce arguments");
+    RcclApi* api = nullptr;
+    if (int rc = load_rccl(&api)) return rc;
+    HIP_TRY(hipSetDevice(comm->device));
+    if (int rc = comm->scratch.reserve((size_t)count)) return rc;
+    HIP_TRY(hipMemcpyAsync(comm->scratch.ptr, buf, sizeof(double) * count, hipMemcpyHostToDevice,
+                           comm->stream));
+    NCCL_TRY(api, api->all_reduce(comm->scratch.ptr, comm->scratch.ptr, (size_t)count, ncclDouble,
+                                  op, comm->comm, comm->stream));
+    HIP_TRY(hipMemcpyAsync(buf, comm->scratch.ptr, sizeof(double) * count, hipMemcpyDeviceToHost,
+                           comm->stream));
+    HIP_TRY(hipStreamSynchronize(comm->stream));
+    return BDG_OK;
+}
+
+}  // namespace
+
+// =========================================================================== ABI
+extern "C" {
+
+const char* bdg_last_error(void) { return g_error.c_str(); }
+const char* bdg_version(void) { return "bodge_hip 0.1 (gfx950)"; }
+
+int bdg_device_count(int* count) {
+    if (!count) return fail(BDG_EINVAL, "null count pointer");
+    int n = 0;
+    hipError_t err = hipGetDeviceCount(&n);
+    if (err != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    *count = n;
+    return BDG_OK;
+}
+
+int bdg_create(int device, int64_t nb, int64_t nnzb, const int32_t* indptr, const int32_t* indices,
+               const double* data, bdg_system** out) {
+    if (!out) return fail(BDG_EINVAL, "null output handle");
+    *out = nullptr;
+    if (nb < 1 || nnzb < 0 || !indptr || (nnzb > 0 && (!indices || !data)))
+        return fail(BDG_EINVAL, "bad matrix arguments (nb=%lld nnzb=%lld)", (long long)nb,
+                    (long long)nnzb);
+    if (nb > (1ll << 29) || nnzb > (1ll << 30))
+        return fail(BDG_EINVAL, "matrix too large for 32-bit block indexing");
+    if (indptr[0] != 0 || indptr[nb] != nnzb) return fail(BDG_EINVAL, "indptr does not span the blocks");
+    int max_row = 0;
+    for (int64_t i = 0; i < nb; ++i)
+        if (indptr[i + 1] < indptr[i] || indptr[i + 1] > nnzb)
+            return fail(BDG_EINVAL, "indptr is not monotone within [0, nnzb] at row %lld", (long long)i);
+    for (int64_t i = 0; i < nb; ++i) {
+        const int len = indptr[i + 1] - indptr[i];
+        max_row = std::max(max_row, len);
+        for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
+            if (indices[k] < 0 || indices[k] >= nb)
+                return fail(BDG_EINVAL, "column index %d out of range in row %lld", indices[k],
+                            (long long)i);
+            if (k > indptr[i] && indices[k] <= indices[k - 1])
+                return fail(BDG_EINVAL, "row %lld is not sorted / has duplicates", (long long)i);
+        }
+    }
+    int n_dev = 0;
+    if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
+        (void)hipGetLastError();
+        return fail(BDG_EDEVICE, "no HIP device is visible");
+    }
+    if (device < 0 || device >= n_dev) return fail(BDG_EINVAL, "device %d out of range", device);
+    HIP_TRY(hipSetDevice(device));
+
+    bdg_system* sys = new bdg_system();
+    sys->device = device;
+    sys->nb = nb;
+    sys->nnzb = nnzb;
+    sys->max_row_blocks = std::max(1, max_row);
+    hipDeviceProp_t prop;
+    auto cleanup = [&](int rc) {
+        bdg_destroy(sys);
+        return rc;
+    };
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess)
+        return cleanup(fail(BDG_EDEVICE, "hipGetDeviceProperties failed"));
+    sys->num_cus = prop.multiProcessorCount;
+    if (hipStreamCreateWithFlags(&sys->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&sys->ev_start) != hipSuccess || hipEventCreate(&sys->ev_stop) != hipSuccess)
+        return cleanup(fail(BDG_EDEVICE, "stream/event creation failed"));
+    if (int rc = sys->indptr.reserve((size_t)nb + 1)) return cleanup(rc);
+    if (int rc = sys->indices.reserve((size_t)std::max<int64_t>(1, nnzb))) return cleanup(rc);
+    if (int rc = sys->blocks.reserve((size_t)std::max<int64_t>(1, nnzb) * 16)) return cleanup(rc);
+    if (hipMemcpy(sys->indptr.ptr, indptr, sizeof(int) * (nb + 1), hipMemcpyHostToDevice) != hipSuccess ||
+        (nnzb > 0 &&
+         (hipMemcpy(sys->indices.ptr, indices, sizeof(int) * nnzb, hipMemcpyHostToDevice) != hipSuccess ||
+          hipMemcpy(sys->blocks.ptr, data, sizeof(double2) * 16 * nnzb, hipMemcpyHostToDevice) !=
+              hipSuccess)))
+        return cleanup(fail(BDG_EDEVICE, "upload of the BSR arrays failed"));
+    *out = sys;
+    return BDG_OK;
+}
+
+int bdg_destroy(bdg_system* sys) {
+    if (!sys) return BDG_OK;
+    (void)hipSetDevice(sys->device);
+    if (sys->stream) (void)hipStreamSynchronize(sys->stream);
+    sys->indptr.release();
+    sys->indices.release();
+    sys->blocks.release();
+    sys->vec_a.release();
+    sys->vec_b.release();
+    sys->partial.release();
+    sys->dots.release();
+    sys->rows.release();
+    if (sys->ev_start) (void)hipEventDestroy(sys->ev_start);
+    if (sys->ev_stop) (void)hipEventDestroy(sys->ev_stop);
+    if (sys->stream) (void)hipStreamDestroy(sys->stream);
+    delete sys;
+    return BDG_OK;
+}
+
+int bdg_set_lanes_per_row(bdg_system* sys, int32_t lanes) {
+    if (!sys) return fail(BDG_EINVAL, "null system handle");
+    if (lanes != 0 && !step_kernel(lanes)) return fail(BDG_EINVAL, "lanes must be a power of two <= 64");
+    sys->lanes_override = lanes;
+    return BDG_OK;
+}
+
+int bdg_spmv(bdg_system* sys, const double* x, double* y) {
+    if (!sys || !x || !y) return fail(BDG_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(sys->device));
+    StepPlan plan;
+    if (int rc = make_plan(sys, 1, &plan)) return rc;
+    const size_t n = (size_t)4 * sys->nb;
+    if (int rc = sys->vec_a.reserve(n)) return rc;
+    if (int rc = sys->vec_b.reserve(n)) return rc;
+    if (int rc = sys->partial.reserve((size_t)plan.grid * 2)) return rc;
+    DeviceBuffer<double2> host_order;
+    if (int rc = host_order.reserve(n)) return rc;
+    hipStream_t st = sys->stream;
+    const int grid = (int)std::min<size_t>(4096, (n + 255) / 256);
+    int rc = BDG_OK;
+    auto body = [&]() -> int {
+        HIP_TRY(hipMemcpyAsync(host_order.ptr, x, sizeof(double2) * n, hipMemcpyHostToDevice, st));
+        bdg::planar_from_sitemajor<<<grid, 256, 0, st>>>(host_order.ptr, sys->vec_a.ptr, sys->nb, 1, 0);
+        bdg::fill_zero<<<grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)n);
+        bdg::StepArgs args{};
+        args.indptr = sys->indptr.ptr;
+        args.indices = sys->indices.ptr;
+        args.blocks = sys->blocks.ptr;
+        args.cur = sys->vec_a.ptr;
+        args.prev = sys->vec_b.ptr;
+        args.partial = sys->partial.ptr;
+        args.coef = 1.0;
+        args.nb = (int)sys->nb;
+        args.n_tiles = plan.n_tiles;
+        args.max_row_blocks = sys->max_row_blocks;
+        plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
+        bdg::sitemajor_from_planar<<<grid, 256, 0, st>>>(sys->vec_b.ptr, host_order.ptr, sys->nb, 1, 0);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(y, host_order.ptr, sizeof(double2) * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        return BDG_OK;
+    };
+    rc = body();
+    host_order.release();
+    return rc;
+}
+
+int bdg_cheb_dots_random(bdg_system* sys, double scale, int32_t n_steps, int32_t n_vectors,
+                         uint64_t seed, uint64_t first_vec_id, int32_t vec_kind, double* d_out,
+                         double* e_out) {
+    if (vec_kind != BDG_VEC_RADEMACHER && vec_kind != BDG_VEC_Z4)
+        return fail(BDG_EINVAL, "unknown start-vector kind %d", vec_kind);
+    StartSpec start{StartKind::Random};
+    start.seed = seed;
+    start.first_id = first_vec_id;
+    start.vec_kind = vec_kind;
+    return run_recurrence(sys, scale, n_steps, n_vectors, start, d_out, e_out);
+}
+
+int bdg_cheb_dots_unit(bdg_system* sys, double scale, int32_t n_steps, int32_t n_vectors,
+                       const int64_t* rows, double* d_out, double* e_out) {
+    if (!sys) return fail(BDG_EINVAL, "null system handle");
+    if (!rows) return fail(BDG_EINVAL, "null rows pointer");
+    for (int r = 0; r < n_vectors; ++r)
+        if (rows[r] < 0 || rows[r] >= 4 * sys->nb)
+            return fail(BDG_EINVAL, "start row %lld out of range", (long long)rows[r]);
+    StartSpec start{StartKind::Unit};
+    start.rows = rows;
+    return run_recurrence(sys, scale, n_steps, n_vectors, start, d_out, e_out);
+}
+
+int bdg_cheb_moments(bdg_system* sys, bdg_comm* comm, double scale, int32_t n_moments,
+                     int32_t n_vectors, uint64_t seed, uint64_t first_vec_id, int32_t vec_kind,
+                     double* mu_out) {
+    if (n_moments < 2 || (n_moments & 1)) return fail(BDG_EINVAL, "n_moments must be even and >= 2");
+    if (!mu_out) return fail(BDG_EINVAL, "null output buffer");
+    const int n_steps = n_moments / 2;
+    std::vector<double> d((size_t)n_steps * n_vectors), e(d.size()), mu((size_t)n_moments * n_vectors);
+    if (int rc = bdg_cheb_dots_random(sys, scale, n_steps, n_vectors, seed, first_vec_id, vec_kind,
+                                      d.data(), e.data()))
+        return rc;
+    dots_to_moments(d.data(), e.data(), n_steps, n_vectors, mu.data());
+    for (int m = 0; m < n_moments; ++m) {
+        double tot = 0.0;
+        for (int r = 0; r < n_vectors; ++r) tot += mu[(size_t)m * n_vectors + r];
+        mu_out[m] = tot;
+    }
+    if (comm) return comm_allreduce(comm, mu_out, n_moments, ncclSum);
+    return BDG_OK;
+}
+
+int bdg_cheb_diag_moments(bdg_system* sys, double scale, int32_t n_moments, int32_t n_vectors,
+                          const int64_t* rows, double* mu_out) {
+    if (n_moments < 2 || (n_moments & 1)) return fail(BDG_EINVAL, "n_moments must be even and >= 2");
+    if (!mu_out) return fail(BDG_EINVAL, "null output buffer");
+    const int n_steps = n_moments / 2;
+    std::vector<double> d((size_t)n_steps * n_vectors), e(d.size());
+    if (int rc = bdg_cheb_dots_unit(sys, scale, n_steps, n_vectors, rows, d.data(), e.data())) return rc;
+    dots_to_moments(d.data(), e.data(), n_steps, n_vectors, mu_out);
+    return BDG_OK;
+}
+
+int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t vec_kind,
+                      double* v_out) {
+    if (!sys || !v_out) return fail(BDG_EINVAL, "null argument");
+    if (vec_kind != BDG_VEC_RADEMACHER && vec_kind != BDG_VEC_Z4)
+        return fail(BDG_EINVAL, "unknown start-vector kind %d", vec_kind);
+    HIP_TRY(hipSetDevice(sys->device));
+    const size_t n = (size_t)4 * sys->nb;
+    if (int rc = sys->vec_a.reserve(n)) return rc;
+    DeviceBuffer<double2> host_order;
+    if (int rc = host_order.reserve(n)) return rc;
+    const int grid = (int)std::min<size_t>(4096, (n + 255) / 256);
+    auto body = [&]() -> int {
+        bdg::fill_random<<<grid, 256, 0, sys->stream>>>(sys->vec_a.ptr, sys->nb, 1, 1, seed, vec_id,
+                                                        vec_kind);
+        bdg::sitemajor_from_planar<<<grid, 256, 0, sys->stream>>>(sys->vec_a.ptr, host_order.ptr,
+                                                                  sys->nb, 1, 0);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(v_out, host_order.ptr, sizeof(double2) * n, hipMemcpyDeviceToHost,
+                               sys->stream));
+        HIP_TRY(hipStreamSynchronize(sys->stream));
+        return BDG_OK;
+    };
+    int rc = body();
+    host_order.release();
+    return rc;
+}
+
+int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
+    if (!sys || !w_out) return fail(BDG_EINVAL, "null argument");
+    HIP_TRY(hipSetDevice(sys->device));
+    SolverApi* api = nullptr;
+    if (int rc = load_solver(&api)) return rc;
+    const int64_t n = 4 * sys->nb;
+    if (n > 46000) return fail(BDG_EINVAL, "dense path limited to 4*nb <= 46000 (32-bit LAPACK sizes)");
+    DeviceBuffer<double2> dense;
+    DeviceBuffer<double> eig, offdiag;
+    DeviceBuffer<int> info;
+    rocblas_handle handle = nullptr;
+    auto body = [&]() -> int {
+        if (int rc = dense.reserve((size_t)n * n)) return rc;
+        if (int rc = eig.reserve((size_t)n)) return rc;
+        if (int rc = offdiag.reserve((size_t)n)) return rc;
+        if (int rc = info.reserve(1)) return rc;
+        HIP_TRY(hipMemsetAsync(dense.ptr, 0, sizeof(double2) * n * n, sys->stream));
+        bdg::scatter_dense<<<(unsigned)sys->nb, 128, 0, sys->stream>>>(
+            sys->indptr.ptr, sys->indices.ptr, sys->blocks.ptr, dense.ptr, (int)sys->nb);
+        HIP_TRY(hipGetLastError());
+        if (api->create_handle(&handle) != rocblas_status_success)
+            return fail(BDG_ELIBRARY, "rocblas_create_handle failed");
+        if (api->set_stream(handle, sys->stream) != rocblas_status_success)
+            return fail(BDG_ELIBRARY, "rocblas_set_stream failed");
+        rocblas_status st = api->zheevd(
+            handle, z_out ? rocblas_evect_original : rocblas_evect_none, rocblas_fill_lower,
+            (rocblas_int)n, reinterpret_cast<rocblas_double_complex*>(dense.ptr), (rocblas_int)n,
+            eig.ptr, offdiag.ptr, info.ptr);
+        if (st != rocblas_status_success) return fail(BDG_ELIBRARY, "rocsolver_zheevd returned %d", (int)st);
+        int host_info = 0;
+        HIP_TRY(hipMemcpyAsync(&host_info, info.ptr, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
+        HIP_TRY(hipMemcpyAsync(w_out, eig.ptr, sizeof(double) * n, hipMemcpyDeviceToHost, sys->stream));
+        if (z_out)
+            HIP_TRY(hipMemcpyAsync(z_out, dense.ptr, sizeof(double2) * n * n, hipMemcpyDeviceToHost,
+                                   sys->stream));
+        HIP_TRY(hipStreamSynchronize(sys->stream));
+        if (host_info != 0) return fail(BDG_ELIBRARY, "zheevd did not converge (info=%d)", host_info);
+        return BDG_OK;
+    };
+    int rc = body();
+    if (handle) api->destroy_handle(handle);
+    dense.release();
+    eig.release();
+    offdiag.release();
+    info.release();
+    return rc;
+}
+
+int bdg_perf_query(bdg_system* sys, bdg_perf* out) {
+    if (!sys || !out) return fail(BDG_EINVAL, "null argument");
+    *out = sys->perf;
+    return BDG_OK;
+}
+
+int bdg_comm_unique_id(uint8_t id_out[128]) {
+    if (!id_out) return fail(BDG_EINVAL, "null id buffer");
+    RcclApi* api = nullptr;
+    if (int rc = load_rccl(&api)) return rc;
+    static_assert(sizeof(ncclUniqueId) == 128, "ncclUniqueId is expected to be 128 bytes");
+    ncclUniqueId id;
+    NCCL_TRY(api, api->get_unique_id(&id));
+    memcpy(id_out, &id, 128);
+    return BDG_OK;
+}
+
+int bdg_comm_init(int device, const uint8_t id[128], int32_t n_ranks, int32_t rank, bdg_comm** out) {
+    if (!id || !out || n_ranks < 1 || rank < 0 || rank >= n_ranks)
+        return fail(BDG_EINVAL, "bad communicator arguments");
+    *out = nullptr;
+    RcclApi* api = nullptr;
+    if (int rc = load_rccl(&api)) return rc;
+    HIP_TRY(hipSetDevice(device));
+    bdg_comm* comm = new bdg_comm();
+    comm->device = device;
+    comm->n_ranks = n_ranks;
+    comm->rank = rank;
+    ncclUniqueId uid;
+    memcpy(&uid, id, 128);
+    if (hipStreamCreateWithFlags(&comm->stream, hipStreamNonBlocking) != hipSuccess) {
+        delete comm;
+        return fail(BDG_EDEVICE, "stream creation failed");
+    }
+    ncclResult_t res = api->comm_init_rank(&comm->comm, n_ranks, uid, rank);
+    if (res != ncclSuccess) {
+        (void)hipStreamDestroy(comm->stream);
+        delete comm;
+        return fail(BDG_ELIBRARY, "ncclCommInitRank failed: %s", api->error_string(res));
+    }
+    *out = comm;
+    return BDG_OK;
+}
+
+int bdg_comm_allreduce_sum(bdg_comm* comm, double* buf, int64_t count) {
+    return comm_allreduce(comm, buf, count, ncclSum);
+}
+
+int bdg_comm_allreduce_max(bdg_comm* comm, double* buf, int64_t count) {
+    return comm_allreduce(comm, buf, count, ncclMax);
+}
+
+int bdg_comm_destroy(bdg_comm* comm) {
+    if (!comm) return BDG_OK;
+    RcclApi* api = nullptr;
+    (void)hipSetDevice(comm->device);
+    if (load_rccl(&api) == BDG_OK && comm->comm) (void)api->comm_destroy(comm->comm);
+    comm->scratch.release();
+    if (comm->stream) (void)hipStreamDestroy(comm->stream);
+    delete comm;
+    return BDG_OK;
+}
+
+}  // extern "C"

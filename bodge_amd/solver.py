@@ -1,0 +1,233 @@
+"""Device-resident Hamiltonian: thin object wrapper over the C ABI handle.
+
+`DeviceSolver` owns one `bdg_system*` (one BSR matrix in the HBM of one GPU).
+`Communicator` owns one RCCL rank.  All numerics happen inside the library;
+this module only marshals numpy buffers.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import time
+
+import numpy as np
+
+from . import backend
+from .backend import VEC_RADEMACHER, VEC_Z4  # noqa: F401  (re-exported)
+
+
+class DeviceSolver:
+    def __init__(self, indptr, indices, data, device: int | None = None):
+        lib = backend.load()
+        backend.require_device()
+        if device is None:
+            device = int(os.environ.get("BODGE_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+            device %= backend.device_count()
+        indptr = np.ascontiguousarray(indptr, dtype=np.int32)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        data = np.ascontiguousarray(data, dtype=np.complex128)
+        self.n_sites = int(indptr.size - 1)
+        self.n_blocks = int(indices.size)
+        self.dim = 4 * self.n_sites
+        self.device = device
+        if data.size != 16 * self.n_blocks:
+            raise ValueError("block data does not match the index arrays")
+        self._lib = lib
+        self._handle = C.c_void_p()
+        backend.check(
+            lib.bdg_create(
+                device, self.n_sites, self.n_blocks, backend.as_i32p(indptr), backend.as_i32p(indices),
+                backend.as_f64p(data.view(np.float64)), C.byref(self._handle),
+            )
+        )
+
+    @classmethod
+    def from_hamiltonian(cls, system, device: int | None = None, drop_zero_blocks: bool = True):
+        indptr, indices, data = system.bsr_arrays(drop_zero_blocks=drop_zero_blocks)
+        return cls(indptr, indices, data, device=device)
+
+    # ------------------------------------------------------------------ lifetime
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle:
+            self._lib.bdg_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    # ------------------------------------------------------------------- kernels
+    def spmv(self, x: np.ndarray) -> np.ndarray:
+        x = np.ascontiguousarray(x, dtype=np.complex128).reshape(-1)
+        if x.size != self.dim:
+            raise ValueError(f"expected a vector of {self.dim} entries")
+        y = np.empty_like(x)
+        backend.check(
+            self._lib.bdg_spmv(self._handle, backend.as_f64p(x.view(np.float64)),
+                               backend.as_f64p(y.view(np.float64)))
+        )
+        return y
+
+    def random_vector(self, seed: int, vec_id: int, kind: int = VEC_RADEMACHER) -> np.ndarray:
+        v = np.empty(self.dim, dtype=np.complex128)
+        backend.check(
+            self._lib.bdg_random_vector(self._handle, seed, vec_id, kind, backend.as_f64p(v.view(np.float64)))
+        )
+        return v
+
+    def dots_random(self, scale, n_steps, n_vectors, seed=0, first_id=0, kind=VEC_RADEMACHER):
+        d = np.empty((n_steps, n_vectors))
+        e = np.empty((n_steps, n_vectors))
+        backend.check(
+            self._lib.bdg_cheb_dots_random(
+                self._handle, float(scale), n_steps, n_vectors, seed, first_id, kind,
+                backend.as_f64p(d), backend.as_f64p(e),
+            )
+        )
+        return d, e
+
+    def dots_unit(self, scale, n_steps, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        d = np.empty((n_steps, rows.size))
+        e = np.empty((n_steps, rows.size))
+        backend.check(
+            self._lib.bdg_cheb_dots_unit(
+                self._handle, float(scale), n_steps, rows.size, backend.as_i64p(rows),
+                backend.as_f64p(d), backend.as_f64p(e),
+            )
+        )
+        return d, e
+
+    def moments_random(self, scale, n_moments, n_vectors, seed=0, first_id=0, kind=VEC_RADEMACHER,
+                       comm: "Communicator | None" = None) -> np.ndarray:
+        """Σ_r <v_r|T_m(H/scale)|v_r> for m < n_moments (summed over ranks if `comm`)."""
+        mu = np.empty(n_moments)
+        backend.check(
+            self._lib.bdg_cheb_moments(
+                self._handle, comm._handle if comm is not None else None, float(scale), n_moments,
+                n_vectors, seed, first_id, kind, backend.as_f64p(mu),
+            )
+        )
+        return mu
+
+    def moments_unit(self, scale, n_moments, rows) -> np.ndarray:
+        """(n_moments, len(rows)) array of <e_row|T_m(H/scale)|e_row>."""
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        mu = np.empty((n_moments, rows.size))
+        backend.check(
+            self._lib.bdg_cheb_diag_moments(
+                self._handle, float(scale), n_moments, rows.size, backend.as_i64p(rows), backend.as_f64p(mu)
+            )
+        )
+        return mu
+
+    def eigh(self, vectors: bool = True):
+        """All eigenvalues ascending (and eigenvectors as columns) from rocSOLVER zheevd."""
+        w = np.empty(self.dim)
+        if not vectors:
+            backend.check(self._lib.bdg_eigh_dense(self._handle, backend.as_f64p(w), None))
+            return w, None
+        z = np.empty((self.dim, self.dim), dtype=np.complex128)  # column-major on return
+        backend.check(
+            self._lib.bdg_eigh_dense(self._handle, backend.as_f64p(w), backend.as_f64p(z.view(np.float64)))
+        )
+        return w, z.T
+
+    def set_lanes_per_row(self, lanes: int) -> None:
+        backend.check(self._lib.bdg_set_lanes_per_row(self._handle, lanes))
+
+    def perf(self) -> dict:
+        rec = backend.Perf()
+        backend.check(self._lib.bdg_perf_query(self._handle, C.byref(rec)))
+        return {name: getattr(rec, name) for name, _ in backend.Perf._fields_}
+
+
+# ---------------------------------------------------------------------------
+class Communicator:
+    """One RCCL rank.  The 128-byte unique id travels through a rendezvous file."""
+
+    def __init__(self, rank: int, n_ranks: int, device: int, unique_id: bytes):
+        lib = backend.load()
+        self._lib = lib
+        self.rank, self.n_ranks, self.device = rank, n_ranks, device
+        self._handle = C.c_void_p()
+        buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        backend.check(lib.bdg_comm_init(device, buf, n_ranks, rank, C.byref(self._handle)))
+
+    @staticmethod
+    def new_unique_id() -> bytes:
+        buf = (C.c_uint8 * 128)()
+        backend.check(backend.load().bdg_comm_unique_id(buf))
+        return bytes(buf)
+
+    @classmethod
+    def from_environment(cls, timeout: float = 300.0) -> "Communicator | None":
+        """Build the communicator of a `torch.distributed.run`-style launch.
+
+        Uses RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT.  Rank 0 publishes the
+        RCCL unique id in a file named after the launcher's pid and the master
+        port (both shared by all ranks of one launch); the others poll for it.
+        Returns None for a single-process run.
+        """
+        world = int(os.environ.get("WORLD_SIZE", "1"))
+        if world <= 1:
+            return None
+        rank = int(os.environ["RANK"])
+        local = int(os.environ.get("LOCAL_RANK", rank))
+        tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+        path = os.path.join(os.environ.get("BODGE_AMD_RDZV_DIR", "/tmp"), f"bodge_amd_rccl_{tag}.id")
+        if rank == 0:
+            uid = cls.new_unique_id()
+            tmp = f"{path}.{os.getpid()}.tmp"
+            with open(tmp, "wb") as fh:
+                fh.write(uid)
+            os.replace(tmp, path)
+        else:
+            deadline = time.time() + timeout
+            while not (os.path.exists(path) and os.path.getsize(path) == 128):
+                if time.time() > deadline:
+                    raise RuntimeError(f"rank {rank}: timed out waiting for the RCCL id at {path}")
+                time.sleep(0.05)
+            with open(path, "rb") as fh:
+                uid = fh.read()
+        comm = cls(rank, world, local, uid)
+        comm.barrier()
+        if rank == 0:
+            try:
+                os.unlink(path)
+            except OSError:
+                pass
+        return comm
+
+    def allreduce_sum(self, values: np.ndarray) -> np.ndarray:
+        out = np.ascontiguousarray(values, dtype=np.float64).copy()
+        backend.check(self._lib.bdg_comm_allreduce_sum(self._handle, backend.as_f64p(out), out.size))
+        return out
+
+    def allreduce_max(self, values: np.ndarray) -> np.ndarray:
+        out = np.ascontiguousarray(values, dtype=np.float64).copy()
+        backend.check(self._lib.bdg_comm_allreduce_max(self._handle, backend.as_f64p(out), out.size))
+        return out
+
+    def barrier(self) -> None:
+        self.allreduce_sum(np.zeros(1))
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle:
+            self._lib.bdg_comm_destroy(self._handle)
+            self._handle = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,141 @@
+/*
+ * bodge_hip.h - C ABI of the MI355X (gfx950) BdG solver library `libbodge_hip.so`.
+ *
+ * The reference package is pure Python and has no FFI layer; its accelerator
+ * seam is the `cuda: bool` switch inside three Hamiltonian methods, each of
+ * which hands ONE matrix to a GPU library call and takes arrays back:
+ *
+ *   free_energy()  bodge/hamiltonian.py:282-302  (dense eigvalsh; CuPy at :291-295)
+ *   diagonalize()  bodge/hamiltonian.py:203-232  (dense eigh;     CuPy at :210-221)
+ *   ldos()         bodge/hamiltonian.py:342-382  (sparse LU resolvent per energy)
+ *
+ * and the matrix they consume is the BSR triple built at :37-67 / :102-118
+ * (4x4 complex128 blocks, int32 indices/indptr).  The entry points below are
+ * what a ctypes binding placed at those call sites would bind: upload the BSR
+ * triple once, then ask for Chebyshev dot products / moments (free energy,
+ * LDOS) or for a dense Hermitian eigensolve (diagonalize, small free_energy).
+ *
+ * Conventions: every pointer is a caller-owned host buffer unless stated; the
+ * library copies to and from HBM.  Complex numbers are interleaved (re, im)
+ * doubles, i.e. numpy complex128.  Every function returns 0 on success or a
+ * negative BDG_E* code; `bdg_last_error()` then describes the failure (thread
+ * local).  No callbacks, no exceptions, one host thread per handle.
+ */
+#ifndef BODGE_HIP_H
+#define BODGE_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define BDG_OK 0
+#define BDG_EINVAL (-1)   /* bad argument (shape, range, null pointer)      */
+#define BDG_EDEVICE (-2)  /* HIP runtime error / no usable GPU              */
+#define BDG_ENOMEM (-3)   /* device allocation failed                       */
+#define BDG_ELIBRARY (-4) /* rocSOLVER / RCCL could not be loaded or failed */
+
+/* start-vector kinds for the stochastic trace (counter-based) */
+#define BDG_VEC_RADEMACHER 0 /* entries +1 / -1                  */
+#define BDG_VEC_Z4 1         /* entries in {1, i, -1, -i}        */
+
+typedef struct bdg_system bdg_system; /* one uploaded Hamiltonian on one GPU */
+typedef struct bdg_comm bdg_comm;     /* one RCCL communicator rank          */
+
+/* Performance record of the most recent Chebyshev call on a handle. */
+typedef struct bdg_perf {
+    double kernel_ms;      /* HIP-event time around the recurrence launches          */
+    int64_t launches;      /* number of recurrence-kernel launches in that window    */
+    int64_t vector_steps;  /* launches x vectors advanced per launch                 */
+    double bytes_per_launch; /* algorithmic HBM bytes of one launch      */
+    int32_t lanes_per_row; /* kernel configuration actually used                     */
+    int32_t vectors_per_launch;
+    int32_t grid;          /* workgroups per launch                                  */
+    int32_t lds_bytes;     /* dynamic LDS per workgroup                              */
+} bdg_perf;
+
+const char* bdg_last_error(void);
+const char* bdg_version(void);
+
+/* Number of visible HIP devices (0 is a valid answer and not an error). */
+int bdg_device_count(int* count);
+
+/*
+ * Upload a BSR matrix with 4x4 complex128 blocks (replaces the host->device
+ * copy `cp.asarray(H)` of hamiltonian.py:214 / :295, but for the sparse form).
+ *   nb      number of block rows (lattice sites)
+ *   nnzb    number of stored blocks
+ *   indptr  int32[nb+1], indices int32[nnzb] (column block per stored block)
+ *   data    double[nnzb*32]: blocks in C order data[k][row][col] (re, im)
+ * The triple must be canonical (sorted, no duplicates); validated on the host.
+ */
+int bdg_create(int device, int64_t nb, int64_t nnzb, const int32_t* indptr,
+               const int32_t* indices, const double* data, bdg_system** out);
+int bdg_destroy(bdg_system* sys);
+
+/* y = H x for one host vector of 4*nb complex entries (site-major, the order
+ * of `H @ x` on the reference's matrix).  For parity tests. */
+int bdg_spmv(bdg_system* sys, const double* x, double* y);
+
+/*
+ * Chebyshev recurrence on `n_vectors` start vectors advanced together:
+ *   t_0 = v,  t_1 = H t_0 / scale,  t_{n+1} = 2 H t_n / scale - t_{n-1}
+ *   d[n*n_vectors + r] = <t_n|t_n>,  e[n*n_vectors + r] = Re <t_{n+1}|t_n>,  n < n_steps
+ * `scale` must bound the spectrum of H.  Random start vectors are generated on
+ * the device from (seed, first_vec_id + r, element index); unit start vectors
+ * are e_{rows[r]} (rows index the 4*nb scalar rows).
+ */
+int bdg_cheb_dots_random(bdg_system* sys, double scale, int32_t n_steps, int32_t n_vectors,
+                         uint64_t seed, uint64_t first_vec_id, int32_t vec_kind,
+                         double* d_out, double* e_out);
+int bdg_cheb_dots_unit(bdg_system* sys, double scale, int32_t n_steps, int32_t n_vectors,
+                       const int64_t* rows, double* d_out, double* e_out);
+
+/*
+ * Moments mu_m = sum_r <v_r|T_m(H/scale)|v_r>, m < n_moments (even), from the
+ * dots above via mu_2n = 2 d_n - mu_0, mu_2n+1 = 2 e_n - mu_1.  If `comm` is
+ * non-null the moment vector is summed over all ranks with one RCCL
+ * all-reduce before it is returned (each rank passes its own first_vec_id).
+ */
+int bdg_cheb_moments(bdg_system* sys, bdg_comm* comm, double scale, int32_t n_moments,
+                     int32_t n_vectors, uint64_t seed, uint64_t first_vec_id, int32_t vec_kind,
+                     double* mu_out);
+/* Per-start-vector moments for unit vectors: mu_out[m*n_vectors + r]. */
+int bdg_cheb_diag_moments(bdg_system* sys, double scale, int32_t n_moments, int32_t n_vectors,
+                          const int64_t* rows, double* mu_out);
+
+/* Write the counter-based start vector (4*nb complex entries) to a host buffer. */
+int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t vec_kind,
+                      double* v_out);
+
+/*
+ * Dense Hermitian eigensolve of the uploaded matrix on the GPU (replaces
+ * cupy.linalg.eigvalsh / eigh at hamiltonian.py:295 / :215): all 4*nb
+ * eigenvalues ascending in w_out; if z_out is non-null it receives the
+ * eigenvectors in column-major (Fortran) order: eigenvector n occupies the
+ * 4nb complex entries starting at z_out[2*n*4nb].
+ */
+int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out);
+
+int bdg_perf_query(bdg_system* sys, bdg_perf* out);
+
+/* Tuning override for experiments: lanes per block row (0 = automatic). */
+int bdg_set_lanes_per_row(bdg_system* sys, int32_t lanes);
+
+/*
+ * RCCL communicator, one rank per process/GPU.  Rank 0 calls
+ * bdg_comm_unique_id and distributes the 128 bytes out of band; every rank
+ * then calls bdg_comm_init with the same bytes.
+ */
+int bdg_comm_unique_id(uint8_t id_out[128]);
+int bdg_comm_init(int device, const uint8_t id[128], int32_t n_ranks, int32_t rank,
+                  bdg_comm** out);
+int bdg_comm_allreduce_sum(bdg_comm* comm, double* buf, int64_t count);
+int bdg_comm_allreduce_max(bdg_comm* comm, double* buf, int64_t count);
+int bdg_comm_destroy(bdg_comm* comm);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BODGE_HIP_H */

@@ -1,0 +1,57 @@
+"""pytest configuration: markers, import path, golden fixtures."""
+
+import json
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for path in (ROOT, os.path.join(ROOT, "tests")):
+    if path not in sys.path:
+        sys.path.insert(0, path)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
+
+
+class Golden:
+    """Values recorded from the reference by tests/golden/make_golden.py."""
+
+    def __init__(self):
+        here = os.path.join(ROOT, "tests", "golden")
+        with open(os.path.join(here, "reference_values.json")) as fh:
+            self.values = json.load(fh)
+        self.arrays = np.load(os.path.join(here, "reference_arrays.npz"))
+
+    def free_energy(self, name, temperature):
+        return self.values[name]["free_energy"][repr(float(temperature))]
+
+    def eigenvalues(self, name):
+        return self.arrays[f"{name}/eigenvalues"]
+
+    def ldos(self, name, n):
+        return self.arrays[f"{name}/ldos{n}"]
+
+
+@pytest.fixture(scope="session")
+def golden():
+    return Golden()
+
+
+@pytest.fixture(scope="session")
+def api():
+    import bodge_amd
+
+    return bodge_amd
+
+
+@pytest.fixture(scope="session")
+def hip_library():
+    """Build (if stale) and load the HIP library; used by CPU ABI tests and all GPU tests."""
+    from bodge_amd import backend, build
+
+    build.build_library()
+    return backend.load()

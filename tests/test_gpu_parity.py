@@ -1,0 +1,231 @@
+"""GPU parity: the HIP path (through the C ABI) against the CPU oracle and the goldens.
+
+Tolerances (fp64 throughout):
+* SpMV and start vectors        bit-level / 1e-13 relative
+* recurrence dots, per moment   1e-12 relative to μ_0
+* free energy                   1e-10 relative, vs goldens where (T, M) supports it
+* eigenvalues                   1e-10 absolute (pattern of ref tests/test_hamiltonian.py:411-413)
+"""
+
+import numpy as np
+import pytest
+
+import systems
+from oracle import cheb_ref, dense_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver_cls(hip_library):
+    from bodge_amd.solver import DeviceSolver
+
+    return DeviceSolver
+
+
+def _build(api, name):
+    spec = systems.CATALOG[name]
+    return spec["build"](api, **spec["kwargs"])
+
+
+# ----------------------------------------------------------------------- SpMV
+@pytest.mark.parametrize("name", ["random357", "complex235", "dwave8", "swave20", "chain128"])
+def test_spmv_matches_scipy(api, solver_cls, name):
+    system = _build(api, name)
+    bsr = system.matrix("bsr")
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(bsr.shape[0]) + 1j * rng.standard_normal(bsr.shape[0])
+    with solver_cls.from_hamiltonian(system) as dev:
+        y = dev.spmv(x)
+    ref = bsr @ x
+    assert np.allclose(y, ref, rtol=1e-13, atol=1e-13 * np.abs(ref).max())
+
+
+def test_spmv_keeps_explicit_zero_blocks_and_empty_rows(api, solver_cls):
+    """Skeleton upload (zero blocks kept) and a matrix with empty block rows."""
+    system = _build(api, "swave20")
+    x = np.arange(system.shape[0], dtype=float) * (1 + 0.5j)
+    with solver_cls.from_hamiltonian(system, drop_zero_blocks=False) as dev:
+        assert dev.n_blocks == system._matrix.indices.size
+        assert np.allclose(dev.spmv(x), system._matrix @ x, rtol=1e-13)
+    indptr = np.array([0, 0, 1, 1, 3], dtype=np.int32)  # rows 0 and 2 are empty
+    indices = np.array([3, 0, 1], dtype=np.int32)
+    rng = np.random.default_rng(1)
+    data = rng.standard_normal((3, 4, 4)) + 1j * rng.standard_normal((3, 4, 4))
+    import scipy.sparse as sp
+
+    mat = sp.bsr_matrix((data, indices, indptr), shape=(16, 16))
+    x = rng.standard_normal(16) + 0j
+    with solver_cls(indptr, indices, data) as dev:
+        assert np.allclose(dev.spmv(x), mat @ x, rtol=1e-13)
+
+
+def test_device_start_vectors_equal_oracle(api, solver_cls):
+    system = _build(api, "barrier")
+    with solver_cls.from_hamiltonian(system) as dev:
+        for kind in (cheb_ref.VEC_RADEMACHER, cheb_ref.VEC_Z4):
+            for seed, vec in [(0, 0), (12345, 7), (2**63 + 5, 2**40)]:
+                assert np.array_equal(dev.random_vector(seed, vec, kind),
+                                      cheb_ref.random_vector(dev.dim, seed, vec, kind))
+
+
+# ----------------------------------------------------------------- recurrence
+@pytest.mark.parametrize("name,n_vectors,kind", [
+    ("random357", 1, cheb_ref.VEC_Z4),
+    ("random357", 3, cheb_ref.VEC_Z4),
+    ("random357", 8, cheb_ref.VEC_RADEMACHER),
+    ("dwave8", 16, cheb_ref.VEC_RADEMACHER),
+    ("swave20", 64, cheb_ref.VEC_Z4),
+    ("complex235", 70, cheb_ref.VEC_Z4),  # more than one batch of 64
+])
+def test_recurrence_dots_match_oracle(api, solver_cls, name, n_vectors, kind):
+    system = _build(api, name)
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    steps = 40
+    start = cheb_ref.random_block(bsr.shape[0], 9, range(5, 5 + n_vectors), kind)
+    d_ref, e_ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, start)
+    with solver_cls.from_hamiltonian(system) as dev:
+        d, e = dev.dots_random(scale, steps, n_vectors, seed=9, first_id=5, kind=kind)
+        d2, e2 = dev.dots_random(scale, steps, n_vectors, seed=9, first_id=5, kind=kind)
+    mu0 = bsr.shape[0]
+    assert np.allclose(d, d_ref, rtol=0, atol=1e-12 * mu0)
+    assert np.allclose(e, e_ref, rtol=0, atol=1e-12 * mu0)
+    assert np.array_equal(d, d2) and np.array_equal(e, e2), "reductions must be bit-reproducible"
+
+
+def test_unit_vector_moments_match_oracle(api, solver_cls):
+    system = _build(api, "random357")
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    rows = np.array([0, 5, 17, 418, 419])
+    ref = cheb_ref.moments(bsr, scale, 64, cheb_ref.unit_block(bsr.shape[0], rows))
+    with solver_cls.from_hamiltonian(system) as dev:
+        mu = dev.moments_unit(scale, 64, rows)
+    assert np.allclose(mu, ref, rtol=0, atol=1e-13)
+
+
+def test_lanes_override_gives_same_numbers(api, solver_cls):
+    system = _build(api, "dwave8")
+    scale = cheb_ref.spectral_bound(system.matrix("bsr"))
+    with solver_cls.from_hamiltonian(system) as dev:
+        base = dev.dots_random(scale, 10, 4, seed=1)
+        for lanes in (4, 8, 16, 32, 64):
+            dev.set_lanes_per_row(lanes)
+            other = dev.dots_random(scale, 10, 4, seed=1)
+            assert dev.perf()["lanes_per_row"] == lanes
+            assert np.allclose(other[0], base[0], rtol=1e-13) and np.allclose(other[1], base[1], rtol=1e-13, atol=1e-9)
+
+
+# ------------------------------------------------------------ free energy / F
+@pytest.mark.parametrize("name", ["swave20", "swave20_zeeman", "snf", "complex235", "random357", "chain128"])
+def test_free_energy_dense_matches_reference(api, golden, name):
+    """Mirrors ref tests/test_hamiltonian.py:421-424 (accelerator vs CPU) with recorded CPU values."""
+    system = _build(api, name)
+    for temperature in systems.CATALOG[name]["temps"]:
+        value = system.free_energy(float(temperature), method="dense")
+        assert np.isclose(value, golden.free_energy(name, temperature), rtol=1e-10, atol=0)
+    with pytest.raises(ValueError):
+        system.free_energy(-1.0)
+
+
+@pytest.mark.parametrize("name,temperature,moments", [
+    ("swave20", 0.5, 128),
+    ("swave20", 1.0, 64),
+    ("swave20", 0.1, 512),
+    ("snf", 1.0, 64),
+    ("complex235", 1.0, 192),
+    ("barrier", 0.1, 1400),
+])
+def test_free_energy_chebyshev_exact_trace_matches_reference(api, golden, name, temperature, moments):
+    system = _build(api, name)
+    value = system.free_energy(temperature, method="chebyshev", trace="exact", moments=moments)
+    assert np.isclose(value, golden.free_energy(name, temperature), rtol=1e-10, atol=0)
+
+
+def test_free_energy_default_moment_rule_reaches_1e10(api, golden):
+    system = _build(api, "snf")
+    for temperature in (0.1, 1.0):
+        value = system.free_energy(temperature, method="chebyshev", trace="exact")
+        assert np.isclose(value, golden.free_energy("snf", temperature), rtol=1e-10, atol=0)
+
+
+def test_free_energy_stochastic_matches_oracle_on_same_vectors(api):
+    system = systems.swave_square(api, L=40)
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    for kind, label in ((cheb_ref.VEC_RADEMACHER, "rademacher"), (cheb_ref.VEC_Z4, "z4")):
+        ref = cheb_ref.free_energy_stochastic(bsr, 0.5, 128, n_vectors=8, seed=3, kind=kind, scale=scale)
+        value = system.free_energy(0.5, method="chebyshev", trace="stochastic", moments=128, vectors=8,
+                                   seed=3, vector_kind=label, scale=scale)
+        assert np.isclose(value, ref, rtol=1e-10, atol=0)
+
+
+def test_free_energy_like_reference_test(api):
+    """ref tests/test_hamiltonian.py:428-464: F against the closed form over ±ε, T = 0, T < 0."""
+    system = _build(api, "snf")
+    eps, _ = system.diagonalize()
+    both = np.hstack([-eps, +eps])
+    for temperature in [0.01, 0.1, 1.0]:
+        closed = -(temperature / 2) * np.sum(np.log(1 + np.exp(-both / temperature)))
+        assert np.allclose(system.free_energy(temperature), closed)
+    assert np.allclose(system.free_energy(0.0), 0.5 * np.sum(both[both < 0]))
+    with pytest.raises(Exception):
+        system.free_energy(-1.0)
+
+
+# ----------------------------------------------------------------- diagonalize
+@pytest.mark.parametrize("name", ["barrier", "complex235", "random357", "snf"])
+def test_diagonalize_matches_reference(api, golden, name):
+    system = _build(api, name)
+    dense = np.asarray(system.matrix("dense"))
+    vals, vecs = system.diagonalize(format="raw")
+    ref = golden.eigenvalues(name)
+    assert vals.shape == ref.shape and vecs.shape == (dense.shape[0], ref.size)
+    assert np.all(vals > 0) and np.all(np.diff(vals) >= 0)
+    assert np.allclose(vals, ref, rtol=0, atol=1e-10)
+    assert np.allclose(dense @ vecs, vecs * vals, atol=1e-9)
+    assert np.allclose(vecs.conj().T @ vecs, np.eye(ref.size), atol=1e-9)
+    vals2, shaped = system.diagonalize()
+    assert shaped.shape == (ref.size, system.lattice.size, 4)
+    for n in (0, ref.size // 2, ref.size - 1):
+        for site in (0, system.lattice.size - 1):
+            assert np.allclose(shaped[n, site, :], vecs[4 * site : 4 * site + 4, n])
+    with pytest.raises(Exception):
+        system.diagonalize(format="foo")
+
+
+def test_diagonalize_counts_2n_states(api):
+    system = _build(api, "barrier")  # ref tests/test_hamiltonian.py:353
+    vals, _ = system.diagonalize()
+    assert vals.size == 2 * system.lattice.size
+
+
+# ------------------------------------------------------------------------ LDOS
+@pytest.mark.parametrize("name", ["ldos16", "random357", "chain128", "pwave31"])
+def test_ldos_matches_reference(api, golden, name):
+    system = _build(api, name)
+    for n, (site, energies) in enumerate(systems.CATALOG[name]["ldos"]):
+        rho = system.ldos(tuple(site), list(energies))
+        assert np.allclose(rho, golden.ldos(name, n), rtol=1e-9, atol=1e-12)
+
+
+def test_ldos_is_positive_everywhere(api):
+    """ref tests/test_hamiltonian.py:467-500 on a seeded random periodic metal."""
+    system = systems.random_periodic(api, shape=(5, 5, 2), seed=21)
+    energies = [0.0, 0.01, 0.10, 0.50, 1.00, 2.00, 4.00]
+    for site in [(0, 0, 0), (2, 3, 1), (4, 4, 1), (1, 0, 1)]:
+        assert np.all(system.ldos(site, energies) >= 0)
+
+
+# ----------------------------------------------------- revision / re-upload
+def test_device_copy_follows_with_block_updates(api):
+    system = systems.swave_square(api, L=6, gap=0.0)
+    before = system.free_energy(0.2)
+    with system as (H, Δ):
+        for i in system.lattice.sites():
+            Δ[i, i] = 0.8 * api.jσ2
+    after = system.free_energy(0.2)
+    assert after < before - 1e-3
+    dense = np.asarray(system.matrix("dense"))
+    assert np.isclose(after, dense_ref.free_energy(dense, 0.2), rtol=1e-10)
