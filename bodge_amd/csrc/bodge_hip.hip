@@ -14,8 +14,10 @@
 #include <rocsolver/rocsolver.h>
 
 #include <algorithm>
+#include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -107,8 +109,6 @@ using StepKernel = void (*)(bdg::StepArgs);
 
 StepKernel step_kernel(int rl) {
     switch (rl) {
-        case 1: return bdg::cheb_step<1>;
-        case 2: return bdg::cheb_step<2>;
         case 4: return bdg::cheb_step<4>;
         case 8: return bdg::cheb_step<8>;
         case 16: return bdg::cheb_step<16>;
@@ -176,8 +176,10 @@ struct StartSpec {
 // [col0, col0 + n_active) of the (n_steps x ld) host arrays.
 int run_batch(bdg_system* sys, double scale, int n_steps, int n_active, const StartSpec& start,
               double* d_out, double* e_out, int ld, int col0, bool first_batch) {
-    int rl = next_pow2(n_active);
-    if (sys->lanes_override >= n_active)
+    // Fewer than 4 lanes per row would put 32-64 rows' blocks into one wave's LDS
+    // region with no reuse; small batches run as 4 columns with zero padding.
+    int rl = std::max(4, next_pow2(n_active));
+    if (sys->lanes_override >= n_active && sys->lanes_override >= 4)
         rl = sys->lanes_override;
     StepPlan plan;
     if (int rc = make_plan(sys, rl, &plan)) return rc;
@@ -299,6 +301,8 @@ struct SolverApi {
     decltype(&rocblas_destroy_handle) destroy_handle = nullptr;
     decltype(&rocblas_set_stream) set_stream = nullptr;
     decltype(&rocsolver_zheevd) zheevd = nullptr;
+    decltype(&rocsolver_zheev) zheev = nullptr;
+    decltype(&rocsolver_zheevj) zheevj = nullptr;
 };
 
 int load_solver(SolverApi** out) {
@@ -318,7 +322,10 @@ int load_solver(SolverApi** out) {
             api.set_stream =
                 reinterpret_cast<decltype(api.set_stream)>(dlsym(api.blas, "rocblas_set_stream"));
             api.zheevd = reinterpret_cast<decltype(api.zheevd)>(dlsym(api.solver, "rocsolver_zheevd"));
-            ok = api.create_handle && api.destroy_handle && api.set_stream && api.zheevd;
+            api.zheev = reinterpret_cast<decltype(api.zheev)>(dlsym(api.solver, "rocsolver_zheev"));
+            api.zheevj = reinterpret_cast<decltype(api.zheevj)>(dlsym(api.solver, "rocsolver_zheevj"));
+            ok = api.create_handle && api.destroy_handle && api.set_stream && api.zheevd && api.zheev &&
+                 api.zheevj;
         }
     }
     if (!ok) return fail(BDG_ELIBRARY, "rocSOLVER/rocBLAS could not be loaded: %s", dlerror());
@@ -488,7 +495,7 @@ int bdg_destroy(bdg_system* sys) {
 
 int bdg_set_lanes_per_row(bdg_system* sys, int32_t lanes) {
     if (!sys) return fail(BDG_EINVAL, "null system handle");
-    if (lanes != 0 && !step_kernel(lanes)) return fail(BDG_EINVAL, "lanes must be a power of two <= 64");
+    if (lanes != 0 && !step_kernel(lanes)) return fail(BDG_EINVAL, "lanes must be 4, 8, 16, 32 or 64");
     sys->lanes_override = lanes;
     return BDG_OK;
 }
@@ -496,21 +503,22 @@ int bdg_set_lanes_per_row(bdg_system* sys, int32_t lanes) {
 int bdg_spmv(bdg_system* sys, const double* x, double* y) {
     if (!sys || !x || !y) return fail(BDG_EINVAL, "null argument");
     HIP_TRY(hipSetDevice(sys->device));
+    constexpr int kCols = 4;  // narrowest kernel configuration; columns 1..3 stay zero
     StepPlan plan;
-    if (int rc = make_plan(sys, 1, &plan)) return rc;
+    if (int rc = make_plan(sys, kCols, &plan)) return rc;
     const size_t n = (size_t)4 * sys->nb;
-    if (int rc = sys->vec_a.reserve(n)) return rc;
-    if (int rc = sys->vec_b.reserve(n)) return rc;
-    if (int rc = sys->partial.reserve((size_t)plan.grid * 2)) return rc;
+    if (int rc = sys->vec_a.reserve(n * kCols)) return rc;
+    if (int rc = sys->vec_b.reserve(n * kCols)) return rc;
+    if (int rc = sys->partial.reserve((size_t)plan.grid * 2 * kCols)) return rc;
     DeviceBuffer<double2> host_order;
     if (int rc = host_order.reserve(n)) return rc;
     hipStream_t st = sys->stream;
-    const int grid = (int)std::min<size_t>(4096, (n + 255) / 256);
-    int rc = BDG_OK;
+    const int grid = (int)std::min<size_t>(4096, (n * kCols + 255) / 256);
     auto body = [&]() -> int {
         HIP_TRY(hipMemcpyAsync(host_order.ptr, x, sizeof(double2) * n, hipMemcpyHostToDevice, st));
-        bdg::planar_from_sitemajor<<<grid, 256, 0, st>>>(host_order.ptr, sys->vec_a.ptr, sys->nb, 1, 0);
-        bdg::fill_zero<<<grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)n);
+        bdg::fill_zero<<<grid, 256, 0, st>>>(sys->vec_a.ptr, (int64_t)(n * kCols));
+        bdg::fill_zero<<<grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)(n * kCols));
+        bdg::planar_from_sitemajor<<<grid, 256, 0, st>>>(host_order.ptr, sys->vec_a.ptr, sys->nb, kCols, 0);
         bdg::StepArgs args{};
         args.indptr = sys->indptr.ptr;
         args.indices = sys->indices.ptr;
@@ -523,13 +531,13 @@ int bdg_spmv(bdg_system* sys, const double* x, double* y) {
         args.n_tiles = plan.n_tiles;
         args.max_row_blocks = sys->max_row_blocks;
         plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
-        bdg::sitemajor_from_planar<<<grid, 256, 0, st>>>(sys->vec_b.ptr, host_order.ptr, sys->nb, 1, 0);
+        bdg::sitemajor_from_planar<<<grid, 256, 0, st>>>(sys->vec_b.ptr, host_order.ptr, sys->nb, kCols, 0);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(y, host_order.ptr, sizeof(double2) * n, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         return BDG_OK;
     };
-    rc = body();
+    int rc = body();
     host_order.release();
     return rc;
 }
@@ -627,24 +635,30 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     DeviceBuffer<double> eig, offdiag;
     DeviceBuffer<int> info;
     rocblas_handle handle = nullptr;
-    auto body = [&]() -> int {
-        if (int rc = dense.reserve((size_t)n * n)) return rc;
-        if (int rc = eig.reserve((size_t)n)) return rc;
-        if (int rc = offdiag.reserve((size_t)n)) return rc;
-        if (int rc = info.reserve(1)) return rc;
+    const rocblas_evect evect = z_out ? rocblas_evect_original : rocblas_evect_none;
+
+    // One attempt with the named rocSOLVER driver: "evd" divide & conquer, "evj" Jacobi, "ev" QL/QR.
+    auto attempt = [&](const std::string& algo) -> int {
         HIP_TRY(hipMemsetAsync(dense.ptr, 0, sizeof(double2) * n * n, sys->stream));
         bdg::scatter_dense<<<(unsigned)sys->nb, 128, 0, sys->stream>>>(
             sys->indptr.ptr, sys->indices.ptr, sys->blocks.ptr, dense.ptr, (int)sys->nb);
         HIP_TRY(hipGetLastError());
-        if (api->create_handle(&handle) != rocblas_status_success)
-            return fail(BDG_ELIBRARY, "rocblas_create_handle failed");
-        if (api->set_stream(handle, sys->stream) != rocblas_status_success)
-            return fail(BDG_ELIBRARY, "rocblas_set_stream failed");
-        rocblas_status st = api->zheevd(
-            handle, z_out ? rocblas_evect_original : rocblas_evect_none, rocblas_fill_lower,
-            (rocblas_int)n, reinterpret_cast<rocblas_double_complex*>(dense.ptr), (rocblas_int)n,
-            eig.ptr, offdiag.ptr, info.ptr);
-        if (st != rocblas_status_success) return fail(BDG_ELIBRARY, "rocsolver_zheevd returned %d", (int)st);
+        auto* a_ptr = reinterpret_cast<rocblas_double_complex*>(dense.ptr);
+        rocblas_status st;
+        if (algo == "ev") {
+            st = api->zheev(handle, evect, rocblas_fill_lower, (rocblas_int)n, a_ptr, (rocblas_int)n,
+                            eig.ptr, offdiag.ptr, info.ptr);
+        } else if (algo == "evj") {
+            // offdiag doubles as {residual, n_sweeps} scratch
+            st = api->zheevj(handle, rocblas_esort_ascending, evect, rocblas_fill_lower, (rocblas_int)n,
+                             a_ptr, (rocblas_int)n, 0.0, offdiag.ptr, 100,
+                             reinterpret_cast<rocblas_int*>(offdiag.ptr + 1), eig.ptr, info.ptr);
+        } else {
+            st = api->zheevd(handle, evect, rocblas_fill_lower, (rocblas_int)n, a_ptr, (rocblas_int)n,
+                             eig.ptr, offdiag.ptr, info.ptr);
+        }
+        if (st != rocblas_status_success)
+            return fail(BDG_ELIBRARY, "rocsolver eigensolver (%s) returned %d", algo.c_str(), (int)st);
         int host_info = 0;
         HIP_TRY(hipMemcpyAsync(&host_info, info.ptr, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
         HIP_TRY(hipMemcpyAsync(w_out, eig.ptr, sizeof(double) * n, hipMemcpyDeviceToHost, sys->stream));
@@ -652,7 +666,36 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
             HIP_TRY(hipMemcpyAsync(z_out, dense.ptr, sizeof(double2) * n * n, hipMemcpyDeviceToHost,
                                    sys->stream));
         HIP_TRY(hipStreamSynchronize(sys->stream));
-        if (host_info != 0) return fail(BDG_ELIBRARY, "zheevd did not converge (info=%d)", host_info);
+        if (host_info != 0)
+            return fail(BDG_ELIBRARY, "eigensolver (%s) did not converge (info=%d)", algo.c_str(), host_info);
+        return BDG_OK;
+    };
+    auto all_finite = [&]() {
+        for (int64_t i = 0; i < n; ++i)
+            if (!std::isfinite(w_out[i])) return false;
+        if (z_out)
+            for (int64_t i = 0; i < 2 * n * n; ++i)
+                if (!std::isfinite(z_out[i])) return false;
+        return true;
+    };
+    auto body = [&]() -> int {
+        if (int rc = dense.reserve((size_t)n * n)) return rc;
+        if (int rc = eig.reserve((size_t)std::max<int64_t>(n, 2))) return rc;
+        if (int rc = offdiag.reserve((size_t)std::max<int64_t>(n, 2))) return rc;
+        if (int rc = info.reserve(1)) return rc;
+        if (api->create_handle(&handle) != rocblas_status_success)
+            return fail(BDG_ELIBRARY, "rocblas_create_handle failed");
+        if (api->set_stream(handle, sys->stream) != rocblas_status_success)
+            return fail(BDG_ELIBRARY, "rocblas_set_stream failed");
+        const char* forced = getenv("BODGE_AMD_EIGH");
+        if (forced && *forced) return attempt(forced);
+        // zheevd is the fast driver, but on ROCm 7.2 / gfx950 its eigenvectors come back
+        // NaN for spectra with exact degeneracies (measured: profiles/r01_eigh_probe.log);
+        // eigenvalues are unaffected.  Verify, and redo with the Jacobi driver if needed.
+        if (int rc = attempt("evd")) return rc;
+        if (all_finite()) return BDG_OK;
+        if (int rc = attempt("evj")) return rc;
+        if (!all_finite()) return fail(BDG_ELIBRARY, "eigensolver returned non-finite values");
         return BDG_OK;
     };
     int rc = body();
