@@ -149,7 +149,7 @@ def main():
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
             "traffic": None,
-            "kernel": f"cheb_step<{perf['lanes_per_row']}>",
+            "kernel": ("cheb_step_pipelined" if perf["pipelined"] else "cheb_step") + f"<{perf['lanes_per_row']}>",
             "launch_ms": launch_ms,
             "bytes_per_launch": perf["bytes_per_launch"],
             "grid": perf["grid"],

@@ -35,6 +35,8 @@ class Perf(C.Structure):
         ("vectors_per_launch", C.c_int32),
         ("grid", C.c_int32),
         ("lds_bytes", C.c_int32),
+        ("pipelined", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -118,38 +118,73 @@ StepKernel step_kernel(int rl) {
     return nullptr;
 }
 
+// Pipelined kernels exist for 8..64 lanes per row and rows of at most 3 / 5 / 7
+// blocks (the 1-D / 2-D / 3-D cubic stencils); anything else runs generic.
+template <int MAXB>
+StepKernel pipelined_for(int rl) {
+    switch (rl) {
+        case 8: return bdg::cheb_step_pipelined<8, MAXB>;
+        case 16: return bdg::cheb_step_pipelined<16, MAXB>;
+        case 32: return bdg::cheb_step_pipelined<32, MAXB>;
+        case 64: return bdg::cheb_step_pipelined<64, MAXB>;
+    }
+    return nullptr;
+}
+
+StepKernel pipelined_kernel(int rl, int max_row_blocks, int* maxb_out) {
+    const char* mode = getenv("BODGE_AMD_KERNEL");
+    if (mode && std::string(mode) == "generic") return nullptr;
+    if (max_row_blocks <= 3) { *maxb_out = 3; return pipelined_for<3>(rl); }
+    if (max_row_blocks <= 5) { *maxb_out = 5; return pipelined_for<5>(rl); }
+    if (max_row_blocks <= 7) { *maxb_out = 7; return pipelined_for<7>(rl); }
+    return nullptr;
+}
+
 struct StepPlan {
     int rl = 0;
     int rows_per_tile = 0;
     int n_tiles = 0;
     int grid = 0;
-    size_t lds_bytes = 0;
+    size_t lds_bytes = 0;      // dynamic LDS to request at launch
+    size_t lds_footprint = 0;  // what one workgroup occupies (reported)
+    bool pipelined = false;
     StepKernel kernel = nullptr;
 };
 
 int make_plan(bdg_system* sys, int rl, StepPlan* plan) {
     plan->rl = rl;
-    plan->kernel = step_kernel(rl);
-    if (!plan->kernel) return fail(BDG_EINVAL, "unsupported lanes-per-row %d", rl);
     const int rows_per_wave = bdg::kWave / rl;
     plan->rows_per_tile = rows_per_wave * bdg::kWavesPerBlock;
     plan->n_tiles = (int)((sys->nb + plan->rows_per_tile - 1) / plan->rows_per_tile);
-    const size_t stage = (size_t)bdg::kWavesPerBlock * rows_per_wave * sys->max_row_blocks *
-                         bdg::kBlockSlots * sizeof(double2);
-    const size_t reduce = (size_t)bdg::kWavesPerBlock * rl * 2 * sizeof(double);
-    plan->lds_bytes = std::max(stage, reduce);
-    if (plan->lds_bytes > 160 * 1024)
-        return fail(BDG_EINVAL,
-                    "a block row with %d blocks needs %zu bytes of LDS per workgroup (limit 160 KiB)",
-                    sys->max_row_blocks, plan->lds_bytes);
-    if (plan->lds_bytes > 64 * 1024)
-        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan->kernel),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize,
-                                    (int)plan->lds_bytes));
+    int maxb = 0;
+    plan->kernel = pipelined_kernel(rl, sys->max_row_blocks, &maxb);
+    if (plan->kernel) {
+        plan->pipelined = true;
+        plan->lds_bytes = 0;
+        plan->lds_footprint = (size_t)bdg::kWavesPerBlock * rows_per_wave * maxb * bdg::kBlockSlots *
+                                  sizeof(double2) +
+                              (size_t)bdg::kWavesPerBlock * rl * 2 * sizeof(double);
+    } else {
+        plan->kernel = step_kernel(rl);
+        if (!plan->kernel) return fail(BDG_EINVAL, "unsupported lanes-per-row %d", rl);
+        const size_t stage = (size_t)bdg::kWavesPerBlock * rows_per_wave * sys->max_row_blocks *
+                             bdg::kBlockSlots * sizeof(double2);
+        const size_t reduce = (size_t)bdg::kWavesPerBlock * rl * 2 * sizeof(double);
+        plan->lds_bytes = plan->lds_footprint = std::max(stage, reduce);
+        if (plan->lds_bytes > 160 * 1024)
+            return fail(BDG_EINVAL,
+                        "a block row with %d blocks needs %zu bytes of LDS per workgroup (limit 160 KiB)",
+                        sys->max_row_blocks, plan->lds_bytes);
+        if (plan->lds_bytes > 64 * 1024)
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan->kernel),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)plan->lds_bytes));
+    }
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &per_cu, reinterpret_cast<const void*>(plan->kernel), bdg::kBlockThreads, plan->lds_bytes));
     per_cu = std::max(1, std::min(per_cu, 8));
+    if (const char* cap = getenv("BODGE_AMD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(cap));
     int grid = std::min(plan->n_tiles, per_cu * sys->num_cus);
     plan->grid = std::max(8, (grid + 7) / 8 * 8);
     return BDG_OK;
@@ -259,7 +294,8 @@ int run_batch(bdg_system* sys, double scale, int n_steps, int n_active, const St
     p.lanes_per_row = rl;
     p.vectors_per_launch = rl;
     p.grid = plan.grid;
-    p.lds_bytes = (int32_t)plan.lds_bytes;
+    p.lds_bytes = (int32_t)plan.lds_footprint;
+    p.pipelined = plan.pipelined ? 1 : 0;
     return BDG_OK;
 }
 

@@ -241,6 +241,188 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
     }
 }
 
+// ----------------------------------------------------------- K1, pipelined form
+// Same arithmetic as cheb_step, restructured so that a wave keeps one tile of
+// matrix data in flight while it computes the previous one:
+//
+//   loop over the wave's tiles:
+//     issue  matrix loads of tile n+1 -> registers (ML x 16 B per lane, streaming)
+//     issue  row metadata of tile n+1 (indptr pair, column indices)
+//     compute tile n from LDS (t_n gathers, 16 complex MACs per block, epilogue)
+//     write  tile n+1 registers -> LDS   (same wave: LDS ops are ordered, no barrier)
+//
+// MAXB (compile time) is the largest number of blocks in any block row; it
+// fixes the LDS region and the register staging depth.  Matrices with longer
+// rows use the generic kernel above.
+template <int RL, int MAXB>
+__global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a) {
+    constexpr int RW = kWave / RL;                    // block rows per wave
+    constexpr int NBLK = RW * MAXB;                   // most blocks a wave tile can hold
+    constexpr int ML = (NBLK * 16 + kWave - 1) / kWave;  // 16-byte loads per lane per tile
+    __shared__ double2 lds[kWavesPerBlock * NBLK * kBlockSlots];
+    __shared__ double red[kWavesPerBlock * RL * 2];
+
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int s = lane / RL;
+    const int r = lane % RL;
+    double2* stage = lds + wave * (NBLK * kBlockSlots);
+
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int slots = gridDim.x >> 3;
+    const int t_lo = (int)(((int64_t)a.n_tiles * xcd) >> 3);
+    const int t_hi = (int)(((int64_t)a.n_tiles * (xcd + 1)) >> 3);
+    const size_t plane = (size_t)a.nb * RL;
+
+    // tile -> first block row of this wave (>= nb means "no work")
+    auto first_row = [&](int t) { return t < t_hi ? (t * kWavesPerBlock + wave) * RW : a.nb; };
+
+    struct RowMeta {
+        int kbeg, kend;
+        int col[MAXB];
+    };
+    auto load_meta = [&](int row0, RowMeta& m) {
+        const int i = row0 + s;
+        m.kbeg = m.kend = 0;
+        if (i < a.nb) {
+            m.kbeg = a.indptr[i];
+            m.kend = a.indptr[i + 1];
+        }
+#pragma unroll
+        for (int q = 0; q < MAXB; ++q) m.col[q] = (m.kbeg + q < m.kend) ? a.indices[m.kbeg + q] : 0;
+    };
+    auto tile_span = [&](int row0, int& kb0, int& n_el) {
+        kb0 = 0;
+        n_el = 0;
+        if (row0 < a.nb) {
+            kb0 = a.indptr[row0];
+            n_el = (a.indptr[min(row0 + RW, a.nb)] - kb0) * 16;
+        }
+    };
+
+    double2 mreg[ML];
+    auto issue_matrix = [&](int kb0, int n_el) {
+        const double2* src = a.blocks + (size_t)kb0 * 16;
+#pragma unroll
+        for (int u = 0; u < ML; ++u) {
+            const int e = u * kWave + lane;
+            if (e < n_el) mreg[u] = load_stream(src + e);
+        }
+    };
+    auto commit_matrix = [&](int n_el) {
+#pragma unroll
+        for (int u = 0; u < ML; ++u) {
+            const int e = u * kWave + lane;
+            if (e < n_el) stage[(e >> 4) * kBlockSlots + (e & 15)] = mreg[u];
+        }
+    };
+
+    double dsum = 0.0, esum = 0.0;
+
+    // ---- prologue: tile 0 into LDS, metadata of tile 0, span of tile 1
+    int t = t_lo + slot;
+    int row0 = first_row(t);
+    int kb0, n_el;
+    tile_span(row0, kb0, n_el);
+    RowMeta meta;
+    load_meta(row0, meta);
+    issue_matrix(kb0, n_el);
+    int row0_n = first_row(t + slots);
+    int kb0_n, n_el_n;
+    tile_span(row0_n, kb0_n, n_el_n);
+    commit_matrix(n_el);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    __builtin_amdgcn_wave_barrier();
+
+    while (row0 < a.nb) {
+        // ---- prefetch tile n+1 (registers) and the span of tile n+2
+        issue_matrix(kb0_n, n_el_n);
+        RowMeta meta_n;
+        load_meta(row0_n, meta_n);
+        t += slots;
+        const int row0_nn = first_row(t + slots);
+        int kb0_nn, n_el_nn;
+        tile_span(row0_nn, kb0_nn, n_el_nn);
+
+        // ---- compute tile n
+        const int i = row0 + s;
+        if (i < a.nb) {
+            const size_t own = (size_t)i * RL + r;
+            double2 acc[4], x[4], xn[4];
+#pragma unroll
+            for (int al = 0; al < 4; ++al) acc[al] = make_double2(0.0, 0.0);
+            const int len = meta.kend - meta.kbeg;
+            if (len > 0) {
+#pragma unroll
+                for (int be = 0; be < 4; ++be) xn[be] = a.cur[be * plane + (size_t)meta.col[0] * RL + r];
+            }
+            const double2* blk = stage + (meta.kbeg - kb0) * kBlockSlots;
+#pragma unroll
+            for (int q = 0; q < MAXB; ++q) {
+                if (q < len) {
+#pragma unroll
+                    for (int be = 0; be < 4; ++be) x[be] = xn[be];
+                    if (q + 1 < MAXB && q + 1 < len) {
+#pragma unroll
+                        for (int be = 0; be < 4; ++be)
+                            xn[be] = a.cur[be * plane + (size_t)meta.col[q + 1 < MAXB ? q + 1 : 0] * RL + r];
+                    }
+#pragma unroll
+                    for (int al = 0; al < 4; ++al)
+#pragma unroll
+                        for (int be = 0; be < 4; ++be)
+                            cmac(acc[al], blk[q * kBlockSlots + al * 4 + be], x[be]);
+                }
+            }
+#pragma unroll
+            for (int al = 0; al < 4; ++al) {
+                const double2 p = a.prev[al * plane + own];
+                const double2 c = a.cur[al * plane + own];
+                double2 nx;
+                nx.x = fma(a.coef, acc[al].x, -p.x);
+                nx.y = fma(a.coef, acc[al].y, -p.y);
+                a.prev[al * plane + own] = nx;
+                dsum = fma(c.x, c.x, dsum);
+                dsum = fma(c.y, c.y, dsum);
+                esum = fma(nx.x, c.x, esum);
+                esum = fma(nx.y, c.y, esum);
+            }
+        }
+
+        // ---- tile n+1: registers -> LDS (reads of tile n were issued earlier by this wave)
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        commit_matrix(n_el_n);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+
+        row0 = row0_n;
+        kb0 = kb0_n;
+        meta = meta_n;
+        row0_n = row0_nn;
+        kb0_n = kb0_nn;
+        n_el_n = n_el_nn;
+    }
+
+#pragma unroll
+    for (int off = kWave / 2; off >= RL; off >>= 1) {
+        dsum += __shfl_xor(dsum, off);
+        esum += __shfl_xor(esum, off);
+    }
+    if (lane < RL) {
+        red[(wave * RL + lane) * 2 + 0] = dsum;
+        red[(wave * RL + lane) * 2 + 1] = esum;
+    }
+    __syncthreads();
+    if (threadIdx.x < 2 * RL) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) tot += red[w * RL * 2 + threadIdx.x];
+        a.partial[(size_t)blockIdx.x * RL * 2 + threadIdx.x] = tot;
+    }
+}
+
 // ------------------------------------------------------------------------ K2
 // out[step][c] = Σ_g partial[step][g][c] in ascending g, c < width (= 2*RL).
 __global__ void reduce_partials(const double* __restrict__ partial, double* __restrict__ out,

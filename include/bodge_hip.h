@@ -52,7 +52,9 @@ typedef struct bdg_perf {
     int32_t lanes_per_row; /* kernel configuration actually used                     */
     int32_t vectors_per_launch;
     int32_t grid;          /* workgroups per launch                                  */
-    int32_t lds_bytes;     /* dynamic LDS per workgroup                              */
+    int32_t lds_bytes;     /* LDS one workgroup occupies                             */
+    int32_t pipelined;     /* 1 = register-prefetch kernel, 0 = generic kernel       */
+    int32_t reserved;
 } bdg_perf;
 
 const char* bdg_last_error(void);
