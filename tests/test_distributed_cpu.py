@@ -1,0 +1,67 @@
+"""N > 1 path on the CPU: two gloo ranks must reproduce the single-rank moments and F."""
+
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import systems
+from bodge_amd import chebyshev
+from bodge_amd.observables import shard_vectors
+from oracle import cheb_ref
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+class FakeComm:
+    def __init__(self, rank, n_ranks):
+        self.rank, self.n_ranks = rank, n_ranks
+
+
+@pytest.mark.parametrize("total,world", [(64, 8), (10, 4), (7, 2), (8, 8), (5, 1)])
+def test_shards_partition_the_vectors(total, world):
+    spans = [shard_vectors(total, FakeComm(r, world)) for r in range(world)]
+    ids = [i for first, count in spans for i in range(first, first + count)]
+    assert ids == list(range(total))
+    counts = [c for _, c in spans]
+    assert max(counts) - min(counts) <= 1
+    assert shard_vectors(total, None) == (0, total)
+    with pytest.raises(ValueError):
+        shard_vectors(2, FakeComm(3, 4))
+
+
+def _free_port():
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        return sock.getsockname()[1]
+
+
+@pytest.mark.timeout(600)
+def test_two_gloo_ranks_match_single_rank(api, tmp_path):
+    total, moments = 6, 64
+    out = tmp_path / "result.json"
+    cmd = [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+        os.path.join(ROOT, "tests", "_dist_worker.py"), str(out), str(total), str(moments),
+    ]
+    env = dict(os.environ, OMP_NUM_THREADS="1")
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    got = json.loads(out.read_text())
+    assert got["world"] == 2
+    spans = [json.loads((tmp_path / f"result.json.rank{r}").read_text()) for r in range(2)]
+    assert [(s["first"], s["count"]) for s in spans] == [(0, 3), (3, 3)]
+
+    system = systems.swave_square(api, L=10, zeeman=0.05)
+    bsr = system.matrix("bsr")
+    indptr, _, data = system.bsr_arrays()
+    scale = chebyshev.spectral_bound(indptr, data)
+    start = cheb_ref.random_block(bsr.shape[0], 0, range(total), cheb_ref.VEC_Z4)
+    mu = cheb_ref.moments(bsr, scale, moments, start).sum(axis=1) / total
+    assert np.allclose(got["mu"], mu, rtol=0, atol=1e-12 * bsr.shape[0])
+    assert np.isclose(got["free_energy"], chebyshev.free_energy_series(mu, scale, 0.5), rtol=1e-12)
