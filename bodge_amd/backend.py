@@ -36,7 +36,7 @@ class Perf(C.Structure):
         ("grid", C.c_int32),
         ("lds_bytes", C.c_int32),
         ("pipelined", C.c_int32),
-        ("reserved", C.c_int32),
+        ("real_arithmetic", C.c_int32),
     ]
 
 

@@ -88,6 +88,9 @@ struct bdg_system {
     int lanes_override = 0;
     DeviceBuffer<int> indptr, indices;
     DeviceBuffer<double2> blocks;
+    DeviceBuffer<double> blocks_real;  // Re(blocks), built on first real-mode call
+    bool is_real = false;              // imag(H) == 0 everywhere (checked at upload)
+    bool real_ready = false;
     DeviceBuffer<double2> vec_a, vec_b;
     DeviceBuffer<double> partial, dots;
     DeviceBuffer<int64_t> rows;
@@ -107,36 +110,54 @@ namespace {
 // ------------------------------------------------------------ kernel dispatch
 using StepKernel = void (*)(bdg::StepArgs);
 
-StepKernel step_kernel(int rl) {
+using bdg::ComplexMode;
+using bdg::RealMode;
+
+template <typename Mode>
+StepKernel generic_kernel(int rl) {
     switch (rl) {
-        case 4: return bdg::cheb_step<4>;
-        case 8: return bdg::cheb_step<8>;
-        case 16: return bdg::cheb_step<16>;
-        case 32: return bdg::cheb_step<32>;
-        case 64: return bdg::cheb_step<64>;
+        case 4: return bdg::cheb_step<Mode, 4>;
+        case 8: return bdg::cheb_step<Mode, 8>;
+        case 16: return bdg::cheb_step<Mode, 16>;
+        case 32: return bdg::cheb_step<Mode, 32>;
+        case 64: return bdg::cheb_step<Mode, 64>;
     }
     return nullptr;
 }
 
-// Pipelined kernels exist for 8..64 lanes per row and rows of at most 3 / 5 / 7
-// blocks (the 1-D / 2-D / 3-D cubic stencils); anything else runs generic.
+StepKernel step_kernel(bool real, int rl) {
+    return real ? generic_kernel<RealMode>(rl) : generic_kernel<ComplexMode>(rl);
+}
+
+// Pipelined kernels exist for rows of at most 3 / 5 / 7 blocks (the 1-D / 2-D /
+// 3-D cubic stencils) and 8..64 lanes per row (complex) or 4..32 (real, two
+// vectors per lane); anything else runs the generic form.
 template <int MAXB>
-StepKernel pipelined_for(int rl) {
+StepKernel pipelined_for(bool real, int rl) {
+    if (real) {
+        switch (rl) {
+            case 4: return bdg::cheb_step_pipelined<RealMode, 4, MAXB>;
+            case 8: return bdg::cheb_step_pipelined<RealMode, 8, MAXB>;
+            case 16: return bdg::cheb_step_pipelined<RealMode, 16, MAXB>;
+            case 32: return bdg::cheb_step_pipelined<RealMode, 32, MAXB>;
+        }
+        return nullptr;
+    }
     switch (rl) {
-        case 8: return bdg::cheb_step_pipelined<8, MAXB>;
-        case 16: return bdg::cheb_step_pipelined<16, MAXB>;
-        case 32: return bdg::cheb_step_pipelined<32, MAXB>;
-        case 64: return bdg::cheb_step_pipelined<64, MAXB>;
+        case 8: return bdg::cheb_step_pipelined<ComplexMode, 8, MAXB>;
+        case 16: return bdg::cheb_step_pipelined<ComplexMode, 16, MAXB>;
+        case 32: return bdg::cheb_step_pipelined<ComplexMode, 32, MAXB>;
+        case 64: return bdg::cheb_step_pipelined<ComplexMode, 64, MAXB>;
     }
     return nullptr;
 }
 
-StepKernel pipelined_kernel(int rl, int max_row_blocks, int* maxb_out) {
+StepKernel pipelined_kernel(bool real, int rl, int max_row_blocks, int* maxb_out) {
     const char* mode = getenv("BODGE_AMD_KERNEL");
     if (mode && std::string(mode) == "generic") return nullptr;
-    if (max_row_blocks <= 3) { *maxb_out = 3; return pipelined_for<3>(rl); }
-    if (max_row_blocks <= 5) { *maxb_out = 5; return pipelined_for<5>(rl); }
-    if (max_row_blocks <= 7) { *maxb_out = 7; return pipelined_for<7>(rl); }
+    if (max_row_blocks <= 3) { *maxb_out = 3; return pipelined_for<3>(real, rl); }
+    if (max_row_blocks <= 5) { *maxb_out = 5; return pipelined_for<5>(real, rl); }
+    if (max_row_blocks <= 7) { *maxb_out = 7; return pipelined_for<7>(real, rl); }
     return nullptr;
 }
 
@@ -148,28 +169,32 @@ struct StepPlan {
     size_t lds_bytes = 0;      // dynamic LDS to request at launch
     size_t lds_footprint = 0;  // what one workgroup occupies (reported)
     bool pipelined = false;
+    bool real = false;
     StepKernel kernel = nullptr;
 };
 
-int make_plan(bdg_system* sys, int rl, StepPlan* plan) {
+int make_plan(bdg_system* sys, int rl, bool real, StepPlan* plan) {
     plan->rl = rl;
+    plan->real = real;
+    const int block_stride = real ? RealMode::kBlockStride : ComplexMode::kBlockStride;
+    const int lane_doubles = 2 * (real ? RealMode::kVec : ComplexMode::kVec);
     const int rows_per_wave = bdg::kWave / rl;
     plan->rows_per_tile = rows_per_wave * bdg::kWavesPerBlock;
     plan->n_tiles = (int)((sys->nb + plan->rows_per_tile - 1) / plan->rows_per_tile);
     int maxb = 0;
-    plan->kernel = pipelined_kernel(rl, sys->max_row_blocks, &maxb);
+    plan->kernel = pipelined_kernel(real, rl, sys->max_row_blocks, &maxb);
     if (plan->kernel) {
         plan->pipelined = true;
         plan->lds_bytes = 0;
-        plan->lds_footprint = (size_t)bdg::kWavesPerBlock * rows_per_wave * maxb * bdg::kBlockSlots *
+        plan->lds_footprint = (size_t)bdg::kWavesPerBlock * rows_per_wave * maxb * block_stride *
                                   sizeof(double2) +
-                              (size_t)bdg::kWavesPerBlock * rl * 2 * sizeof(double);
+                              (size_t)bdg::kWavesPerBlock * rl * lane_doubles * sizeof(double);
     } else {
-        plan->kernel = step_kernel(rl);
+        plan->kernel = step_kernel(real, rl);
         if (!plan->kernel) return fail(BDG_EINVAL, "unsupported lanes-per-row %d", rl);
         const size_t stage = (size_t)bdg::kWavesPerBlock * rows_per_wave * sys->max_row_blocks *
-                             bdg::kBlockSlots * sizeof(double2);
-        const size_t reduce = (size_t)bdg::kWavesPerBlock * rl * 2 * sizeof(double);
+                             block_stride * sizeof(double2);
+        const size_t reduce = (size_t)bdg::kWavesPerBlock * rl * lane_doubles * sizeof(double);
         plan->lds_bytes = plan->lds_footprint = std::max(stage, reduce);
         if (plan->lds_bytes > 160 * 1024)
             return fail(BDG_EINVAL,
@@ -193,9 +218,23 @@ int make_plan(bdg_system* sys, int rl, StepPlan* plan) {
 // Algorithmic HBM bytes of one recurrence launch: every stored block and index
 // once, and per (site, vector) one read of t_n, one read of t_{n-1}, one write
 // of t_{n+1} (260 nnzb + 4 (nb+1) + 192 R nb).
-double algorithmic_bytes(const bdg_system* sys, int vectors) {
-    return 260.0 * (double)sys->nnzb + 4.0 * (double)(sys->nb + 1) +
-           192.0 * (double)vectors * (double)sys->nb;
+// Real mode stores and moves half of that: 128 B per block, 8 B per vector entry.
+double algorithmic_bytes(const bdg_system* sys, int vectors, bool real) {
+    const double block = real ? 132.0 : 260.0, entry = real ? 96.0 : 192.0;
+    return block * (double)sys->nnzb + 4.0 * (double)(sys->nb + 1) +
+           entry * (double)vectors * (double)sys->nb;
+}
+
+int ensure_real_blocks(bdg_system* sys) {
+    if (sys->real_ready) return BDG_OK;
+    const size_t count = (size_t)std::max<int64_t>(1, sys->nnzb) * 16;
+    if (int rc = sys->blocks_real.reserve(count)) return rc;
+    const int grid = (int)std::min<size_t>(8192, (count + 255) / 256);
+    bdg::extract_real<<<grid, 256, 0, sys->stream>>>(sys->blocks.ptr, sys->blocks_real.ptr,
+                                                     (int64_t)sys->nnzb * 16);
+    HIP_TRY(hipGetLastError());
+    sys->real_ready = true;
+    return BDG_OK;
 }
 
 enum class StartKind { Random, Unit };
@@ -211,18 +250,28 @@ struct StartSpec {
 // [col0, col0 + n_active) of the (n_steps x ld) host arrays.
 int run_batch(bdg_system* sys, double scale, int n_steps, int n_active, const StartSpec& start,
               double* d_out, double* e_out, int ld, int col0, bool first_batch) {
+    // Real arithmetic applies when H has no imaginary part and the start vectors are real
+    // (±1 or unit vectors): every t_n then stays real.  BODGE_AMD_REAL=0 forces complex.
+    const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
+    const char* real_env = getenv("BODGE_AMD_REAL");
+    const bool real = sys->is_real && start_is_real && !(real_env && real_env[0] == '0');
+    const int per_lane = real ? RealMode::kVec : ComplexMode::kVec;
     // Fewer than 4 lanes per row would put 32-64 rows' blocks into one wave's LDS
-    // region with no reuse; small batches run as 4 columns with zero padding.
-    int rl = std::max(4, next_pow2(n_active));
-    if (sys->lanes_override >= n_active && sys->lanes_override >= 4)
+    // region with no reuse; small batches run with zero-padded columns.
+    int rl = std::max(4, next_pow2((n_active + per_lane - 1) / per_lane));
+    if (sys->lanes_override * per_lane >= n_active && sys->lanes_override >= 4 &&
+        sys->lanes_override * per_lane <= 64)
         rl = sys->lanes_override;
+    const int rv = rl * per_lane;  // vector columns in the buffers
     StepPlan plan;
-    if (int rc = make_plan(sys, rl, &plan)) return rc;
+    if (int rc = make_plan(sys, rl, real, &plan)) return rc;
+    if (real)
+        if (int rc = ensure_real_blocks(sys)) return rc;
 
-    const size_t vec_count = (size_t)4 * sys->nb * rl;
+    const size_t vec_count = (size_t)4 * sys->nb * rl;  // 16-byte lane payloads
     if (int rc = sys->vec_a.reserve(vec_count)) return rc;
     if (int rc = sys->vec_b.reserve(vec_count)) return rc;
-    const size_t width = (size_t)2 * rl;
+    const size_t width = (size_t)2 * rv;
     // keep the partial buffer below 256 MiB by reducing in chunks of steps
     const size_t per_step = (size_t)plan.grid * width;
     int chunk = (int)std::max<size_t>(1, std::min<size_t>(n_steps, (32u << 20) / per_step));
@@ -232,14 +281,23 @@ int run_batch(bdg_system* sys, double scale, int n_steps, int n_active, const St
     hipStream_t st = sys->stream;
     const int fill_grid = (int)std::min<size_t>(4096, (vec_count + 255) / 256);
     if (start.kind == StartKind::Random) {
-        bdg::fill_random<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, sys->nb, rl, n_active,
-                                                    start.seed, start.first_id, start.vec_kind);
+        if (real)
+            bdg::fill_random_real<<<fill_grid, 256, 0, st>>>(reinterpret_cast<double*>(sys->vec_a.ptr),
+                                                             sys->nb, rv, n_active, start.seed,
+                                                             start.first_id);
+        else
+            bdg::fill_random<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, sys->nb, rv, n_active,
+                                                        start.seed, start.first_id, start.vec_kind);
     } else {
         if (int rc = sys->rows.reserve(64)) return rc;
         HIP_TRY(hipMemcpyAsync(sys->rows.ptr, start.rows, sizeof(int64_t) * n_active,
                                hipMemcpyHostToDevice, st));
         bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, (int64_t)vec_count);
-        bdg::set_unit<<<1, 64, 0, st>>>(sys->vec_a.ptr, sys->nb, rl, n_active, sys->rows.ptr);
+        if (real)
+            bdg::set_unit_real<<<1, 64, 0, st>>>(reinterpret_cast<double*>(sys->vec_a.ptr), sys->nb, rv,
+                                                 n_active, sys->rows.ptr);
+        else
+            bdg::set_unit<<<1, 64, 0, st>>>(sys->vec_a.ptr, sys->nb, rv, n_active, sys->rows.ptr);
     }
     bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)vec_count);
     HIP_TRY(hipGetLastError());
@@ -247,7 +305,8 @@ int run_batch(bdg_system* sys, double scale, int n_steps, int n_active, const St
     bdg::StepArgs args{};
     args.indptr = sys->indptr.ptr;
     args.indices = sys->indices.ptr;
-    args.blocks = sys->blocks.ptr;
+    args.blocks = real ? static_cast<const void*>(sys->blocks_real.ptr)
+                       : static_cast<const void*>(sys->blocks.ptr);
     args.nb = (int)sys->nb;
     args.n_tiles = plan.n_tiles;
     args.max_row_blocks = sys->max_row_blocks;
@@ -290,9 +349,10 @@ int run_batch(bdg_system* sys, double scale, int n_steps, int n_active, const St
     p.kernel_ms += total_ms;
     p.launches += n_steps;
     p.vector_steps += (int64_t)n_steps * n_active;
-    p.bytes_per_launch = algorithmic_bytes(sys, rl);
+    p.bytes_per_launch = algorithmic_bytes(sys, rv, real);
     p.lanes_per_row = rl;
-    p.vectors_per_launch = rl;
+    p.vectors_per_launch = rv;
+    p.real_arithmetic = real ? 1 : 0;
     p.grid = plan.grid;
     p.lds_bytes = (int32_t)plan.lds_footprint;
     p.pipelined = plan.pipelined ? 1 : 0;
@@ -473,6 +533,8 @@ int bdg_create(int device, int64_t nb, int64_t nnzb, const int32_t* indptr, cons
                 return fail(BDG_EINVAL, "row %lld is not sorted / has duplicates", (long long)i);
         }
     }
+    bool is_real = true;
+    for (int64_t q = 0; q < nnzb * 16 && is_real; ++q) is_real = data[2 * q + 1] == 0.0;
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
         (void)hipGetLastError();
@@ -486,6 +548,7 @@ int bdg_create(int device, int64_t nb, int64_t nnzb, const int32_t* indptr, cons
     sys->nb = nb;
     sys->nnzb = nnzb;
     sys->max_row_blocks = std::max(1, max_row);
+    sys->is_real = is_real;
     hipDeviceProp_t prop;
     auto cleanup = [&](int rc) {
         bdg_destroy(sys);
@@ -517,6 +580,7 @@ int bdg_destroy(bdg_system* sys) {
     sys->indptr.release();
     sys->indices.release();
     sys->blocks.release();
+    sys->blocks_real.release();
     sys->vec_a.release();
     sys->vec_b.release();
     sys->partial.release();
@@ -531,7 +595,7 @@ int bdg_destroy(bdg_system* sys) {
 
 int bdg_set_lanes_per_row(bdg_system* sys, int32_t lanes) {
     if (!sys) return fail(BDG_EINVAL, "null system handle");
-    if (lanes != 0 && !step_kernel(lanes)) return fail(BDG_EINVAL, "lanes must be 4, 8, 16, 32 or 64");
+    if (lanes != 0 && !step_kernel(false, lanes)) return fail(BDG_EINVAL, "lanes must be 4, 8, 16, 32 or 64");
     sys->lanes_override = lanes;
     return BDG_OK;
 }
@@ -541,7 +605,7 @@ int bdg_spmv(bdg_system* sys, const double* x, double* y) {
     HIP_TRY(hipSetDevice(sys->device));
     constexpr int kCols = 4;  // narrowest kernel configuration; columns 1..3 stay zero
     StepPlan plan;
-    if (int rc = make_plan(sys, kCols, &plan)) return rc;
+    if (int rc = make_plan(sys, kCols, /*real=*/false, &plan)) return rc;
     const size_t n = (size_t)4 * sys->nb;
     if (int rc = sys->vec_a.reserve(n * kCols)) return rc;
     if (int rc = sys->vec_b.reserve(n * kCols)) return rc;

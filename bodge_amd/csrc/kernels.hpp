@@ -76,6 +76,30 @@ __global__ void fill_random(double2* __restrict__ vec, int64_t nb, int rv, int n
     }
 }
 
+// RealMode layout: double[α][site][rv]; only the Rademacher kind is real.
+__global__ void fill_random_real(double* __restrict__ vec, int64_t nb, int rv, int n_active,
+                                 uint64_t seed, uint64_t first_id) {
+    const int64_t total = 4 * nb * rv;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx % rv);
+        const int64_t site = (idx / rv) % nb;
+        const int alpha = (int)(idx / (rv * nb));
+        double v = 0.0;
+        if (r < n_active) v = start_entry(vector_key(seed, first_id + r), 4 * site + alpha, 0).x;
+        vec[idx] = v;
+    }
+}
+
+__global__ void set_unit_real(double* __restrict__ vec, int64_t nb, int rv, int n_active,
+                              const int64_t* __restrict__ rows) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_active) {
+        const int64_t row = rows[r];
+        vec[((row & 3) * nb + (row >> 2)) * rv + r] = 1.0;
+    }
+}
+
 __global__ void fill_zero(double2* __restrict__ vec, int64_t count) {
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < count;
          idx += (int64_t)gridDim.x * blockDim.x)
@@ -96,41 +120,112 @@ __global__ void set_unit(double2* __restrict__ vec, int64_t nb, int rv, int n_ac
 struct StepArgs {
     const int* indptr;
     const int* indices;
-    const double2* blocks;
-    const double2* cur;  // t_n      planar [4][nb][RL]
-    double2* prev;       // t_{n-1} in, t_{n+1} out (same site, same thread: in place)
-    double* partial;     // [gridDim.x][RL][2]
+    const void* blocks;   // ComplexMode: double2[nnzb][16]; RealMode: double[nnzb][16]
+    const double2* cur;   // t_n      planar [4][nb][RL] lane payloads
+    double2* prev;        // t_{n-1} in, t_{n+1} out (same site, same thread: in place)
+    double* partial;      // [gridDim.x][RL * kVec][2]
     double coef;
     int nb;
     int n_tiles;  // workgroup tiles of 4 * (64/RL) block rows
     int max_row_blocks;
 };
 
-__device__ inline void cmac(double2& acc, const double2 a, const double2 x) {
-    acc.x = fma(a.x, x.x, acc.x);
-    acc.x = fma(-a.y, x.y, acc.x);
-    acc.y = fma(a.x, x.y, acc.y);
-    acc.y = fma(a.y, x.x, acc.y);
+// Arithmetic modes.  A lane's 16-byte payload is either one complex number of
+// one vector (ComplexMode) or the real entries of two adjacent vectors
+// (RealMode, used when imag(H) == 0 and the start vectors are real: every t_n
+// is then real and half the bytes of both the matrix and the vectors vanish).
+// Memory access structure is the same in both: 16 B per lane everywhere.
+struct ComplexMode {
+    static constexpr int kVec = 1;          // vectors per lane
+    static constexpr int kSlotsPerBlock = 16;  // 16-byte staging slots holding one 4x4 block
+    static constexpr int kBlockStride = 17;    // padded slot stride in LDS
+    __device__ static inline void mac_row(double2 acc[4], const double2* blk, const double2 x[4]) {
+#pragma unroll
+        for (int al = 0; al < 4; ++al)
+#pragma unroll
+            for (int be = 0; be < 4; ++be) {
+                const double2 m = blk[al * 4 + be];
+                acc[al].x = fma(m.x, x[be].x, acc[al].x);
+                acc[al].x = fma(-m.y, x[be].y, acc[al].x);
+                acc[al].y = fma(m.x, x[be].y, acc[al].y);
+                acc[al].y = fma(m.y, x[be].x, acc[al].y);
+            }
+    }
+    // dot[0] = <c|c>, dot[1] = Re<n|c> for the lane's single vector
+    __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
+        dot[0] = fma(c.x, c.x, dot[0]);
+        dot[0] = fma(c.y, c.y, dot[0]);
+        dot[1] = fma(n.x, c.x, dot[1]);
+        dot[1] = fma(n.y, c.y, dot[1]);
+    }
+};
+
+struct RealMode {
+    static constexpr int kVec = 2;
+    static constexpr int kSlotsPerBlock = 8;
+    static constexpr int kBlockStride = 9;  // 144 B: keeps 16-B alignment, odd in 16-B units
+    __device__ static inline void mac_row(double2 acc[4], const double2* blk, const double2 x[4]) {
+#pragma unroll
+        for (int al = 0; al < 4; ++al)
+#pragma unroll
+            for (int pr = 0; pr < 2; ++pr) {
+                const double2 m = blk[al * 2 + pr];  // elements (al, 2pr) and (al, 2pr+1)
+                acc[al].x = fma(m.x, x[2 * pr].x, acc[al].x);
+                acc[al].y = fma(m.x, x[2 * pr].y, acc[al].y);
+                acc[al].x = fma(m.y, x[2 * pr + 1].x, acc[al].x);
+                acc[al].y = fma(m.y, x[2 * pr + 1].y, acc[al].y);
+            }
+    }
+    // dot[0], dot[1] for the first vector (.x), dot[2], dot[3] for the second (.y)
+    __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
+        dot[0] = fma(c.x, c.x, dot[0]);
+        dot[1] = fma(n.x, c.x, dot[1]);
+        dot[2] = fma(c.y, c.y, dot[2]);
+        dot[3] = fma(n.y, c.y, dot[3]);
+    }
+};
+
+// Wave reduction over the site lanes, then over the 4 waves through `red`,
+// one partial per workgroup: partial[block][vector][{d, e}].
+template <typename Mode, int RL>
+__device__ inline void reduce_dots(double dot[4], double* red, double* partial, int lane, int wave) {
+    constexpr int W = 2 * Mode::kVec;  // doubles per lane
+#pragma unroll
+    for (int off = kWave / 2; off >= RL; off >>= 1)
+#pragma unroll
+        for (int c = 0; c < W; ++c) dot[c] += __shfl_xor(dot[c], off);
+    if (lane < RL)
+#pragma unroll
+        for (int c = 0; c < W; ++c) red[(wave * RL + lane) * W + c] = dot[c];
+    __syncthreads();
+    if ((int)threadIdx.x < W * RL) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < kWavesPerBlock; ++w) tot += red[w * RL * W + threadIdx.x];
+        partial[(size_t)blockIdx.x * RL * W + threadIdx.x] = tot;
+    }
 }
 
-// RL = lanes per block row = vectors advanced together (1..64, power of two).
-// A wave owns 64/RL consecutive block rows; lane (s, r) produces the four
-// components of row s for vector r.  The wave stages its rows' blocks into a
-// private LDS region with fully coalesced 16-byte loads, then every lane reads
-// the block elements it needs as LDS broadcasts (the RL lanes of a row read
-// the same address).  No workgroup barrier inside the tile loop: LDS traffic of
-// one wave is ordered, and nothing is shared between waves until the final dot
-// reduction.
-template <int RL>
+// Generic form.  RL = lanes per block row (4..64); a wave owns 64/RL
+// consecutive block rows; lane (s, r) produces the four components of row s
+// for its vector(s).  The wave stages its rows' blocks into a private LDS
+// region with fully coalesced 16-byte streaming loads, then every lane reads
+// the block elements it needs as LDS broadcasts (the RL lanes of a row read the
+// same address).  No workgroup barrier inside the tile loop: LDS traffic of one
+// wave is ordered, and nothing is shared between waves until the dot reduction.
+template <typename Mode, int RL>
 __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
     extern __shared__ double2 lds[];
     constexpr int RW = kWave / RL;  // block rows per wave
+    constexpr int SPB = Mode::kSlotsPerBlock;
+    constexpr int STRIDE = Mode::kBlockStride;
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = threadIdx.x / kWave;
     const int s = lane / RL;
     const int r = lane % RL;
-    const int region = RW * a.max_row_blocks * kBlockSlots;
+    const int region = RW * a.max_row_blocks * STRIDE;
     double2* stage = lds + wave * region;
+    const double2* all_blocks = static_cast<const double2*>(a.blocks);
 
     // XCD-aware tile order: workgroups b, b+8, b+16, ... share an XCD (and its
     // L2), so each such group sweeps one contiguous eighth of the tiles.
@@ -141,7 +236,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
     const int t_hi = (int)(((int64_t)a.n_tiles * (xcd + 1)) >> 3);
 
     const size_t plane = (size_t)a.nb * RL;
-    double dsum = 0.0, esum = 0.0;
+    double dot[4] = {0.0, 0.0, 0.0, 0.0};
 
     for (int t = t_lo + slot; t < t_hi; t += slots) {
         const int row0 = (t * kWavesPerBlock + wave) * RW;
@@ -150,9 +245,9 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
         const int kb0 = a.indptr[row0];
         const int kb1 = a.indptr[row_end];
 
-        // -- stage this wave's blocks: element e of the run goes to slot (e/16)*17 + e%16
-        const int n_el = (kb1 - kb0) * 16;
-        const double2* src = a.blocks + (size_t)kb0 * 16;
+        // -- stage this wave's blocks: slot e of the run goes to (e / SPB) * STRIDE + e % SPB
+        const int n_el = (kb1 - kb0) * SPB;
+        const double2* src = all_blocks + (size_t)kb0 * SPB;
         for (int e0 = 0; e0 < n_el; e0 += 4 * kWave) {
             double2 v[4];
 #pragma unroll
@@ -163,7 +258,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
 #pragma unroll
             for (int u = 0; u < 4; ++u) {
                 const int e = e0 + u * kWave + lane;
-                if (e < n_el) stage[(e >> 4) * kBlockSlots + (e & 15)] = v[u];
+                if (e < n_el) stage[(e / SPB) * STRIDE + (e % SPB)] = v[u];
             }
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
@@ -192,11 +287,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
 #pragma unroll
                     for (int be = 0; be < 4; ++be) xn[be] = a.cur[be * plane + j * RL + r];
                 }
-                const double2* blk = stage + (k - kb0) * kBlockSlots;
-#pragma unroll
-                for (int al = 0; al < 4; ++al)
-#pragma unroll
-                    for (int be = 0; be < 4; ++be) cmac(acc[al], blk[al * 4 + be], x[be]);
+                Mode::mac_row(acc, stage + (k - kb0) * STRIDE, x);
             }
 
             const size_t own = (size_t)i * RL + r;
@@ -208,10 +299,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
                 nx.x = fma(a.coef, acc[al].x, -p.x);
                 nx.y = fma(a.coef, acc[al].y, -p.y);
                 a.prev[al * plane + own] = nx;
-                dsum = fma(c.x, c.x, dsum);
-                dsum = fma(c.y, c.y, dsum);
-                esum = fma(nx.x, c.x, esum);
-                esum = fma(nx.y, c.y, esum);
+                Mode::dots(dot, c, nx);
             }
         }
         // the next tile overwrites `stage`; same-wave LDS ops are ordered, the
@@ -220,25 +308,8 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
         __builtin_amdgcn_wave_barrier();
     }
 
-    // -- dot products: lanes with equal r across the wave, then across the 4 waves
-#pragma unroll
-    for (int off = kWave / 2; off >= RL; off >>= 1) {
-        dsum += __shfl_xor(dsum, off);
-        esum += __shfl_xor(esum, off);
-    }
     __syncthreads();  // every wave is done with its staging region
-    double* red = reinterpret_cast<double*>(lds);
-    if (lane < RL) {
-        red[(wave * RL + lane) * 2 + 0] = dsum;
-        red[(wave * RL + lane) * 2 + 1] = esum;
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 * RL) {
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < kWavesPerBlock; ++w) tot += red[w * RL * 2 + threadIdx.x];
-        a.partial[(size_t)blockIdx.x * RL * 2 + threadIdx.x] = tot;
-    }
+    reduce_dots<Mode, RL>(dot, reinterpret_cast<double*>(lds), a.partial, lane, wave);
 }
 
 // ----------------------------------------------------------- K1, pipelined form
@@ -248,25 +319,29 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
 //   loop over the wave's tiles:
 //     issue  matrix loads of tile n+1 -> registers (ML x 16 B per lane, streaming)
 //     issue  row metadata of tile n+1 (indptr pair, column indices)
-//     compute tile n from LDS (t_n gathers, 16 complex MACs per block, epilogue)
+//     compute tile n from LDS (t_n gathers, 16 MACs per block, epilogue)
 //     write  tile n+1 registers -> LDS   (same wave: LDS ops are ordered, no barrier)
 //
 // MAXB (compile time) is the largest number of blocks in any block row; it
 // fixes the LDS region and the register staging depth.  Matrices with longer
 // rows use the generic kernel above.
-template <int RL, int MAXB>
+template <typename Mode, int RL, int MAXB>
 __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a) {
-    constexpr int RW = kWave / RL;                    // block rows per wave
-    constexpr int NBLK = RW * MAXB;                   // most blocks a wave tile can hold
-    constexpr int ML = (NBLK * 16 + kWave - 1) / kWave;  // 16-byte loads per lane per tile
-    __shared__ double2 lds[kWavesPerBlock * NBLK * kBlockSlots];
-    __shared__ double red[kWavesPerBlock * RL * 2];
+    constexpr int RW = kWave / RL;   // block rows per wave
+    constexpr int NBLK = RW * MAXB;  // most blocks a wave tile can hold
+    constexpr int SPB = Mode::kSlotsPerBlock;
+    constexpr int STRIDE = Mode::kBlockStride;
+    constexpr int ML = (NBLK * SPB + kWave - 1) / kWave;  // 16-byte loads per lane per tile
+    constexpr int W = 2 * Mode::kVec;
+    __shared__ double2 lds[kWavesPerBlock * NBLK * STRIDE];
+    __shared__ double red[kWavesPerBlock * RL * W];
 
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int s = lane / RL;
     const int r = lane % RL;
-    double2* stage = lds + wave * (NBLK * kBlockSlots);
+    double2* stage = lds + wave * (NBLK * STRIDE);
+    const double2* all_blocks = static_cast<const double2*>(a.blocks);
 
     const int xcd = blockIdx.x & 7;
     const int slot = blockIdx.x >> 3;
@@ -297,13 +372,13 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
         n_el = 0;
         if (row0 < a.nb) {
             kb0 = a.indptr[row0];
-            n_el = (a.indptr[min(row0 + RW, a.nb)] - kb0) * 16;
+            n_el = (a.indptr[min(row0 + RW, a.nb)] - kb0) * SPB;
         }
     };
 
     double2 mreg[ML];
     auto issue_matrix = [&](int kb0, int n_el) {
-        const double2* src = a.blocks + (size_t)kb0 * 16;
+        const double2* src = all_blocks + (size_t)kb0 * SPB;
 #pragma unroll
         for (int u = 0; u < ML; ++u) {
             const int e = u * kWave + lane;
@@ -314,11 +389,11 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
 #pragma unroll
         for (int u = 0; u < ML; ++u) {
             const int e = u * kWave + lane;
-            if (e < n_el) stage[(e >> 4) * kBlockSlots + (e & 15)] = mreg[u];
+            if (e < n_el) stage[(e / SPB) * STRIDE + (e % SPB)] = mreg[u];
         }
     };
 
-    double dsum = 0.0, esum = 0.0;
+    double dot[4] = {0.0, 0.0, 0.0, 0.0};
 
     // ---- prologue: tile 0 into LDS, metadata of tile 0, span of tile 1
     int t = t_lo + slot;
@@ -357,7 +432,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
 #pragma unroll
                 for (int be = 0; be < 4; ++be) xn[be] = a.cur[be * plane + (size_t)meta.col[0] * RL + r];
             }
-            const double2* blk = stage + (meta.kbeg - kb0) * kBlockSlots;
+            const double2* blk = stage + (meta.kbeg - kb0) * STRIDE;
 #pragma unroll
             for (int q = 0; q < MAXB; ++q) {
                 if (q < len) {
@@ -368,11 +443,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
                         for (int be = 0; be < 4; ++be)
                             xn[be] = a.cur[be * plane + (size_t)meta.col[q + 1 < MAXB ? q + 1 : 0] * RL + r];
                     }
-#pragma unroll
-                    for (int al = 0; al < 4; ++al)
-#pragma unroll
-                        for (int be = 0; be < 4; ++be)
-                            cmac(acc[al], blk[q * kBlockSlots + al * 4 + be], x[be]);
+                    Mode::mac_row(acc, blk + q * STRIDE, x);
                 }
             }
 #pragma unroll
@@ -383,10 +454,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
                 nx.x = fma(a.coef, acc[al].x, -p.x);
                 nx.y = fma(a.coef, acc[al].y, -p.y);
                 a.prev[al * plane + own] = nx;
-                dsum = fma(c.x, c.x, dsum);
-                dsum = fma(c.y, c.y, dsum);
-                esum = fma(nx.x, c.x, esum);
-                esum = fma(nx.y, c.y, esum);
+                Mode::dots(dot, c, nx);
             }
         }
 
@@ -405,22 +473,15 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
         n_el_n = n_el_nn;
     }
 
-#pragma unroll
-    for (int off = kWave / 2; off >= RL; off >>= 1) {
-        dsum += __shfl_xor(dsum, off);
-        esum += __shfl_xor(esum, off);
-    }
-    if (lane < RL) {
-        red[(wave * RL + lane) * 2 + 0] = dsum;
-        red[(wave * RL + lane) * 2 + 1] = esum;
-    }
-    __syncthreads();
-    if (threadIdx.x < 2 * RL) {
-        double tot = 0.0;
-#pragma unroll
-        for (int w = 0; w < kWavesPerBlock; ++w) tot += red[w * RL * 2 + threadIdx.x];
-        a.partial[(size_t)blockIdx.x * RL * 2 + threadIdx.x] = tot;
-    }
+    reduce_dots<Mode, RL>(dot, red, a.partial, lane, wave);
+}
+
+// real[k][e] = Re blocks[k][e]   (device-side conversion for RealMode)
+__global__ void extract_real(const double2* __restrict__ blocks, double* __restrict__ real,
+                             int64_t count) {
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < count;
+         idx += (int64_t)gridDim.x * blockDim.x)
+        real[idx] = blocks[idx].x;
 }
 
 // ------------------------------------------------------------------------ K2

@@ -54,7 +54,7 @@ typedef struct bdg_perf {
     int32_t grid;          /* workgroups per launch                                  */
     int32_t lds_bytes;     /* LDS one workgroup occupies                             */
     int32_t pipelined;     /* 1 = register-prefetch kernel, 0 = generic kernel       */
-    int32_t reserved;
+    int32_t real_arithmetic; /* 1 = real-valued specialisation (imag(H)=0, real vectors) */
 } bdg_perf;
 
 const char* bdg_last_error(void);

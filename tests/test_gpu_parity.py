@@ -105,14 +105,43 @@ def test_unit_vector_moments_match_oracle(api, solver_cls):
     assert np.allclose(mu, ref, rtol=0, atol=1e-13)
 
 
-def test_lanes_override_gives_same_numbers(api, solver_cls):
-    system = _build(api, "dwave8")
+@pytest.mark.parametrize("name,n_vectors", [("dwave8", 5), ("swave20", 8), ("swave20", 64), ("chain128", 3)])
+def test_real_arithmetic_equals_complex_arithmetic(api, solver_cls, monkeypatch, name, n_vectors):
+    """imag(H) == 0 and ±1 start vectors select the real-valued kernels; they must agree with
+    the complex kernels (forced with BODGE_AMD_REAL=0) and with the oracle."""
+    system = _build(api, name)
+    bsr = system.matrix("bsr")
+    real_h = not np.any(bsr.data.imag)
+    scale = cheb_ref.spectral_bound(bsr)
+    steps = 24
+    with solver_cls.from_hamiltonian(system) as dev:
+        fast = dev.dots_random(scale, steps, n_vectors, seed=4)
+        assert dev.perf()["real_arithmetic"] == int(real_h)
+        unit_fast = dev.moments_unit(scale, 2 * steps, np.array([1, 6, 11]))
+        monkeypatch.setenv("BODGE_AMD_REAL", "0")
+        slow = dev.dots_random(scale, steps, n_vectors, seed=4)
+        assert dev.perf()["real_arithmetic"] == 0
+        unit_slow = dev.moments_unit(scale, 2 * steps, np.array([1, 6, 11]))
+    start = cheb_ref.random_block(bsr.shape[0], 4, range(n_vectors))
+    ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, start)
+    for got in (fast, slow):
+        assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * bsr.shape[0])
+        assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * bsr.shape[0])
+    assert np.allclose(unit_fast, unit_slow, rtol=0, atol=1e-13)
+
+
+@pytest.mark.parametrize("name,kind,lane_options", [
+    ("dwave8", cheb_ref.VEC_RADEMACHER, (4, 8, 16, 32)),  # real arithmetic: two vectors per lane
+    ("random357", cheb_ref.VEC_Z4, (4, 8, 16, 32, 64)),   # complex arithmetic
+])
+def test_lanes_override_gives_same_numbers(api, solver_cls, name, kind, lane_options):
+    system = _build(api, name)
     scale = cheb_ref.spectral_bound(system.matrix("bsr"))
     with solver_cls.from_hamiltonian(system) as dev:
-        base = dev.dots_random(scale, 10, 4, seed=1)
-        for lanes in (4, 8, 16, 32, 64):
+        base = dev.dots_random(scale, 10, 4, seed=1, kind=kind)
+        for lanes in lane_options:
             dev.set_lanes_per_row(lanes)
-            other = dev.dots_random(scale, 10, 4, seed=1)
+            other = dev.dots_random(scale, 10, 4, seed=1, kind=kind)
             assert dev.perf()["lanes_per_row"] == lanes
             assert np.allclose(other[0], base[0], rtol=1e-13) and np.allclose(other[1], base[1], rtol=1e-13, atol=1e-9)
 

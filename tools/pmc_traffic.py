@@ -1,0 +1,79 @@
+#!/usr/bin/env python3
+"""Turn rocprofv3 PMC passes into per-launch HBM traffic of the recurrence kernel.
+
+    # on the GPU box, one pass per counter (FETCH_SIZE and WRITE_SIZE do not fit one pass):
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT/pmc_FETCH_SIZE -- python3 bench.py --steps 8 --warmup 2 --cpu-seconds 0
+    rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d OUT/pmc_WRITE_SIZE -- python3 bench.py --steps 8 --warmup 2 --cpu-seconds 0
+    # then, anywhere:
+    python3 tools/pmc_traffic.py OUT/pmc_FETCH_SIZE OUT/pmc_WRITE_SIZE --workload "1000x1000x1 R=8" --out profiles/traffic.json
+
+Units and corrections follow MI355X_MICROARCH.md (HBM section): FETCH_SIZE and
+WRITE_SIZE are in KiB; on gfx950 FETCH_SIZE tallies the 128-byte requests of
+wide coalesced streaming reads at 64 bytes, so the read side is doubled;
+WRITE_SIZE is exact for 16-byte-per-lane stores.  bench.py looks the result up
+by kernel name and workload and reports it as `roofline.traffic`.
+"""
+
+import argparse
+import collections
+import csv
+import glob
+import json
+import os
+import re
+
+
+def kernel_key(name: str) -> str:
+    m = re.search(r"(cheb_step\w*)<bdg::(\w+), (\d+)", name)
+    return f"{m.group(1)}<{m.group(2)},{m.group(3)}>" if m else ""
+
+
+def collect(directory):
+    sums = collections.defaultdict(lambda: collections.defaultdict(list))
+    for path in glob.glob(os.path.join(directory, "**", "*counter_collection.csv"), recursive=True):
+        with open(path) as fh:
+            for row in csv.DictReader(fh):
+                key = kernel_key(row["Kernel_Name"])
+                if key:
+                    sums[key][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    return sums
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("dirs", nargs="+")
+    ap.add_argument("--workload", required=True)
+    ap.add_argument("--out", default="profiles/traffic.json")
+    args = ap.parse_args()
+    merged = collections.defaultdict(dict)
+    for d in args.dirs:
+        for kernel, counters in collect(d).items():
+            for counter, values in counters.items():
+                merged[kernel][counter] = (sum(values) / len(values), len(values))
+    table = {}
+    if os.path.exists(args.out):
+        with open(args.out) as fh:
+            table = json.load(fh)
+    for kernel, counters in merged.items():
+        if "FETCH_SIZE" not in counters or "WRITE_SIZE" not in counters:
+            continue
+        fetch_kib, n_f = counters["FETCH_SIZE"]
+        write_kib, n_w = counters["WRITE_SIZE"]
+        read_bytes = 2.0 * fetch_kib * 1024.0
+        write_bytes = write_kib * 1024.0
+        table[f"{kernel}|{args.workload}"] = {
+            "traffic_bytes_per_launch": read_bytes + write_bytes,
+            "read_bytes": read_bytes,
+            "write_bytes": write_bytes,
+            "FETCH_SIZE_KiB_raw": fetch_kib,
+            "WRITE_SIZE_KiB_raw": write_kib,
+            "launches_averaged": [n_f, n_w],
+            "correction": "read = 2 x FETCH_SIZE (gfx950 counts 128-B streaming requests as 64 B)",
+        }
+    with open(args.out, "w") as fh:
+        json.dump(table, fh, indent=1, sort_keys=True)
+    print(json.dumps(table, indent=1, sort_keys=True))
+
+
+if __name__ == "__main__":
+    main()
