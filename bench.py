@@ -104,6 +104,7 @@ def main():
     t_build = time.perf_counter() - t0
     device = local % backend.device_count()
     solver = DeviceSolver(indptr, indices, data, device=device)
+    solver.set_lattice_shape(shape)
     if args.lanes:
         solver.set_lanes_per_row(args.lanes)
     kind = VEC_RADEMACHER if args.vector_kind == "rademacher" else VEC_Z4
@@ -195,6 +196,7 @@ def main():
             "bytes_per_launch": perf["bytes_per_launch"],
             "grid": perf["grid"],
             "lds_bytes": perf["lds_bytes"],
+            "strip_rows": perf["strip_rows"],
         },
         "free_energy_wall_s": elapsed,
         "free_energy_estimate": free_energy,

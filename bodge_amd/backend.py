@@ -37,6 +37,8 @@ class Perf(C.Structure):
         ("lds_bytes", C.c_int32),
         ("pipelined", C.c_int32),
         ("real_arithmetic", C.c_int32),
+        ("strip_rows", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -61,6 +63,7 @@ SIGNATURES = {
     "bdg_random_vector": (C.c_int, [_handle, C.c_uint64, C.c_uint64, C.c_int32, _f64p]),
     "bdg_eigh_dense": (C.c_int, [_handle, _f64p, _f64p]),
     "bdg_perf_query": (C.c_int, [_handle, C.POINTER(Perf)]),
+    "bdg_set_lattice_shape": (C.c_int, [_handle, C.c_int32, C.c_int32, C.c_int32]),
     "bdg_set_lanes_per_row": (C.c_int, [_handle, C.c_int32]),
     "bdg_comm_unique_id": (C.c_int, [_u8p]),
     "bdg_comm_init": (C.c_int, [C.c_int, _u8p, C.c_int32, C.c_int32, C.POINTER(_handle)]),

@@ -20,6 +20,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <tuple>
 #include <vector>
 
 #include "kernels.hpp"
@@ -94,6 +95,10 @@ struct bdg_system {
     DeviceBuffer<double2> vec_a, vec_b;
     DeviceBuffer<double> partial, dots;
     DeviceBuffer<int64_t> rows;
+    // lattice geometry hint (rows = z + lz*(y + ly*x)) and the cached strip-major tile order
+    int shape[3] = {0, 0, 0};
+    DeviceBuffer<int> tile_order;
+    int order_rows_per_tile = 0, order_strip_rows = 0;
     bdg_perf perf{};
 };
 
@@ -237,6 +242,52 @@ int ensure_real_blocks(bdg_system* sys) {
     return BDG_OK;
 }
 
+// Strip-major tile order for lattice matrices.  Block rows are numbered
+// z + lz*(y + ly*x): neighbours along x are a whole plane (ly*lz rows) apart, so a
+// sweep in natural order re-touches a t_n line only after 2*ly*lz rows of other
+// traffic.  When that exceeds what the XCD's 4 MB L2 keeps, the planes are cut
+// into strips of `strip_rows` consecutive rows and the sweep runs along x inside
+// one strip before moving to the next; the re-use distance becomes 2*strip_rows.
+// Returns nullptr (natural order) when no geometry is known or one strip suffices.
+int prepare_tile_order(bdg_system* sys, int rows_per_tile, int n_tiles, double row_bytes,
+                       const int** order_out, int* strip_out) {
+    *order_out = nullptr;
+    *strip_out = 0;
+    const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
+    if (plane <= 0 || (int64_t)sys->shape[0] * plane != sys->nb) return BDG_OK;
+    double budget = 1024.0 * 1024.0;  // bytes of t_n lines an XCD should have to hold between re-uses
+    if (const char* env = getenv("BODGE_AMD_L2_BUDGET")) budget = atof(env);
+    int64_t strip = (int64_t)(budget / (2.0 * row_bytes));
+    strip = std::max<int64_t>(rows_per_tile, strip / rows_per_tile * rows_per_tile);
+    if (strip >= plane || budget <= 0) return BDG_OK;
+    *strip_out = (int)strip;
+    if (sys->order_rows_per_tile == rows_per_tile && sys->order_strip_rows == strip) {
+        *order_out = sys->tile_order.ptr;
+        return BDG_OK;
+    }
+    // Tile t (first row r0 = t * rows_per_tile) belongs to plane x = r0 / plane and strip
+    // (r0 % plane) / strip; emit strip by strip, plane by plane, ascending inside.  O(n_tiles).
+    std::vector<int> order;
+    order.reserve(n_tiles);
+    const int64_t T = rows_per_tile;
+    for (int64_t lo_w = 0; lo_w < plane; lo_w += strip) {
+        const int64_t hi_w = std::min(plane, lo_w + strip);
+        for (int64_t x = 0; x < sys->shape[0]; ++x) {
+            const int64_t first = (x * plane + lo_w + T - 1) / T;  // first tile starting in the window
+            const int64_t last = (x * plane + hi_w + T - 1) / T;   // one past the last such tile
+            for (int64_t t = first; t < last && t < n_tiles; ++t) order.push_back((int)t);
+        }
+    }
+    if ((int)order.size() != n_tiles)
+        return fail(BDG_EDEVICE, "internal error: tile order has %zu of %d tiles", order.size(), n_tiles);
+    if (int rc = sys->tile_order.reserve((size_t)n_tiles)) return rc;
+    HIP_TRY(hipMemcpy(sys->tile_order.ptr, order.data(), sizeof(int) * n_tiles, hipMemcpyHostToDevice));
+    sys->order_rows_per_tile = rows_per_tile;
+    sys->order_strip_rows = (int)strip;
+    *order_out = sys->tile_order.ptr;
+    return BDG_OK;
+}
+
 enum class StartKind { Random, Unit };
 
 struct StartSpec {
@@ -310,6 +361,11 @@ int run_batch(bdg_system* sys, double scale, int n_steps, int n_active, const St
     args.nb = (int)sys->nb;
     args.n_tiles = plan.n_tiles;
     args.max_row_blocks = sys->max_row_blocks;
+    int strip_rows = 0;
+    // bytes of t_n per block row that neighbouring rows re-read: 4 entries per vector
+    if (int rc = prepare_tile_order(sys, plan.rows_per_tile, plan.n_tiles, (real ? 32.0 : 64.0) * rv,
+                                    &args.tile_order, &strip_rows))
+        return rc;
 
     double2* cur = sys->vec_a.ptr;
     double2* prev = sys->vec_b.ptr;
@@ -353,6 +409,7 @@ int run_batch(bdg_system* sys, double scale, int n_steps, int n_active, const St
     p.lanes_per_row = rl;
     p.vectors_per_launch = rv;
     p.real_arithmetic = real ? 1 : 0;
+    p.strip_rows = strip_rows;
     p.grid = plan.grid;
     p.lds_bytes = (int32_t)plan.lds_footprint;
     p.pipelined = plan.pipelined ? 1 : 0;
@@ -586,10 +643,24 @@ int bdg_destroy(bdg_system* sys) {
     sys->partial.release();
     sys->dots.release();
     sys->rows.release();
+    sys->tile_order.release();
     if (sys->ev_start) (void)hipEventDestroy(sys->ev_start);
     if (sys->ev_stop) (void)hipEventDestroy(sys->ev_stop);
     if (sys->stream) (void)hipStreamDestroy(sys->stream);
     delete sys;
+    return BDG_OK;
+}
+
+int bdg_set_lattice_shape(bdg_system* sys, int32_t lx, int32_t ly, int32_t lz) {
+    if (!sys) return fail(BDG_EINVAL, "null system handle");
+    if (lx < 0 || ly < 0 || lz < 0) return fail(BDG_EINVAL, "negative lattice extent");
+    if ((int64_t)lx * ly * lz != sys->nb && (lx | ly | lz) != 0)
+        return fail(BDG_EINVAL, "lattice %dx%dx%d does not have %lld sites", lx, ly, lz,
+                    (long long)sys->nb);
+    sys->shape[0] = lx;
+    sys->shape[1] = ly;
+    sys->shape[2] = lz;
+    sys->order_rows_per_tile = 0;
     return BDG_OK;
 }
 

@@ -124,6 +124,7 @@ struct StepArgs {
     const double2* cur;   // t_n      planar [4][nb][RL] lane payloads
     double2* prev;        // t_{n-1} in, t_{n+1} out (same site, same thread: in place)
     double* partial;      // [gridDim.x][RL * kVec][2]
+    const int* tile_order;  // optional permutation of workgroup tiles (nullptr = natural order)
     double coef;
     int nb;
     int n_tiles;  // workgroup tiles of 4 * (64/RL) block rows
@@ -239,7 +240,8 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
     double dot[4] = {0.0, 0.0, 0.0, 0.0};
 
     for (int t = t_lo + slot; t < t_hi; t += slots) {
-        const int row0 = (t * kWavesPerBlock + wave) * RW;
+        const int tile = a.tile_order ? a.tile_order[t] : t;
+        const int row0 = (tile * kWavesPerBlock + wave) * RW;
         if (row0 >= a.nb) continue;
         const int row_end = min(row0 + RW, a.nb);
         const int kb0 = a.indptr[row0];
@@ -351,7 +353,11 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
     const size_t plane = (size_t)a.nb * RL;
 
     // tile -> first block row of this wave (>= nb means "no work")
-    auto first_row = [&](int t) { return t < t_hi ? (t * kWavesPerBlock + wave) * RW : a.nb; };
+    auto first_row = [&](int t) {
+        if (t >= t_hi) return a.nb;
+        const int tile = a.tile_order ? a.tile_order[t] : t;
+        return (tile * kWavesPerBlock + wave) * RW;
+    };
 
     struct RowMeta {
         int kbeg, kend;
@@ -396,27 +402,28 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
     double dot[4] = {0.0, 0.0, 0.0, 0.0};
 
     // ---- prologue: tile 0 into LDS, metadata of tile 0, span of tile 1
-    int t = t_lo + slot;
-    int row0 = first_row(t);
+    // `pos` walks this workgroup's positions in the (possibly permuted) tile order; a
+    // position whose rows fall beyond nb (ragged last tile) simply has no work.
+    int pos = t_lo + slot;
+    int row0 = first_row(pos);
     int kb0, n_el;
     tile_span(row0, kb0, n_el);
     RowMeta meta;
     load_meta(row0, meta);
     issue_matrix(kb0, n_el);
-    int row0_n = first_row(t + slots);
+    int row0_n = first_row(pos + slots);
     int kb0_n, n_el_n;
     tile_span(row0_n, kb0_n, n_el_n);
     commit_matrix(n_el);
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
     __builtin_amdgcn_wave_barrier();
 
-    while (row0 < a.nb) {
+    for (; pos < t_hi; pos += slots) {
         // ---- prefetch tile n+1 (registers) and the span of tile n+2
         issue_matrix(kb0_n, n_el_n);
         RowMeta meta_n;
         load_meta(row0_n, meta_n);
-        t += slots;
-        const int row0_nn = first_row(t + slots);
+        const int row0_nn = first_row(pos + 2 * slots);
         int kb0_nn, n_el_nn;
         tile_span(row0_nn, kb0_nn, n_el_nn);
 

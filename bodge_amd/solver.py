@@ -45,7 +45,17 @@ class DeviceSolver:
     @classmethod
     def from_hamiltonian(cls, system, device: int | None = None, drop_zero_blocks: bool = True):
         indptr, indices, data = system.bsr_arrays(drop_zero_blocks=drop_zero_blocks)
-        return cls(indptr, indices, data, device=device)
+        solver = cls(indptr, indices, data, device=device)
+        from .lattice import CubicLattice
+
+        if isinstance(system.lattice, CubicLattice):
+            solver.set_lattice_shape(system.lattice.shape)
+        return solver
+
+    def set_lattice_shape(self, shape) -> None:
+        """Geometry hint (performance only): rows are numbered z + Lz*(y + Ly*x)."""
+        lx, ly, lz = (int(v) for v in shape)
+        backend.check(self._lib.bdg_set_lattice_shape(self._handle, lx, ly, lz))
 
     # ------------------------------------------------------------------ lifetime
     def close(self) -> None:

@@ -55,6 +55,8 @@ typedef struct bdg_perf {
     int32_t lds_bytes;     /* LDS one workgroup occupies                             */
     int32_t pipelined;     /* 1 = register-prefetch kernel, 0 = generic kernel       */
     int32_t real_arithmetic; /* 1 = real-valued specialisation (imag(H)=0, real vectors) */
+    int32_t strip_rows;    /* strip width of the tile order in block rows, 0 = natural order */
+    int32_t reserved;
 } bdg_perf;
 
 const char* bdg_last_error(void);
@@ -121,6 +123,14 @@ int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t v
 int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out);
 
 int bdg_perf_query(bdg_system* sys, bdg_perf* out);
+
+/*
+ * Optional geometry hint: block row i is site (x, y, z) of an lx x ly x lz cubic
+ * lattice with i = z + lz*(y + ly*x) (reference lattice.py:108).  Lets the library
+ * order its row tiles strip-major so that neighbour re-reads stay in L2.  Pure
+ * performance hint: results do not depend on it.  (0,0,0) clears it.
+ */
+int bdg_set_lattice_shape(bdg_system* sys, int32_t lx, int32_t ly, int32_t lz);
 
 /* Tuning override for experiments: lanes per block row (0 = automatic). */
 int bdg_set_lanes_per_row(bdg_system* sys, int32_t lanes);

@@ -130,6 +130,46 @@ def test_real_arithmetic_equals_complex_arithmetic(api, solver_cls, monkeypatch,
     assert np.allclose(unit_fast, unit_slow, rtol=0, atol=1e-13)
 
 
+def _plain_lattice_system(api, shape, complex_terms):
+    lattice = api.CubicLattice(shape)
+    system = api.Hamiltonian(lattice)
+    with system as (H, Δ):
+        H.set_sites(2.5 * api.σ0 - 0.1 * api.σ3 + (0.2 * api.σ2 if complex_terms else 0))
+        Δ.set_sites(-0.3 * api.jσ2)
+        H.set_bonds(-1.0 * api.σ0)
+        H.set_edges(-0.4 * api.σ0, axis=1)
+    return system
+
+
+@pytest.mark.parametrize("shape,n_vectors,kind,complex_terms", [
+    ((6, 150, 1), 8, cheb_ref.VEC_Z4, True),            # 900 rows, 32-row tiles: ragged tile mid-order
+    ((5, 10, 31), 16, cheb_ref.VEC_RADEMACHER, False),  # 3-D real, plane of 310 rows, ragged
+    ((3, 500, 1), 64, cheb_ref.VEC_Z4, False),          # 4-row tiles, many strips
+    ((7, 90, 1), 5, cheb_ref.VEC_RADEMACHER, False),    # generic (RL=4) kernel, 64-row tiles
+])
+def test_strip_ordered_tiles_do_not_change_results(api, solver_cls, monkeypatch, shape, n_vectors, kind,
+                                                    complex_terms):
+    """The geometry hint only permutes the order in which row tiles are processed."""
+    system = _plain_lattice_system(api, shape, complex_terms)
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    ref = cheb_ref.recurrence_dots(bsr, scale, 24, cheb_ref.random_block(bsr.shape[0], 2, range(n_vectors), kind))
+    with solver_cls.from_hamiltonian(system) as dev:
+        dev.set_lattice_shape((0, 0, 0))
+        natural = dev.dots_random(scale, 12, n_vectors, seed=2, kind=kind)
+        assert dev.perf()["strip_rows"] == 0
+        dev.set_lattice_shape(shape)
+        monkeypatch.setenv("BODGE_AMD_L2_BUDGET", "4096")  # absurdly small: forces the narrowest strips
+        strips = dev.dots_random(scale, 12, n_vectors, seed=2, kind=kind)
+        assert 0 < dev.perf()["strip_rows"] < shape[1] * shape[2]
+        with pytest.raises(ValueError):
+            dev.set_lattice_shape((3, 3, 3))
+    mu0 = system.shape[0]
+    for got in (natural, strips):
+        assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * mu0)
+        assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * mu0)
+
+
 @pytest.mark.parametrize("name,kind,lane_options", [
     ("dwave8", cheb_ref.VEC_RADEMACHER, (4, 8, 16, 32)),  # real arithmetic: two vectors per lane
     ("random357", cheb_ref.VEC_Z4, (4, 8, 16, 32, 64)),   # complex arithmetic
