@@ -13,7 +13,9 @@ import os
 
 import numpy as np
 
-LIBRARY_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libbodge_hip.so")
+LIBRARY_PATH = os.environ.get(  # override: A/B experiments with a second build of the same source
+    "BODGE_AMD_LIBRARY", os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", "libbodge_hip.so")
+)
 
 VEC_RADEMACHER = 0
 VEC_Z4 = 1

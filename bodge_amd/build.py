@@ -36,13 +36,17 @@ def is_stale() -> bool:
     return any(os.path.getmtime(p) > built for p in SOURCES + HEADERS)
 
 
-def build_library(force: bool = False, verbose: bool = False) -> str:
-    if not force and not is_stale():
+def build_library(force: bool = False, verbose: bool = False, output: str | None = None,
+                  defines: tuple[str, ...] = ()) -> str:
+    """Compile to `output` (default: the in-tree library).  `defines` are extra -D macros,
+    used only for A/B experiments that build a second library next to the product one."""
+    target = output or LIBRARY
+    if output is None and not force and not is_stale():
         return LIBRARY
     cmd = [
         _hipcc(), "-O3", "-std=c++17", f"--offload-arch={ARCH}", "-fPIC", "-shared",
-        "-Wall", "-Wno-unused-result", f"-I{INCLUDE}", f"-I{CSRC}",
-        "-o", LIBRARY + f".{os.getpid()}.tmp", *SOURCES, "-ldl",
+        "-Wall", "-Wno-unused-result", f"-I{INCLUDE}", f"-I{CSRC}", *[f"-D{d}" for d in defines],
+        "-o", target + f".{os.getpid()}.tmp", *SOURCES, "-ldl",
     ]
     if verbose:
         print(" ".join(cmd), flush=True)
@@ -51,8 +55,8 @@ def build_library(force: bool = False, verbose: bool = False) -> str:
         raise RuntimeError(f"hipcc failed:\n{proc.stdout}\n{proc.stderr}")
     if verbose and proc.stderr.strip():
         print(proc.stderr, file=sys.stderr)
-    os.replace(LIBRARY + f".{os.getpid()}.tmp", LIBRARY)  # atomic: never expose a partial file
-    return LIBRARY
+    os.replace(target + f".{os.getpid()}.tmp", target)  # atomic: never expose a partial file
+    return target
 
 
 if __name__ == "__main__":

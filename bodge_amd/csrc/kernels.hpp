@@ -38,6 +38,29 @@ __device__ inline double2 load_stream(const double2* p) {
     return make_double2(v.x, v.y);
 }
 
+// Flat slot of (component alpha, block row `site`, lane payload r) in a vector buffer
+// with rv payloads per (site, component).  Planar: one plane per component.
+#ifndef BDG_LAYOUT_INTERLEAVED
+#define BDG_LAYOUT_INTERLEAVED 0
+#endif
+__host__ __device__ inline size_t vslot(int alpha, size_t site, int r, size_t nb, int rv) {
+#if BDG_LAYOUT_INTERLEAVED
+    return (site * 4 + alpha) * rv + r;
+#else
+    return ((size_t)alpha * nb + site) * rv + r;
+#endif
+}
+// inverse of vslot / rv: (alpha, site) of the idx-th (site, component) pair
+__host__ __device__ inline void vpair(int64_t pair, int64_t nb, int& alpha, int64_t& site) {
+#if BDG_LAYOUT_INTERLEAVED
+    site = pair >> 2;
+    alpha = (int)(pair & 3);
+#else
+    alpha = (int)(pair / nb);
+    site = pair % nb;
+#endif
+}
+
 // ------------------------------------------------------------------ RNG (K3)
 __host__ __device__ inline uint64_t splitmix64(uint64_t x) {
     uint64_t z = x + 0x9E3779B97F4A7C15ull;
@@ -68,8 +91,9 @@ __global__ void fill_random(double2* __restrict__ vec, int64_t nb, int rv, int n
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(idx % rv);
-        const int64_t site = (idx / rv) % nb;
-        const int alpha = (int)(idx / (rv * nb));
+        int alpha;
+        int64_t site;
+        vpair(idx / rv, nb, alpha, site);
         double2 v = make_double2(0.0, 0.0);
         if (r < n_active) v = start_entry(vector_key(seed, first_id + r), 4 * site + alpha, kind);
         vec[idx] = v;
@@ -83,8 +107,9 @@ __global__ void fill_random_real(double* __restrict__ vec, int64_t nb, int rv, i
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(idx % rv);
-        const int64_t site = (idx / rv) % nb;
-        const int alpha = (int)(idx / (rv * nb));
+        int alpha;
+        int64_t site;
+        vpair(idx / rv, nb, alpha, site);
         double v = 0.0;
         if (r < n_active) v = start_entry(vector_key(seed, first_id + r), 4 * site + alpha, 0).x;
         vec[idx] = v;
@@ -96,7 +121,7 @@ __global__ void set_unit_real(double* __restrict__ vec, int64_t nb, int rv, int 
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n_active) {
         const int64_t row = rows[r];
-        vec[((row & 3) * nb + (row >> 2)) * rv + r] = 1.0;
+        vec[vslot((int)(row & 3), (size_t)(row >> 2), r, (size_t)nb, rv)] = 1.0;
     }
 }
 
@@ -112,7 +137,7 @@ __global__ void set_unit(double2* __restrict__ vec, int64_t nb, int rv, int n_ac
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n_active) {
         const int64_t row = rows[r];
-        vec[((row & 3) * nb + (row >> 2)) * rv + r] = make_double2(1.0, 0.0);
+        vec[vslot((int)(row & 3), (size_t)(row >> 2), r, (size_t)nb, rv)] = make_double2(1.0, 0.0);
     }
 }
 
@@ -236,7 +261,6 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
     const int t_lo = (int)(((int64_t)a.n_tiles * xcd) >> 3);
     const int t_hi = (int)(((int64_t)a.n_tiles * (xcd + 1)) >> 3);
 
-    const size_t plane = (size_t)a.nb * RL;
     double dot[4] = {0.0, 0.0, 0.0, 0.0};
 
     for (int t = t_lo + slot; t < t_hi; t += slots) {
@@ -279,7 +303,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
             if (kbeg < kend) {
                 const size_t j = (size_t)a.indices[kbeg];
 #pragma unroll
-                for (int be = 0; be < 4; ++be) xn[be] = a.cur[be * plane + j * RL + r];
+                for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, j, r, a.nb, RL)];
             }
             for (int k = kbeg; k < kend; ++k) {
 #pragma unroll
@@ -287,20 +311,20 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
                 if (k + 1 < kend) {
                     const size_t j = (size_t)a.indices[k + 1];
 #pragma unroll
-                    for (int be = 0; be < 4; ++be) xn[be] = a.cur[be * plane + j * RL + r];
+                    for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, j, r, a.nb, RL)];
                 }
                 Mode::mac_row(acc, stage + (k - kb0) * STRIDE, x);
             }
 
-            const size_t own = (size_t)i * RL + r;
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
-                const double2 p = a.prev[al * plane + own];
-                const double2 c = a.cur[al * plane + own];
+                const size_t own = vslot(al, (size_t)i, r, a.nb, RL);
+                const double2 p = a.prev[own];
+                const double2 c = a.cur[own];
                 double2 nx;
                 nx.x = fma(a.coef, acc[al].x, -p.x);
                 nx.y = fma(a.coef, acc[al].y, -p.y);
-                a.prev[al * plane + own] = nx;
+                a.prev[own] = nx;
                 Mode::dots(dot, c, nx);
             }
         }
@@ -350,7 +374,6 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
     const int slots = gridDim.x >> 3;
     const int t_lo = (int)(((int64_t)a.n_tiles * xcd) >> 3);
     const int t_hi = (int)(((int64_t)a.n_tiles * (xcd + 1)) >> 3);
-    const size_t plane = (size_t)a.nb * RL;
 
     // tile -> first block row of this wave (>= nb means "no work")
     auto first_row = [&](int t) {
@@ -430,14 +453,13 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
         // ---- compute tile n
         const int i = row0 + s;
         if (i < a.nb) {
-            const size_t own = (size_t)i * RL + r;
             double2 acc[4], x[4], xn[4];
 #pragma unroll
             for (int al = 0; al < 4; ++al) acc[al] = make_double2(0.0, 0.0);
             const int len = meta.kend - meta.kbeg;
             if (len > 0) {
 #pragma unroll
-                for (int be = 0; be < 4; ++be) xn[be] = a.cur[be * plane + (size_t)meta.col[0] * RL + r];
+                for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, (size_t)meta.col[0], r, a.nb, RL)];
             }
             const double2* blk = stage + (meta.kbeg - kb0) * STRIDE;
 #pragma unroll
@@ -448,19 +470,20 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
                     if (q + 1 < MAXB && q + 1 < len) {
 #pragma unroll
                         for (int be = 0; be < 4; ++be)
-                            xn[be] = a.cur[be * plane + (size_t)meta.col[q + 1 < MAXB ? q + 1 : 0] * RL + r];
+                            xn[be] = a.cur[vslot(be, (size_t)meta.col[q + 1 < MAXB ? q + 1 : 0], r, a.nb, RL)];
                     }
                     Mode::mac_row(acc, blk + q * STRIDE, x);
                 }
             }
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
-                const double2 p = a.prev[al * plane + own];
-                const double2 c = a.cur[al * plane + own];
+                const size_t own = vslot(al, (size_t)i, r, a.nb, RL);
+                const double2 p = a.prev[own];
+                const double2 c = a.cur[own];
                 double2 nx;
                 nx.x = fma(a.coef, acc[al].x, -p.x);
                 nx.y = fma(a.coef, acc[al].y, -p.y);
-                a.prev[al * plane + own] = nx;
+                a.prev[own] = nx;
                 Mode::dots(dot, c, nx);
             }
         }
@@ -524,14 +547,14 @@ __global__ void planar_from_sitemajor(const double2* __restrict__ x, double2* __
                                       int64_t nb, int rv, int r) {
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < 4 * nb;
          idx += (int64_t)gridDim.x * blockDim.x)
-        planar[((idx & 3) * nb + (idx >> 2)) * rv + r] = x[idx];
+        planar[vslot((int)(idx & 3), (size_t)(idx >> 2), r, (size_t)nb, rv)] = x[idx];
 }
 
 __global__ void sitemajor_from_planar(const double2* __restrict__ planar, double2* __restrict__ x,
                                       int64_t nb, int rv, int r) {
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < 4 * nb;
          idx += (int64_t)gridDim.x * blockDim.x)
-        x[idx] = planar[((idx & 3) * nb + (idx >> 2)) * rv + r];
+        x[idx] = planar[vslot((int)(idx & 3), (size_t)(idx >> 2), r, (size_t)nb, rv)];
 }
 
 }  // namespace bdg

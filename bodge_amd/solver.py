@@ -162,6 +162,22 @@ class DeviceSolver:
 
 
 # ---------------------------------------------------------------------------
+class _StdoutToStderr:
+    """RCCL prints a version banner on stdout at communicator creation; programs that emit
+    machine-readable stdout (bench.py's single JSON line) must not see it."""
+
+    def __enter__(self):
+        import sys
+
+        sys.stdout.flush()
+        self._saved = os.dup(1)
+        os.dup2(2, 1)
+
+    def __exit__(self, *exc):
+        os.dup2(self._saved, 1)
+        os.close(self._saved)
+
+
 class Communicator:
     """One RCCL rank.  The 128-byte unique id travels through a rendezvous file."""
 
@@ -171,12 +187,14 @@ class Communicator:
         self.rank, self.n_ranks, self.device = rank, n_ranks, device
         self._handle = C.c_void_p()
         buf = (C.c_uint8 * 128).from_buffer_copy(unique_id)
-        backend.check(lib.bdg_comm_init(device, buf, n_ranks, rank, C.byref(self._handle)))
+        with _StdoutToStderr():
+            backend.check(lib.bdg_comm_init(device, buf, n_ranks, rank, C.byref(self._handle)))
 
     @staticmethod
     def new_unique_id() -> bytes:
         buf = (C.c_uint8 * 128)()
-        backend.check(backend.load().bdg_comm_unique_id(buf))
+        with _StdoutToStderr():
+            backend.check(backend.load().bdg_comm_unique_id(buf))
         return bytes(buf)
 
     @classmethod
@@ -189,9 +207,9 @@ class Communicator:
         Returns None for a single-process run.
         """
         world = int(os.environ.get("WORLD_SIZE", "1"))
-        if world <= 1:
-            return None
-        rank = int(os.environ["RANK"])
+        if world <= 1 and os.environ.get("BODGE_AMD_FORCE_COMM") != "1":
+            return None  # (the override builds a one-rank communicator: exercises the RCCL path on one GPU)
+        rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", rank))
         tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
         path = os.path.join(os.environ.get("BODGE_AMD_RDZV_DIR", "/tmp"), f"bodge_amd_rccl_{tag}.id")
