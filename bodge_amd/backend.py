@@ -50,6 +50,18 @@ SIGNATURES = {
     "bdg_version": (C.c_char_p, []),
     "bdg_device_count": (C.c_int, [C.POINTER(C.c_int)]),
     "bdg_create": (C.c_int, [C.c_int, C.c_int64, C.c_int64, _i32p, _i32p, _f64p, C.POINTER(_handle)]),
+    "bdg_create_slab": (
+        C.c_int,
+        [C.c_int, C.c_int64, C.c_int64, C.c_int64, _i32p, _i32p, _f64p, C.c_int64, C.POINTER(_handle)],
+    ),
+    "bdg_slab_set_exchange": (C.c_int, [_handle, _handle, C.c_int32, _i32p, _i64p, _i64p, _i64p, _i64p]),
+    "bdg_group_create": (C.c_int, [C.POINTER(_handle), C.c_int32, C.POINTER(_handle)]),
+    "bdg_group_destroy": (C.c_int, [_handle]),
+    "bdg_group_dots_random": (
+        C.c_int,
+        [_handle, C.c_double, C.c_int32, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, _f64p, _f64p],
+    ),
+    "bdg_group_dots_unit": (C.c_int, [_handle, C.c_double, C.c_int32, C.c_int32, _i64p, _f64p, _f64p]),
     "bdg_destroy": (C.c_int, [_handle]),
     "bdg_spmv": (C.c_int, [_handle, _f64p, _f64p]),
     "bdg_cheb_dots_random": (

@@ -79,11 +79,27 @@ int next_pow2(int v) {
 
 }  // namespace
 
+struct ExchangePeer {
+    int rank = 0;            // peer's rank (RCCL) or member index (same-process group)
+    int64_t send_begin = 0;  // offset into send_rows / send buffer rows
+    int64_t send_count = 0;
+    int64_t recv_col = 0;    // first local column of the rows received from this peer
+    int64_t recv_begin = 0;  // offset into the receive buffer rows
+    int64_t recv_count = 0;
+};
+
 struct bdg_system {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     int64_t nb = 0, nnzb = 0;
+    int64_t ncols = 0;       // block rows of the vector buffers: nb owned + halo
+    int64_t row_offset = 0;  // global block row of local row 0 (slab mode)
+    std::vector<ExchangePeer> peers;
+    DeviceBuffer<int64_t> send_rows;
+    DeviceBuffer<double2> send_buf, recv_buf;
+    int64_t send_total = 0, recv_total = 0;
+    bdg_comm* slab_comm = nullptr;  // RCCL transport for the halo exchange (not owned)
     int max_row_blocks = 0;
     int num_cus = 0;
     int lanes_override = 0;
@@ -108,6 +124,11 @@ struct bdg_comm {
     ncclComm_t comm = nullptr;
     hipStream_t stream = nullptr;
     DeviceBuffer<double> scratch;
+};
+
+struct bdg_group {
+    std::vector<bdg_system*> members;
+    std::vector<hipEvent_t> packed, copied;  // per member
 };
 
 namespace {
@@ -297,144 +318,6 @@ struct StartSpec {
     const int64_t* rows = nullptr;  // host
 };
 
-// Advance `n_active` (<= 64) vectors for n_steps; write d/e into columns
-// [col0, col0 + n_active) of the (n_steps x ld) host arrays.
-int run_batch(bdg_system* sys, double scale, int n_steps, int n_active, const StartSpec& start,
-              double* d_out, double* e_out, int ld, int col0, bool first_batch) {
-    // Real arithmetic applies when H has no imaginary part and the start vectors are real
-    // (±1 or unit vectors): every t_n then stays real.  BODGE_AMD_REAL=0 forces complex.
-    const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
-    const char* real_env = getenv("BODGE_AMD_REAL");
-    const bool real = sys->is_real && start_is_real && !(real_env && real_env[0] == '0');
-    const int per_lane = real ? RealMode::kVec : ComplexMode::kVec;
-    // Fewer than 4 lanes per row would put 32-64 rows' blocks into one wave's LDS
-    // region with no reuse; small batches run with zero-padded columns.
-    int rl = std::max(4, next_pow2((n_active + per_lane - 1) / per_lane));
-    if (sys->lanes_override * per_lane >= n_active && sys->lanes_override >= 4 &&
-        sys->lanes_override * per_lane <= 64)
-        rl = sys->lanes_override;
-    const int rv = rl * per_lane;  // vector columns in the buffers
-    StepPlan plan;
-    if (int rc = make_plan(sys, rl, real, &plan)) return rc;
-    if (real)
-        if (int rc = ensure_real_blocks(sys)) return rc;
-
-    const size_t vec_count = (size_t)4 * sys->nb * rl;  // 16-byte lane payloads
-    if (int rc = sys->vec_a.reserve(vec_count)) return rc;
-    if (int rc = sys->vec_b.reserve(vec_count)) return rc;
-    const size_t width = (size_t)2 * rv;
-    // keep the partial buffer below 256 MiB by reducing in chunks of steps
-    const size_t per_step = (size_t)plan.grid * width;
-    int chunk = (int)std::max<size_t>(1, std::min<size_t>(n_steps, (32u << 20) / per_step));
-    if (int rc = sys->partial.reserve((size_t)chunk * per_step)) return rc;
-    if (int rc = sys->dots.reserve((size_t)n_steps * width)) return rc;
-
-    hipStream_t st = sys->stream;
-    const int fill_grid = (int)std::min<size_t>(4096, (vec_count + 255) / 256);
-    if (start.kind == StartKind::Random) {
-        if (real)
-            bdg::fill_random_real<<<fill_grid, 256, 0, st>>>(reinterpret_cast<double*>(sys->vec_a.ptr),
-                                                             sys->nb, rv, n_active, start.seed,
-                                                             start.first_id);
-        else
-            bdg::fill_random<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, sys->nb, rv, n_active,
-                                                        start.seed, start.first_id, start.vec_kind);
-    } else {
-        if (int rc = sys->rows.reserve(64)) return rc;
-        HIP_TRY(hipMemcpyAsync(sys->rows.ptr, start.rows, sizeof(int64_t) * n_active,
-                               hipMemcpyHostToDevice, st));
-        bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, (int64_t)vec_count);
-        if (real)
-            bdg::set_unit_real<<<1, 64, 0, st>>>(reinterpret_cast<double*>(sys->vec_a.ptr), sys->nb, rv,
-                                                 n_active, sys->rows.ptr);
-        else
-            bdg::set_unit<<<1, 64, 0, st>>>(sys->vec_a.ptr, sys->nb, rv, n_active, sys->rows.ptr);
-    }
-    bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)vec_count);
-    HIP_TRY(hipGetLastError());
-
-    bdg::StepArgs args{};
-    args.indptr = sys->indptr.ptr;
-    args.indices = sys->indices.ptr;
-    args.blocks = real ? static_cast<const void*>(sys->blocks_real.ptr)
-                       : static_cast<const void*>(sys->blocks.ptr);
-    args.nb = (int)sys->nb;
-    args.n_tiles = plan.n_tiles;
-    args.max_row_blocks = sys->max_row_blocks;
-    int strip_rows = 0;
-    // bytes of t_n per block row that neighbouring rows re-read: 4 entries per vector
-    if (int rc = prepare_tile_order(sys, plan.rows_per_tile, plan.n_tiles, (real ? 32.0 : 64.0) * rv,
-                                    &args.tile_order, &strip_rows))
-        return rc;
-
-    double2* cur = sys->vec_a.ptr;
-    double2* prev = sys->vec_b.ptr;
-    float total_ms = 0.f;
-    for (int s0 = 0; s0 < n_steps; s0 += chunk) {
-        const int s1 = std::min(n_steps, s0 + chunk);
-        HIP_TRY(hipEventRecord(sys->ev_start, st));
-        for (int n = s0; n < s1; ++n) {
-            args.cur = cur;
-            args.prev = prev;
-            args.coef = (n == 0 ? 1.0 : 2.0) / scale;
-            args.partial = sys->partial.ptr + (size_t)(n - s0) * per_step;
-            plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
-            std::swap(cur, prev);
-        }
-        HIP_TRY(hipEventRecord(sys->ev_stop, st));
-        bdg::reduce_partials<<<s1 - s0, (unsigned)std::max<size_t>(64, width), 0, st>>>(
-            sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, plan.grid, (int)width);
-        HIP_TRY(hipGetLastError());
-        HIP_TRY(hipEventSynchronize(sys->ev_stop));
-        float ms = 0.f;
-        HIP_TRY(hipEventElapsedTime(&ms, sys->ev_start, sys->ev_stop));
-        total_ms += ms;
-    }
-    std::vector<double> host((size_t)n_steps * width);
-    HIP_TRY(hipMemcpyAsync(host.data(), sys->dots.ptr, host.size() * sizeof(double),
-                           hipMemcpyDeviceToHost, st));
-    HIP_TRY(hipStreamSynchronize(st));
-    for (int n = 0; n < n_steps; ++n)
-        for (int r = 0; r < n_active; ++r) {
-            d_out[(size_t)n * ld + col0 + r] = host[(size_t)n * width + 2 * r];
-            e_out[(size_t)n * ld + col0 + r] = host[(size_t)n * width + 2 * r + 1];
-        }
-
-    bdg_perf& p = sys->perf;
-    if (first_batch) p = bdg_perf{};
-    p.kernel_ms += total_ms;
-    p.launches += n_steps;
-    p.vector_steps += (int64_t)n_steps * n_active;
-    p.bytes_per_launch = algorithmic_bytes(sys, rv, real);
-    p.lanes_per_row = rl;
-    p.vectors_per_launch = rv;
-    p.real_arithmetic = real ? 1 : 0;
-    p.strip_rows = strip_rows;
-    p.grid = plan.grid;
-    p.lds_bytes = (int32_t)plan.lds_footprint;
-    p.pipelined = plan.pipelined ? 1 : 0;
-    return BDG_OK;
-}
-
-int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, StartSpec start,
-                   double* d_out, double* e_out) {
-    if (!sys) return fail(BDG_EINVAL, "null system handle");
-    if (!(scale > 0.0)) return fail(BDG_EINVAL, "scale must be positive");
-    if (n_steps < 1 || n_vectors < 1) return fail(BDG_EINVAL, "n_steps and n_vectors must be >= 1");
-    if (!d_out || !e_out) return fail(BDG_EINVAL, "null output buffer");
-    HIP_TRY(hipSetDevice(sys->device));
-    for (int col = 0; col < n_vectors; col += 64) {
-        const int n_active = std::min(64, n_vectors - col);
-        StartSpec batch = start;
-        if (start.kind == StartKind::Random) batch.first_id = start.first_id + col;
-        else batch.rows = start.rows + col;
-        if (int rc = run_batch(sys, scale, n_steps, n_active, batch, d_out, e_out, n_vectors, col,
-                               col == 0))
-            return rc;
-    }
-    return BDG_OK;
-}
-
 void dots_to_moments(const double* d, const double* e, int n_steps, int n_vectors, double* mu) {
     // mu[m][r]; mu_2n = 2 d_n - mu_0, mu_2n+1 = 2 e_n - mu_1
     for (int n = 0; n < n_steps; ++n)
@@ -493,6 +376,10 @@ struct RcclApi {
     decltype(&ncclAllReduce) all_reduce = nullptr;
     decltype(&ncclCommDestroy) comm_destroy = nullptr;
     decltype(&ncclGetErrorString) error_string = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
 };
 
 int load_rccl(RcclApi** out) {
@@ -513,8 +400,12 @@ int load_rccl(RcclApi** out) {
                 reinterpret_cast<decltype(api.comm_destroy)>(dlsym(api.lib, "ncclCommDestroy"));
             api.error_string =
                 reinterpret_cast<decltype(api.error_string)>(dlsym(api.lib, "ncclGetErrorString"));
+            api.send = reinterpret_cast<decltype(api.send)>(dlsym(api.lib, "ncclSend"));
+            api.recv = reinterpret_cast<decltype(api.recv)>(dlsym(api.lib, "ncclRecv"));
+            api.group_start = reinterpret_cast<decltype(api.group_start)>(dlsym(api.lib, "ncclGroupStart"));
+            api.group_end = reinterpret_cast<decltype(api.group_end)>(dlsym(api.lib, "ncclGroupEnd"));
             ok = api.get_unique_id && api.comm_init_rank && api.all_reduce && api.comm_destroy &&
-                 api.error_string;
+                 api.error_string && api.send && api.recv && api.group_start && api.group_end;
         }
     }
     if (!ok) return fail(BDG_ELIBRARY, "RCCL could not be loaded: %s", dlerror());
@@ -545,6 +436,316 @@ int comm_allreduce(bdg_comm* comm, double* buf, int64_t count, ncclRedOp_t op) {
     return BDG_OK;
 }
 
+
+// ------------------------------------------------------------------ recurrence
+// One batch = up to 64 start vectors advanced together on one handle.  The three
+// phases are separate so that a group of slabs can be driven in lock step:
+//   begin()  choose kernel + mode, allocate, write t_0 (own rows) and zero t_{-1}
+//   step(n)  one launch of K1 (after the caller has refreshed the halo of t_n)
+//   finish() reduce partials (done per chunk inside step), copy dots to the host
+struct Batch {
+    bdg_system* sys = nullptr;
+    StepPlan plan;
+    bdg::StepArgs args{};
+    bool real = false;
+    int rl = 0, rv = 0, n_active = 0, n_steps = 0, chunk = 1, strip_rows = 0;
+    size_t width = 0, per_step = 0, vec_count = 0;
+    double scale = 1.0;
+    double2* cur = nullptr;
+    double2* prev = nullptr;
+    float kernel_ms = 0.f;
+    bool timing_open = false;
+
+    int begin(bdg_system* system, double scale_in, int steps, int active, const StartSpec& start,
+              int force_real /* -1 auto, 0 complex, 1 real */) {
+        sys = system;
+        scale = scale_in;
+        n_steps = steps;
+        n_active = active;
+        HIP_TRY(hipSetDevice(sys->device));
+        // Real arithmetic applies when H has no imaginary part and the start vectors are real
+        // (±1 or unit vectors): every t_n then stays real.  BODGE_AMD_REAL=0 forces complex.
+        const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
+        const char* real_env = getenv("BODGE_AMD_REAL");
+        real = sys->is_real && start_is_real && !(real_env && real_env[0] == '0');
+        if (force_real >= 0) real = force_real != 0;
+        const int per_lane = real ? RealMode::kVec : ComplexMode::kVec;
+        // Fewer than 4 lanes per row would put 32-64 rows' blocks into one wave's LDS
+        // region with no reuse; small batches run with zero-padded columns.
+        rl = std::max(4, next_pow2((n_active + per_lane - 1) / per_lane));
+        if (sys->lanes_override * per_lane >= n_active && sys->lanes_override >= 4 &&
+            sys->lanes_override * per_lane <= 64)
+            rl = sys->lanes_override;
+        rv = rl * per_lane;  // vector columns in the buffers
+        if (int rc = make_plan(sys, rl, real, &plan)) return rc;
+        if (real)
+            if (int rc = ensure_real_blocks(sys)) return rc;
+
+        vec_count = (size_t)4 * sys->ncols * rl;  // 16-byte lane payloads
+        if (int rc = sys->vec_a.reserve(vec_count)) return rc;
+        if (int rc = sys->vec_b.reserve(vec_count)) return rc;
+        width = (size_t)2 * rv;
+        // keep the partial buffer below 256 MiB by reducing in chunks of steps
+        per_step = (size_t)plan.grid * width;
+        chunk = (int)std::max<size_t>(1, std::min<size_t>(n_steps, (32u << 20) / per_step));
+        if (int rc = sys->partial.reserve((size_t)chunk * per_step)) return rc;
+        if (int rc = sys->dots.reserve((size_t)n_steps * width)) return rc;
+        if (sys->send_total > 0)
+            if (int rc = sys->send_buf.reserve((size_t)sys->send_total * 4 * rl)) return rc;
+        if (sys->recv_total > 0)
+            if (int rc = sys->recv_buf.reserve((size_t)sys->recv_total * 4 * rl)) return rc;
+
+        hipStream_t st = sys->stream;
+        const int fill_grid = (int)std::min<size_t>(4096, (vec_count + 255) / 256);
+        if (start.kind == StartKind::Random) {
+            if (real)
+                bdg::fill_random_real<<<fill_grid, 256, 0, st>>>(
+                    reinterpret_cast<double*>(sys->vec_a.ptr), sys->nb, sys->ncols, rv, n_active,
+                    start.seed, start.first_id, sys->row_offset);
+            else
+                bdg::fill_random<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, sys->nb, sys->ncols, rv,
+                                                            n_active, start.seed, start.first_id,
+                                                            start.vec_kind, sys->row_offset);
+        } else {
+            if (int rc = sys->rows.reserve(64)) return rc;
+            HIP_TRY(hipMemcpyAsync(sys->rows.ptr, start.rows, sizeof(int64_t) * n_active,
+                                   hipMemcpyHostToDevice, st));
+            bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, (int64_t)vec_count);
+            if (real)
+                bdg::set_unit_real<<<1, 64, 0, st>>>(reinterpret_cast<double*>(sys->vec_a.ptr), sys->nb,
+                                                     sys->ncols, rv, n_active, sys->rows.ptr,
+                                                     sys->row_offset);
+            else
+                bdg::set_unit<<<1, 64, 0, st>>>(sys->vec_a.ptr, sys->nb, sys->ncols, rv, n_active,
+                                                sys->rows.ptr, sys->row_offset);
+        }
+        bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)vec_count);
+        HIP_TRY(hipGetLastError());
+
+        args = bdg::StepArgs{};
+        args.indptr = sys->indptr.ptr;
+        args.indices = sys->indices.ptr;
+        args.blocks = real ? static_cast<const void*>(sys->blocks_real.ptr)
+                           : static_cast<const void*>(sys->blocks.ptr);
+        args.nb = (int)sys->nb;
+        args.ncols = (int)sys->ncols;
+        args.n_tiles = plan.n_tiles;
+        args.max_row_blocks = sys->max_row_blocks;
+        // bytes of t_n per block row that neighbouring rows re-read: 4 entries per vector
+        if (int rc = prepare_tile_order(sys, plan.rows_per_tile, plan.n_tiles,
+                                        (real ? 32.0 : 64.0) * rv, &args.tile_order, &strip_rows))
+            return rc;
+        cur = sys->vec_a.ptr;
+        prev = sys->vec_b.ptr;
+        kernel_ms = 0.f;
+        timing_open = false;
+        return BDG_OK;
+    }
+
+    // Halo exchange, split so that a same-process group can interleave its members.
+    int pack() {
+        if (sys->send_total == 0) return BDG_OK;
+        HIP_TRY(hipSetDevice(sys->device));
+        const int64_t total = sys->send_total * 4 * rl;
+        bdg::halo_pack<<<(unsigned)std::min<int64_t>(2048, (total + 255) / 256), 256, 0, sys->stream>>>(
+            cur, sys->send_rows.ptr, sys->send_total, sys->ncols, rl, sys->send_buf.ptr);
+        HIP_TRY(hipGetLastError());
+        return BDG_OK;
+    }
+    int unpack() {
+        HIP_TRY(hipSetDevice(sys->device));
+        for (const ExchangePeer& peer : sys->peers) {
+            if (peer.recv_count == 0) continue;
+            const int64_t total = peer.recv_count * 4 * rl;
+            bdg::halo_unpack<<<(unsigned)std::min<int64_t>(2048, (total + 255) / 256), 256, 0,
+                               sys->stream>>>(cur, peer.recv_col, peer.recv_count, sys->ncols, rl,
+                                              sys->recv_buf.ptr + (size_t)peer.recv_begin * 4 * rl);
+        }
+        HIP_TRY(hipGetLastError());
+        return BDG_OK;
+    }
+    // RCCL transport: grouped send/recv of the packed rows on the compute stream.
+    int exchange_rccl() {
+        if (sys->peers.empty()) return BDG_OK;
+        bdg_comm* comm = sys->slab_comm;
+        if (!comm) return fail(BDG_EINVAL, "slab handle has exchange peers but no communicator");
+        RcclApi* api = nullptr;
+        if (int rc = load_rccl(&api)) return rc;
+        if (int rc = pack()) return rc;
+        NCCL_TRY(api, api->group_start());
+        for (const ExchangePeer& peer : sys->peers) {
+            const size_t unit = (size_t)4 * rl * 2;  // doubles per exchanged block row
+            if (peer.send_count > 0)
+                NCCL_TRY(api, api->send(sys->send_buf.ptr + (size_t)peer.send_begin * 4 * rl,
+                                        (size_t)peer.send_count * unit, ncclDouble, peer.rank, comm->comm,
+                                        sys->stream));
+            if (peer.recv_count > 0)
+                NCCL_TRY(api, api->recv(sys->recv_buf.ptr + (size_t)peer.recv_begin * 4 * rl,
+                                        (size_t)peer.recv_count * unit, ncclDouble, peer.rank, comm->comm,
+                                        sys->stream));
+        }
+        NCCL_TRY(api, api->group_end());
+        return unpack();
+    }
+
+    int step(int n) {
+        HIP_TRY(hipSetDevice(sys->device));
+        hipStream_t st = sys->stream;
+        const int in_chunk = n % chunk;
+        if (in_chunk == 0) {
+            HIP_TRY(hipEventRecord(sys->ev_start, st));
+            timing_open = true;
+        }
+        args.cur = cur;
+        args.prev = prev;
+        args.coef = (n == 0 ? 1.0 : 2.0) / scale;
+        args.partial = sys->partial.ptr + (size_t)in_chunk * per_step;
+        plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
+        std::swap(cur, prev);
+        if (in_chunk == chunk - 1 || n == n_steps - 1) {
+            const int s0 = n - in_chunk;
+            HIP_TRY(hipEventRecord(sys->ev_stop, st));
+            bdg::reduce_partials<<<in_chunk + 1, (unsigned)std::max<size_t>(64, width), 0, st>>>(
+                sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, plan.grid, (int)width);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipEventSynchronize(sys->ev_stop));
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, sys->ev_start, sys->ev_stop));
+            kernel_ms += ms;
+            timing_open = false;
+        }
+        return BDG_OK;
+    }
+
+    // d/e of this handle's rows into columns [col0, col0 + n_active) of (n_steps x ld) arrays;
+    // accumulate = true adds to what is there (summing the slabs of a group).
+    int finish(double* d_out, double* e_out, int ld, int col0, bool accumulate, bool first_batch) {
+        HIP_TRY(hipSetDevice(sys->device));
+        std::vector<double> host((size_t)n_steps * width);
+        HIP_TRY(hipMemcpyAsync(host.data(), sys->dots.ptr, host.size() * sizeof(double),
+                               hipMemcpyDeviceToHost, sys->stream));
+        HIP_TRY(hipStreamSynchronize(sys->stream));
+        for (int n = 0; n < n_steps; ++n)
+            for (int r = 0; r < n_active; ++r) {
+                double& d = d_out[(size_t)n * ld + col0 + r];
+                double& e = e_out[(size_t)n * ld + col0 + r];
+                const double dv = host[(size_t)n * width + 2 * r], ev = host[(size_t)n * width + 2 * r + 1];
+                d = accumulate ? d + dv : dv;
+                e = accumulate ? e + ev : ev;
+            }
+        bdg_perf& p = sys->perf;
+        if (first_batch) p = bdg_perf{};
+        p.kernel_ms += kernel_ms;
+        p.launches += n_steps;
+        p.vector_steps += (int64_t)n_steps * n_active;
+        p.bytes_per_launch = algorithmic_bytes(sys, rv, real);
+        p.lanes_per_row = rl;
+        p.vectors_per_launch = rv;
+        p.real_arithmetic = real ? 1 : 0;
+        p.strip_rows = strip_rows;
+        p.grid = plan.grid;
+        p.lds_bytes = (int32_t)plan.lds_footprint;
+        p.pipelined = plan.pipelined ? 1 : 0;
+        return BDG_OK;
+    }
+};
+
+int check_recurrence_args(const void* sys, double scale, int n_steps, int n_vectors, const double* d_out,
+                          const double* e_out) {
+    if (!sys) return fail(BDG_EINVAL, "null system handle");
+    if (!(scale > 0.0)) return fail(BDG_EINVAL, "scale must be positive");
+    if (n_steps < 1 || n_vectors < 1) return fail(BDG_EINVAL, "n_steps and n_vectors must be >= 1");
+    if (!d_out || !e_out) return fail(BDG_EINVAL, "null output buffer");
+    return BDG_OK;
+}
+
+StartSpec batch_start(const StartSpec& start, int col) {
+    StartSpec batch = start;
+    if (start.kind == StartKind::Random) batch.first_id = start.first_id + col;
+    else batch.rows = start.rows + col;
+    return batch;
+}
+
+// Single handle (whole matrix, or one slab of a multi-process run with RCCL halos).
+int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, StartSpec start,
+                   double* d_out, double* e_out) {
+    if (int rc = check_recurrence_args(sys, scale, n_steps, n_vectors, d_out, e_out)) return rc;
+    for (int col = 0; col < n_vectors; col += 64) {
+        Batch batch;
+        if (int rc = batch.begin(sys, scale, n_steps, std::min(64, n_vectors - col),
+                                 batch_start(start, col), -1))
+            return rc;
+        for (int n = 0; n < n_steps; ++n) {
+            if (int rc = batch.exchange_rccl()) return rc;
+            if (int rc = batch.step(n)) return rc;
+        }
+        if (int rc = batch.finish(d_out, e_out, n_vectors, col, false, col == 0)) return rc;
+    }
+    return BDG_OK;
+}
+
+// Same-process group of slabs (one handle per slab, on one or several devices of this
+// process): the halo rows travel by device-to-device copies ordered with events.
+//   stream m:  [wait until my previous send buffer was consumed] pack -> ev packed[m]
+//              for each peer p: wait packed[p]; copy p.send segment -> my recv segment
+//              -> ev copied[m]; unpack; K1
+int run_group(bdg_group* group, double scale, int n_steps, int n_vectors, StartSpec start,
+              double* d_out, double* e_out) {
+    if (int rc = check_recurrence_args(group, scale, n_steps, n_vectors, d_out, e_out)) return rc;
+    const size_t n_members = group->members.size();
+    bool all_real = true;
+    for (bdg_system* m : group->members) all_real = all_real && m->is_real;
+    const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
+    const char* real_env = getenv("BODGE_AMD_REAL");
+    const int force_real = (all_real && start_is_real && !(real_env && real_env[0] == '0')) ? 1 : 0;
+
+    for (int col = 0; col < n_vectors; col += 64) {
+        std::vector<Batch> batch(n_members);
+        for (size_t m = 0; m < n_members; ++m)
+            if (int rc = batch[m].begin(group->members[m], scale, n_steps, std::min(64, n_vectors - col),
+                                        batch_start(start, col), force_real))
+                return rc;
+        for (size_t m = 1; m < n_members; ++m)
+            if (batch[m].rl != batch[0].rl)
+                return fail(BDG_EINVAL, "group members chose different kernel configurations");
+        const size_t unit = (size_t)4 * batch[0].rl * sizeof(double2);  // bytes per exchanged block row
+        for (int n = 0; n < n_steps; ++n) {
+            for (size_t m = 0; m < n_members; ++m) {
+                bdg_system* sys = group->members[m];
+                HIP_TRY(hipSetDevice(sys->device));
+                if (n > 0)
+                    for (const ExchangePeer& peer : sys->peers)
+                        HIP_TRY(hipStreamWaitEvent(sys->stream, group->copied[peer.rank], 0));
+                if (int rc = batch[m].pack()) return rc;
+                HIP_TRY(hipEventRecord(group->packed[m], sys->stream));
+            }
+            for (size_t m = 0; m < n_members; ++m) {
+                bdg_system* sys = group->members[m];
+                HIP_TRY(hipSetDevice(sys->device));
+                for (const ExchangePeer& peer : sys->peers) {
+                    if (peer.recv_count == 0) continue;
+                    bdg_system* src = group->members[peer.rank];
+                    const ExchangePeer* back = nullptr;
+                    for (const ExchangePeer& q : src->peers)
+                        if (q.rank == (int)m) back = &q;
+                    HIP_TRY(hipStreamWaitEvent(sys->stream, group->packed[peer.rank], 0));
+                    HIP_TRY(hipMemcpyPeerAsync(
+                        reinterpret_cast<char*>(sys->recv_buf.ptr) + (size_t)peer.recv_begin * unit,
+                        sys->device,
+                        reinterpret_cast<const char*>(src->send_buf.ptr) + (size_t)back->send_begin * unit,
+                        src->device, (size_t)peer.recv_count * unit, sys->stream));
+                }
+                HIP_TRY(hipEventRecord(group->copied[m], sys->stream));
+                if (int rc = batch[m].unpack()) return rc;
+                if (int rc = batch[m].step(n)) return rc;
+            }
+        }
+        for (size_t m = 0; m < n_members; ++m)
+            if (int rc = batch[m].finish(d_out, e_out, n_vectors, col, m > 0, col == 0)) return rc;
+    }
+    return BDG_OK;
+}
+
 }  // namespace
 
 // =========================================================================== ABI
@@ -567,12 +768,17 @@ int bdg_device_count(int* count) {
 
 int bdg_create(int device, int64_t nb, int64_t nnzb, const int32_t* indptr, const int32_t* indices,
                const double* data, bdg_system** out) {
+    return bdg_create_slab(device, nb, nb, nnzb, indptr, indices, data, 0, out);
+}
+
+int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const int32_t* indptr,
+                    const int32_t* indices, const double* data, int64_t row_offset, bdg_system** out) {
     if (!out) return fail(BDG_EINVAL, "null output handle");
     *out = nullptr;
-    if (nb < 1 || nnzb < 0 || !indptr || (nnzb > 0 && (!indices || !data)))
-        return fail(BDG_EINVAL, "bad matrix arguments (nb=%lld nnzb=%lld)", (long long)nb,
-                    (long long)nnzb);
-    if (nb > (1ll << 29) || nnzb > (1ll << 30))
+    if (nb < 1 || ncols < nb || nnzb < 0 || row_offset < 0 || !indptr || (nnzb > 0 && (!indices || !data)))
+        return fail(BDG_EINVAL, "bad matrix arguments (nb=%lld ncols=%lld nnzb=%lld)", (long long)nb,
+                    (long long)ncols, (long long)nnzb);
+    if (ncols > (1ll << 29) || nnzb > (1ll << 30))
         return fail(BDG_EINVAL, "matrix too large for 32-bit block indexing");
     if (indptr[0] != 0 || indptr[nb] != nnzb) return fail(BDG_EINVAL, "indptr does not span the blocks");
     int max_row = 0;
@@ -583,11 +789,13 @@ int bdg_create(int device, int64_t nb, int64_t nnzb, const int32_t* indptr, cons
         const int len = indptr[i + 1] - indptr[i];
         max_row = std::max(max_row, len);
         for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
-            if (indices[k] < 0 || indices[k] >= nb)
+            if (indices[k] < 0 || indices[k] >= ncols)
                 return fail(BDG_EINVAL, "column index %d out of range in row %lld", indices[k],
                             (long long)i);
-            if (k > indptr[i] && indices[k] <= indices[k - 1])
-                return fail(BDG_EINVAL, "row %lld is not sorted / has duplicates", (long long)i);
+            if (k > indptr[i] && indices[k] == indices[k - 1])
+                return fail(BDG_EINVAL, "row %lld has a duplicate column", (long long)i);
+            if (ncols == nb && k > indptr[i] && indices[k] < indices[k - 1])
+                return fail(BDG_EINVAL, "row %lld is not sorted", (long long)i);
         }
     }
     bool is_real = true;
@@ -603,6 +811,8 @@ int bdg_create(int device, int64_t nb, int64_t nnzb, const int32_t* indptr, cons
     bdg_system* sys = new bdg_system();
     sys->device = device;
     sys->nb = nb;
+    sys->ncols = ncols;
+    sys->row_offset = row_offset;
     sys->nnzb = nnzb;
     sys->max_row_blocks = std::max(1, max_row);
     sys->is_real = is_real;
@@ -630,6 +840,107 @@ int bdg_create(int device, int64_t nb, int64_t nnzb, const int32_t* indptr, cons
     return BDG_OK;
 }
 
+int bdg_slab_set_exchange(bdg_system* sys, bdg_comm* comm, int32_t n_peers, const int32_t* peer_rank,
+                          const int64_t* send_count, const int64_t* send_rows, const int64_t* recv_col,
+                          const int64_t* recv_count) {
+    if (!sys) return fail(BDG_EINVAL, "null system handle");
+    if (n_peers < 0 || (n_peers > 0 && (!peer_rank || !send_count || !recv_col || !recv_count)))
+        return fail(BDG_EINVAL, "bad exchange arguments");
+    std::vector<ExchangePeer> peers((size_t)n_peers);
+    int64_t send_total = 0, recv_total = 0;
+    for (int p = 0; p < n_peers; ++p) {
+        ExchangePeer& e = peers[p];
+        e.rank = peer_rank[p];
+        e.send_begin = send_total;
+        e.send_count = send_count[p];
+        e.recv_col = recv_col[p];
+        e.recv_begin = recv_total;
+        e.recv_count = recv_count[p];
+        if (e.rank < 0 || e.send_count < 0 || e.recv_count < 0)
+            return fail(BDG_EINVAL, "negative count or rank for peer %d", p);
+        if (e.recv_count > 0 && (e.recv_col < sys->nb || e.recv_col + e.recv_count > sys->ncols))
+            return fail(BDG_EINVAL, "receive range of peer %d is outside the halo columns", p);
+        send_total += e.send_count;
+        recv_total += e.recv_count;
+    }
+    if (send_total > 0 && !send_rows) return fail(BDG_EINVAL, "null send_rows");
+    for (int64_t k = 0; k < send_total; ++k)
+        if (send_rows[k] < 0 || send_rows[k] >= sys->nb)
+            return fail(BDG_EINVAL, "send row %lld is not an owned row", (long long)send_rows[k]);
+    HIP_TRY(hipSetDevice(sys->device));
+    if (send_total > 0) {
+        if (int rc = sys->send_rows.reserve((size_t)send_total)) return rc;
+        HIP_TRY(hipMemcpy(sys->send_rows.ptr, send_rows, sizeof(int64_t) * send_total, hipMemcpyHostToDevice));
+    }
+    sys->peers = std::move(peers);
+    sys->send_total = send_total;
+    sys->recv_total = recv_total;
+    sys->slab_comm = comm;
+    return BDG_OK;
+}
+
+int bdg_group_create(bdg_system** members, int32_t n_members, bdg_group** out) {
+    if (!members || n_members < 1 || !out) return fail(BDG_EINVAL, "bad group arguments");
+    *out = nullptr;
+    for (int m = 0; m < n_members; ++m) {
+        if (!members[m]) return fail(BDG_EINVAL, "null group member %d", m);
+        for (const ExchangePeer& peer : members[m]->peers) {
+            if (peer.rank >= n_members) return fail(BDG_EINVAL, "member %d names peer %d outside the group", m, peer.rank);
+            const ExchangePeer* back = nullptr;
+            for (const ExchangePeer& q : members[peer.rank]->peers)
+                if (q.rank == m) back = &q;
+            if (!back || back->send_count != peer.recv_count || back->recv_count != peer.send_count)
+                return fail(BDG_EINVAL, "exchange lists of members %d and %d do not match", m, peer.rank);
+        }
+    }
+    bdg_group* group = new bdg_group();
+    group->members.assign(members, members + n_members);
+    group->packed.resize(n_members);
+    group->copied.resize(n_members);
+    for (int m = 0; m < n_members; ++m) {
+        (void)hipSetDevice(members[m]->device);
+        if (hipEventCreateWithFlags(&group->packed[m], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&group->copied[m], hipEventDisableTiming) != hipSuccess) {
+            delete group;
+            return fail(BDG_EDEVICE, "event creation failed");
+        }
+    }
+    *out = group;
+    return BDG_OK;
+}
+
+int bdg_group_destroy(bdg_group* group) {
+    if (!group) return BDG_OK;
+    for (size_t m = 0; m < group->members.size(); ++m) {
+        (void)hipSetDevice(group->members[m]->device);
+        (void)hipStreamSynchronize(group->members[m]->stream);
+        if (group->packed[m]) (void)hipEventDestroy(group->packed[m]);
+        if (group->copied[m]) (void)hipEventDestroy(group->copied[m]);
+    }
+    delete group;
+    return BDG_OK;
+}
+
+int bdg_group_dots_random(bdg_group* group, double scale, int32_t n_steps, int32_t n_vectors,
+                          uint64_t seed, uint64_t first_vec_id, int32_t vec_kind, double* d_out,
+                          double* e_out) {
+    if (vec_kind != BDG_VEC_RADEMACHER && vec_kind != BDG_VEC_Z4)
+        return fail(BDG_EINVAL, "unknown start-vector kind %d", vec_kind);
+    StartSpec start{StartKind::Random};
+    start.seed = seed;
+    start.first_id = first_vec_id;
+    start.vec_kind = vec_kind;
+    return run_group(group, scale, n_steps, n_vectors, start, d_out, e_out);
+}
+
+int bdg_group_dots_unit(bdg_group* group, double scale, int32_t n_steps, int32_t n_vectors,
+                        const int64_t* rows, double* d_out, double* e_out) {
+    if (!rows) return fail(BDG_EINVAL, "null rows pointer");
+    StartSpec start{StartKind::Unit};
+    start.rows = rows;
+    return run_group(group, scale, n_steps, n_vectors, start, d_out, e_out);
+}
+
 int bdg_destroy(bdg_system* sys) {
     if (!sys) return BDG_OK;
     (void)hipSetDevice(sys->device);
@@ -644,6 +955,9 @@ int bdg_destroy(bdg_system* sys) {
     sys->dots.release();
     sys->rows.release();
     sys->tile_order.release();
+    sys->send_rows.release();
+    sys->send_buf.release();
+    sys->recv_buf.release();
     if (sys->ev_start) (void)hipEventDestroy(sys->ev_start);
     if (sys->ev_stop) (void)hipEventDestroy(sys->ev_stop);
     if (sys->stream) (void)hipStreamDestroy(sys->stream);
@@ -673,6 +987,7 @@ int bdg_set_lanes_per_row(bdg_system* sys, int32_t lanes) {
 
 int bdg_spmv(bdg_system* sys, const double* x, double* y) {
     if (!sys || !x || !y) return fail(BDG_EINVAL, "null argument");
+    if (sys->ncols != sys->nb) return fail(BDG_EINVAL, "bdg_spmv needs a whole (square) matrix, not a slab");
     HIP_TRY(hipSetDevice(sys->device));
     constexpr int kCols = 4;  // narrowest kernel configuration; columns 1..3 stay zero
     StepPlan plan;
@@ -699,6 +1014,7 @@ int bdg_spmv(bdg_system* sys, const double* x, double* y) {
         args.partial = sys->partial.ptr;
         args.coef = 1.0;
         args.nb = (int)sys->nb;
+        args.ncols = (int)sys->nb;
         args.n_tiles = plan.n_tiles;
         args.max_row_blocks = sys->max_row_blocks;
         plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
@@ -730,7 +1046,7 @@ int bdg_cheb_dots_unit(bdg_system* sys, double scale, int32_t n_steps, int32_t n
     if (!sys) return fail(BDG_EINVAL, "null system handle");
     if (!rows) return fail(BDG_EINVAL, "null rows pointer");
     for (int r = 0; r < n_vectors; ++r)
-        if (rows[r] < 0 || rows[r] >= 4 * sys->nb)
+        if (rows[r] < 0 || (sys->ncols == sys->nb && rows[r] >= 4 * sys->nb))
             return fail(BDG_EINVAL, "start row %lld out of range", (long long)rows[r]);
     StartSpec start{StartKind::Unit};
     start.rows = rows;
@@ -780,8 +1096,8 @@ int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t v
     if (int rc = host_order.reserve(n)) return rc;
     const int grid = (int)std::min<size_t>(4096, (n + 255) / 256);
     auto body = [&]() -> int {
-        bdg::fill_random<<<grid, 256, 0, sys->stream>>>(sys->vec_a.ptr, sys->nb, 1, 1, seed, vec_id,
-                                                        vec_kind);
+        bdg::fill_random<<<grid, 256, 0, sys->stream>>>(sys->vec_a.ptr, sys->nb, sys->nb, 1, 1, seed,
+                                                        vec_id, vec_kind, sys->row_offset);
         bdg::sitemajor_from_planar<<<grid, 256, 0, sys->stream>>>(sys->vec_a.ptr, host_order.ptr,
                                                                   sys->nb, 1, 0);
         HIP_TRY(hipGetLastError());
@@ -797,6 +1113,7 @@ int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t v
 
 int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     if (!sys || !w_out) return fail(BDG_EINVAL, "null argument");
+    if (sys->ncols != sys->nb) return fail(BDG_EINVAL, "bdg_eigh_dense needs a whole (square) matrix, not a slab");
     HIP_TRY(hipSetDevice(sys->device));
     SolverApi* api = nullptr;
     if (int rc = load_solver(&api)) return rc;

@@ -14,6 +14,7 @@
 //                     192 B per (site, vector); no MFMA (0.5-2 flop/B).
 // K2  reduce_partials fixed-order sum of the per-workgroup dot partials (bit reproducible).
 // K3  fill_random / fill_unit / zero   start vectors from a counter-based generator.
+// K4  halo_pack / halo_unpack   t_n rows exchanged between row slabs (multi-GPU slab mode).
 // K5  scatter_dense   BSR -> dense column-major for the rocSOLVER path.
 #pragma once
 
@@ -84,44 +85,40 @@ __host__ __device__ inline double2 start_entry(uint64_t key, uint64_t element, i
     }
 }
 
-// vec[α][site][r] = entry(seed, first_id + r, 4*site + α) for r < n_active, else 0.
-__global__ void fill_random(double2* __restrict__ vec, int64_t nb, int rv, int n_active,
-                            uint64_t seed, uint64_t first_id, int kind) {
-    const int64_t total = 4 * nb * rv;
+// Vector buffers hold `ncols` block rows: the first `nb` are the rows this handle owns
+// (global block row = row_offset + local row), the rest is halo filled by the exchange.
+// vec[α][site][r] = entry(seed, first_id + r, 4*(row_offset + site) + α) for site < nb,
+// r < n_active; everything else 0.
+__global__ void fill_random(double2* __restrict__ vec, int64_t nb, int64_t ncols, int rv, int n_active,
+                            uint64_t seed, uint64_t first_id, int kind, int64_t row_offset) {
+    const int64_t total = 4 * ncols * rv;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(idx % rv);
         int alpha;
         int64_t site;
-        vpair(idx / rv, nb, alpha, site);
+        vpair(idx / rv, ncols, alpha, site);
         double2 v = make_double2(0.0, 0.0);
-        if (r < n_active) v = start_entry(vector_key(seed, first_id + r), 4 * site + alpha, kind);
+        if (r < n_active && site < nb)
+            v = start_entry(vector_key(seed, first_id + r), 4 * (row_offset + site) + alpha, kind);
         vec[idx] = v;
     }
 }
 
 // RealMode layout: double[α][site][rv]; only the Rademacher kind is real.
-__global__ void fill_random_real(double* __restrict__ vec, int64_t nb, int rv, int n_active,
-                                 uint64_t seed, uint64_t first_id) {
-    const int64_t total = 4 * nb * rv;
+__global__ void fill_random_real(double* __restrict__ vec, int64_t nb, int64_t ncols, int rv,
+                                 int n_active, uint64_t seed, uint64_t first_id, int64_t row_offset) {
+    const int64_t total = 4 * ncols * rv;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const int r = (int)(idx % rv);
         int alpha;
         int64_t site;
-        vpair(idx / rv, nb, alpha, site);
+        vpair(idx / rv, ncols, alpha, site);
         double v = 0.0;
-        if (r < n_active) v = start_entry(vector_key(seed, first_id + r), 4 * site + alpha, 0).x;
+        if (r < n_active && site < nb)
+            v = start_entry(vector_key(seed, first_id + r), 4 * (row_offset + site) + alpha, 0).x;
         vec[idx] = v;
-    }
-}
-
-__global__ void set_unit_real(double* __restrict__ vec, int64_t nb, int rv, int n_active,
-                              const int64_t* __restrict__ rows) {
-    const int r = blockIdx.x * blockDim.x + threadIdx.x;
-    if (r < n_active) {
-        const int64_t row = rows[r];
-        vec[vslot((int)(row & 3), (size_t)(row >> 2), r, (size_t)nb, rv)] = 1.0;
     }
 }
 
@@ -131,13 +128,51 @@ __global__ void fill_zero(double2* __restrict__ vec, int64_t count) {
         vec[idx] = make_double2(0.0, 0.0);
 }
 
-// vec = 0 everywhere except vec[row%4][row/4][r] = 1 for r < n_active.
-__global__ void set_unit(double2* __restrict__ vec, int64_t nb, int rv, int n_active,
-                         const int64_t* __restrict__ rows) {
+// vec = 0 everywhere except the unit entry of GLOBAL scalar row rows[r] in column r; a
+// handle sets it only if it owns that row.
+__global__ void set_unit(double2* __restrict__ vec, int64_t nb, int64_t ncols, int rv, int n_active,
+                         const int64_t* __restrict__ rows, int64_t row_offset) {
     const int r = blockIdx.x * blockDim.x + threadIdx.x;
     if (r < n_active) {
-        const int64_t row = rows[r];
-        vec[vslot((int)(row & 3), (size_t)(row >> 2), r, (size_t)nb, rv)] = make_double2(1.0, 0.0);
+        const int64_t site = (rows[r] >> 2) - row_offset;
+        if (site >= 0 && site < nb)
+            vec[vslot((int)(rows[r] & 3), (size_t)site, r, (size_t)ncols, rv)] = make_double2(1.0, 0.0);
+    }
+}
+
+__global__ void set_unit_real(double* __restrict__ vec, int64_t nb, int64_t ncols, int rv, int n_active,
+                              const int64_t* __restrict__ rows, int64_t row_offset) {
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r < n_active) {
+        const int64_t site = (rows[r] >> 2) - row_offset;
+        if (site >= 0 && site < nb) vec[vslot((int)(rows[r] & 3), (size_t)site, r, (size_t)ncols, rv)] = 1.0;
+    }
+}
+
+// ------------------------------------------------------------------------ K4
+// Halo exchange of t_n between row slabs.  Lane payloads are 16 B in both arithmetic
+// modes, so one pair of kernels serves both.  Message layout: buf[k][α][r].
+__global__ void halo_pack(const double2* __restrict__ vec, const int64_t* __restrict__ send_rows,
+                          int64_t n_send, int64_t ncols, int rl, double2* __restrict__ buf) {
+    const int64_t total = n_send * 4 * rl;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx % rl);
+        const int alpha = (int)((idx / rl) & 3);
+        const int64_t k = idx / (4 * rl);
+        buf[idx] = vec[vslot(alpha, (size_t)send_rows[k], r, (size_t)ncols, rl)];
+    }
+}
+
+__global__ void halo_unpack(double2* __restrict__ vec, int64_t first_col, int64_t n_recv, int64_t ncols,
+                            int rl, const double2* __restrict__ buf) {
+    const int64_t total = n_recv * 4 * rl;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int r = (int)(idx % rl);
+        const int alpha = (int)((idx / rl) & 3);
+        const int64_t k = idx / (4 * rl);
+        vec[vslot(alpha, (size_t)(first_col + k), r, (size_t)ncols, rl)] = buf[idx];
     }
 }
 
@@ -151,7 +186,8 @@ struct StepArgs {
     double* partial;      // [gridDim.x][RL * kVec][2]
     const int* tile_order;  // optional permutation of workgroup tiles (nullptr = natural order)
     double coef;
-    int nb;
+    int nb;       // block rows owned (computed)
+    int ncols;    // block rows of the vector buffers (owned + halo); == nb without slabs
     int n_tiles;  // workgroup tiles of 4 * (64/RL) block rows
     int max_row_blocks;
 };
@@ -303,7 +339,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
             if (kbeg < kend) {
                 const size_t j = (size_t)a.indices[kbeg];
 #pragma unroll
-                for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, j, r, a.nb, RL)];
+                for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, j, r, a.ncols, RL)];
             }
             for (int k = kbeg; k < kend; ++k) {
 #pragma unroll
@@ -311,14 +347,14 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
                 if (k + 1 < kend) {
                     const size_t j = (size_t)a.indices[k + 1];
 #pragma unroll
-                    for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, j, r, a.nb, RL)];
+                    for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, j, r, a.ncols, RL)];
                 }
                 Mode::mac_row(acc, stage + (k - kb0) * STRIDE, x);
             }
 
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
-                const size_t own = vslot(al, (size_t)i, r, a.nb, RL);
+                const size_t own = vslot(al, (size_t)i, r, a.ncols, RL);
                 const double2 p = a.prev[own];
                 const double2 c = a.cur[own];
                 double2 nx;
@@ -459,7 +495,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
             const int len = meta.kend - meta.kbeg;
             if (len > 0) {
 #pragma unroll
-                for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, (size_t)meta.col[0], r, a.nb, RL)];
+                for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, (size_t)meta.col[0], r, a.ncols, RL)];
             }
             const double2* blk = stage + (meta.kbeg - kb0) * STRIDE;
 #pragma unroll
@@ -470,14 +506,14 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
                     if (q + 1 < MAXB && q + 1 < len) {
 #pragma unroll
                         for (int be = 0; be < 4; ++be)
-                            xn[be] = a.cur[vslot(be, (size_t)meta.col[q + 1 < MAXB ? q + 1 : 0], r, a.nb, RL)];
+                            xn[be] = a.cur[vslot(be, (size_t)meta.col[q + 1 < MAXB ? q + 1 : 0], r, a.ncols, RL)];
                     }
                     Mode::mac_row(acc, blk + q * STRIDE, x);
                 }
             }
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
-                const size_t own = vslot(al, (size_t)i, r, a.nb, RL);
+                const size_t own = vslot(al, (size_t)i, r, a.ncols, RL);
                 const double2 p = a.prev[own];
                 const double2 c = a.cur[own];
                 double2 nx;

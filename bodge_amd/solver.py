@@ -17,17 +17,24 @@ from . import backend
 from .backend import VEC_RADEMACHER, VEC_Z4  # noqa: F401  (re-exported)
 
 
+def _default_device() -> int:
+    device = int(os.environ.get("BODGE_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
+    return device % backend.device_count()
+
+
 class DeviceSolver:
-    def __init__(self, indptr, indices, data, device: int | None = None):
+    def __init__(self, indptr, indices, data, device: int | None = None, n_cols: int | None = None,
+                 row_offset: int = 0):
+        """Upload a BSR matrix.  `n_cols` / `row_offset` describe a row slab (see `from_slab_plan`)."""
         lib = backend.load()
         backend.require_device()
         if device is None:
-            device = int(os.environ.get("BODGE_AMD_DEVICE", os.environ.get("LOCAL_RANK", "0")))
-            device %= backend.device_count()
+            device = _default_device()
         indptr = np.ascontiguousarray(indptr, dtype=np.int32)
         indices = np.ascontiguousarray(indices, dtype=np.int32)
         data = np.ascontiguousarray(data, dtype=np.complex128)
         self.n_sites = int(indptr.size - 1)
+        self.n_cols = self.n_sites if n_cols is None else int(n_cols)
         self.n_blocks = int(indices.size)
         self.dim = 4 * self.n_sites
         self.device = device
@@ -35,12 +42,36 @@ class DeviceSolver:
             raise ValueError("block data does not match the index arrays")
         self._lib = lib
         self._handle = C.c_void_p()
+        self._keepalive = None
         backend.check(
-            lib.bdg_create(
-                device, self.n_sites, self.n_blocks, backend.as_i32p(indptr), backend.as_i32p(indices),
-                backend.as_f64p(data.view(np.float64)), C.byref(self._handle),
+            lib.bdg_create_slab(
+                device, self.n_sites, self.n_cols, self.n_blocks, backend.as_i32p(indptr),
+                backend.as_i32p(indices), backend.as_f64p(data.view(np.float64)), int(row_offset),
+                C.byref(self._handle),
             )
         )
+
+    @classmethod
+    def from_slab_plan(cls, plan, comm: "Communicator | None" = None, device: int | None = None):
+        """One row slab (`bodge_amd.slab.SlabPlan`).  With `comm` the halo exchange uses RCCL
+        send/recv between ranks; without it the handle must be put into a `SlabGroup`."""
+        solver = cls(plan.indptr, plan.indices, plan.data, device=device, n_cols=plan.n_cols,
+                     row_offset=plan.row0)
+        n_peers = len(plan.peers)
+        peer_rank = np.asarray(plan.peers, dtype=np.int32)
+        send_count = np.asarray([rows.size for rows in plan.send_rows], dtype=np.int64)
+        send_rows = (np.concatenate(plan.send_rows) if n_peers else np.zeros(0)).astype(np.int64)
+        recv_col = np.asarray(plan.recv_offset, dtype=np.int64)
+        recv_count = np.asarray(plan.recv_count, dtype=np.int64)
+        backend.check(
+            solver._lib.bdg_slab_set_exchange(
+                solver._handle, comm._handle if comm is not None else None, n_peers,
+                backend.as_i32p(peer_rank), backend.as_i64p(send_count), backend.as_i64p(send_rows),
+                backend.as_i64p(recv_col), backend.as_i64p(recv_count),
+            )
+        )
+        solver._keepalive = comm
+        return solver
 
     @classmethod
     def from_hamiltonian(cls, system, device: int | None = None, drop_zero_blocks: bool = True):
@@ -162,6 +193,77 @@ class DeviceSolver:
 
 
 # ---------------------------------------------------------------------------
+class SlabGroup:
+    """Several row slabs of one matrix driven in lock step by this process.
+
+    The slabs may sit on one GPU (how the slab path is validated on a single-GPU box) or on
+    several GPUs of the node (`devices`); halo rows move by device-to-device copies.
+    """
+
+    def __init__(self, indptr, indices, data, n_slabs: int, granule: int = 1, devices=None):
+        from . import slab
+
+        n_rows = len(indptr) - 1
+        self.bounds = slab.partition_rows(n_rows, n_slabs, granule)
+        self.plans = [slab.build_plan(indptr, indices, data, self.bounds, r) for r in range(n_slabs)]
+        devices = [None] * n_slabs if devices is None else list(devices)
+        self.members = [DeviceSolver.from_slab_plan(p, device=d) for p, d in zip(self.plans, devices)]
+        self._lib = backend.load()
+        self._handle = C.c_void_p()
+        handles = (C.c_void_p * n_slabs)(*[m._handle for m in self.members])
+        backend.check(self._lib.bdg_group_create(handles, n_slabs, C.byref(self._handle)))
+        self.dim = 4 * n_rows
+
+    @classmethod
+    def from_hamiltonian(cls, system, n_slabs: int, devices=None):
+        from . import slab
+
+        indptr, indices, data = system.bsr_arrays()
+        return cls(indptr, indices, data, n_slabs, slab.lattice_granule(system.lattice), devices)
+
+    def dots_random(self, scale, n_steps, n_vectors, seed=0, first_id=0, kind=VEC_RADEMACHER):
+        d = np.empty((n_steps, n_vectors))
+        e = np.empty((n_steps, n_vectors))
+        backend.check(
+            self._lib.bdg_group_dots_random(
+                self._handle, float(scale), n_steps, n_vectors, seed, first_id, kind,
+                backend.as_f64p(d), backend.as_f64p(e),
+            )
+        )
+        return d, e
+
+    def dots_unit(self, scale, n_steps, rows):
+        rows = np.ascontiguousarray(rows, dtype=np.int64)
+        d = np.empty((n_steps, rows.size))
+        e = np.empty((n_steps, rows.size))
+        backend.check(
+            self._lib.bdg_group_dots_unit(
+                self._handle, float(scale), n_steps, rows.size, backend.as_i64p(rows),
+                backend.as_f64p(d), backend.as_f64p(e),
+            )
+        )
+        return d, e
+
+    def close(self) -> None:
+        if getattr(self, "_handle", None) is not None and self._handle:
+            self._lib.bdg_group_destroy(self._handle)
+            self._handle = C.c_void_p()
+            for member in self.members:
+                member.close()
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class _StdoutToStderr:
     """RCCL prints a version banner on stdout at communicator creation; programs that emit
     machine-readable stdout (bench.py's single JSON line) must not see it."""

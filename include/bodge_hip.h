@@ -42,6 +42,7 @@ extern "C" {
 
 typedef struct bdg_system bdg_system; /* one uploaded Hamiltonian on one GPU */
 typedef struct bdg_comm bdg_comm;     /* one RCCL communicator rank          */
+typedef struct bdg_group bdg_group;   /* several slabs driven by one process */
 
 /* Performance record of the most recent Chebyshev call on a handle. */
 typedef struct bdg_perf {
@@ -77,6 +78,36 @@ int bdg_device_count(int* count);
 int bdg_create(int device, int64_t nb, int64_t nnzb, const int32_t* indptr,
                const int32_t* indices, const double* data, bdg_system** out);
 int bdg_destroy(bdg_system* sys);
+
+/*
+ * Row-slab variant (domain decomposition over lattice planes, one slab per GPU): the
+ * handle owns block rows [row_offset, row_offset + nb) of the global matrix.  Column ids
+ * are LOCAL: 0..nb-1 are the owned rows, nb..ncols-1 are halo rows whose t_n entries are
+ * refreshed from other slabs before every recurrence launch.  Start vectors are indexed
+ * globally, so the result does not depend on how the rows are cut.  bodge_amd/slab.py
+ * derives these arrays from the global BSR triple.
+ */
+int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const int32_t* indptr,
+                    const int32_t* indices, const double* data, int64_t row_offset,
+                    bdg_system** out);
+/*
+ * Exchange lists of a slab.  For peer p: send_count[p] owned rows (local ids, concatenated
+ * in send_rows) go to it and recv_count[p] rows arrive from it into local columns
+ * recv_col[p] .. recv_col[p]+recv_count[p]-1.  peer_rank[p] is an RCCL rank when `comm` is
+ * given (one process per GPU: grouped ncclSend/ncclRecv per launch), or a member index of a
+ * bdg_group when comm is NULL (one process driving several slabs: device-to-device copies).
+ */
+int bdg_slab_set_exchange(bdg_system* sys, bdg_comm* comm, int32_t n_peers, const int32_t* peer_rank,
+                          const int64_t* send_count, const int64_t* send_rows,
+                          const int64_t* recv_col, const int64_t* recv_count);
+/* Same-process group of slabs: the dot products returned are summed over the members. */
+int bdg_group_create(bdg_system** members, int32_t n_members, bdg_group** out);
+int bdg_group_destroy(bdg_group* group);
+int bdg_group_dots_random(bdg_group* group, double scale, int32_t n_steps, int32_t n_vectors,
+                          uint64_t seed, uint64_t first_vec_id, int32_t vec_kind,
+                          double* d_out, double* e_out);
+int bdg_group_dots_unit(bdg_group* group, double scale, int32_t n_steps, int32_t n_vectors,
+                        const int64_t* rows, double* d_out, double* e_out);
 
 /* y = H x for one host vector of 4*nb complex entries (site-major, the order
  * of `H @ x` on the reference's matrix).  For parity tests. */

@@ -298,3 +298,59 @@ def test_device_copy_follows_with_block_updates(api):
     assert after < before - 1e-3
     dense = np.asarray(system.matrix("dense"))
     assert np.isclose(after, dense_ref.free_energy(dense, 0.2), rtol=1e-10)
+
+
+# ------------------------------------------------------------ slab decomposition
+@pytest.mark.parametrize("name,n_slabs,n_vectors,kind", [
+    ("random357", 3, 4, cheb_ref.VEC_Z4),           # periodic: every slab has wrap-around halos
+    ("dwave8", 4, 8, cheb_ref.VEC_RADEMACHER),      # 3-D real, 2 planes per slab
+    ("dwave8", 8, 3, cheb_ref.VEC_Z4),              # one plane per slab
+    ("swave20", 5, 64, cheb_ref.VEC_RADEMACHER),    # wide batch, real
+    ("chain128", 7, 2, cheb_ref.VEC_Z4),            # complex chain, uneven slabs
+])
+def test_slab_group_matches_whole_matrix(api, solver_cls, name, n_slabs, n_vectors, kind):
+    """Row slabs with halo exchange (same-process transport) against the undivided matrix
+    and the oracle: the decomposition must not change any dot product."""
+    from bodge_amd.solver import SlabGroup
+
+    system = _build(api, name)
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    steps = 20
+    ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps,
+                                   cheb_ref.random_block(bsr.shape[0], 6, range(2, 2 + n_vectors), kind))
+    with solver_cls.from_hamiltonian(system) as whole:
+        mono = whole.dots_random(scale, steps, n_vectors, seed=6, first_id=2, kind=kind)
+    with SlabGroup.from_hamiltonian(system, n_slabs) as group:
+        assert sum(p.n_own for p in group.plans) == system.lattice.size
+        split = group.dots_random(scale, steps, n_vectors, seed=6, first_id=2, kind=kind)
+        rows = np.array([3, 4 * (system.lattice.size // 2) + 1, system.shape[0] - 2])
+        unit_split = group.dots_unit(scale, steps, rows)
+    mu0 = bsr.shape[0]
+    for got in (mono, split):
+        assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * mu0)
+        assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * mu0)
+    unit_ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.unit_block(bsr.shape[0], rows))
+    assert np.allclose(unit_split[0], unit_ref[0], rtol=0, atol=1e-13)
+    assert np.allclose(unit_split[1], unit_ref[1], rtol=0, atol=1e-13)
+
+
+def test_slab_with_rccl_self_exchange(api, solver_cls):
+    """The RCCL send/recv halo path on one GPU: a one-rank plan whose periodic wrap blocks are
+    routed through the halo region, exchanged with itself through ncclSend/ncclRecv."""
+    from bodge_amd import slab
+    from bodge_amd.solver import Communicator
+
+    system = systems.random_periodic(api, shape=(6, 4, 3), seed=5)
+    indptr, indices, data = system.bsr_arrays()
+    plan = slab.build_plan(indptr, indices, data, np.array([0, system.lattice.size]), 0, self_exchange=True)
+    assert plan.halo_rows == 24
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    comm = Communicator(0, 1, 0, Communicator.new_unique_id())
+    with solver_cls.from_slab_plan(plan, comm=comm) as dev:
+        got = dev.dots_random(scale, 16, 5, seed=8, kind=cheb_ref.VEC_Z4)
+    ref = cheb_ref.recurrence_dots(bsr, scale, 32, cheb_ref.random_block(bsr.shape[0], 8, range(5), cheb_ref.VEC_Z4))
+    assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * bsr.shape[0])
+    assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * bsr.shape[0])
+    comm.close()
