@@ -39,15 +39,24 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def build_system(shape, zeeman=0.05, gap=0.1, mu=3.0):
+def build_system(shape, model="swave", zeeman=0.05, gap=0.1, mu=3.0):
+    """Synthetic Hamiltonians of SURVEY §8d: "swave" = README model (+Zeeman), "dwave" = config 4."""
     import bodge_amd as ba
 
     lattice = ba.CubicLattice(tuple(shape))
     system = ba.Hamiltonian(lattice)
     with system as (H, Δ):
-        H.set_sites(mu * ba.σ0 - zeeman * ba.σ3)
-        Δ.set_sites(-gap * ba.jσ2)
-        H.set_bonds(-1.0 * ba.σ0)
+        if model == "swave":
+            H.set_sites(mu * ba.σ0 - zeeman * ba.σ3)
+            Δ.set_sites(-gap * ba.jσ2)
+            H.set_bonds(-1.0 * ba.σ0)
+        elif model == "dwave":
+            pairs = lattice.bond_array(coords=True)
+            H.set_sites(mu * ba.σ0)
+            H.set_bonds(-1.0 * ba.σ0)
+            Δ.set_bonds(-gap * ba.dwave()(pairs[:, 0], pairs[:, 1]))
+        else:
+            raise ValueError(model)
     return system
 
 
@@ -62,7 +71,7 @@ def measured_traffic(kernel: str, shape, vectors: int):
         return None
     with open(path) as fh:
         table = json.load(fh)
-    entry = table.get(f"{kernel}|{'x'.join(str(v) for v in shape)} R={vectors}")
+    entry = table.get(f"{kernel}|{'x'.join(str(v) for v in shape)} R={vectors}")  # swave/vectors-mode entries
     return entry["traffic_bytes_per_launch"] if entry else None
 
 
@@ -77,6 +86,10 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="override lanes per block row (tuning)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--temperature", type=float, default=0.5)
+    ap.add_argument("--model", default="swave", choices=["swave", "dwave"])
+    ap.add_argument("--mode", default="vectors", choices=["vectors", "slab"],
+                    help="vectors: H replicated, start vectors sharded (weak scaling, headline); "
+                         "slab: lattice planes sharded with per-step halo exchange (strong scaling, config 4)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -98,18 +111,27 @@ def main():
 
     shape = [int(v) for v in args.lattice.split(",")]
     t0 = time.perf_counter()
-    system = build_system(shape)
+    system = build_system(shape, args.model)
     indptr, indices, data = system.bsr_arrays()
     scale = chebyshev.spectral_bound(indptr, data)
     t_build = time.perf_counter() - t0
     device = local % backend.device_count()
-    solver = DeviceSolver(indptr, indices, data, device=device)
-    solver.set_lattice_shape(shape)
-    if args.lanes:
-        solver.set_lanes_per_row(args.lanes)
     kind = VEC_RADEMACHER if args.vector_kind == "rademacher" else VEC_Z4
     r_local = args.vectors_per_gpu
-    first = rank * r_local
+    if args.mode == "slab":
+        # every rank advances the same r_local vectors on its own slab of x-planes
+        from bodge_amd import slab
+
+        bounds = slab.partition_rows(system.lattice.size, world, slab.lattice_granule(system.lattice))
+        plan = slab.build_plan(indptr, indices, data, bounds, rank)
+        solver = DeviceSolver.from_slab_plan(plan, comm=comm, device=device)
+        first = 0
+    else:
+        solver = DeviceSolver(indptr, indices, data, device=device)
+        solver.set_lattice_shape(shape)
+        first = rank * r_local
+    if args.lanes:
+        solver.set_lanes_per_row(args.lanes)
 
     def run(steps):
         return solver.moments_random(scale, 2 * steps, r_local, seed=0, first_id=first, kind=kind, comm=comm)
@@ -141,7 +163,7 @@ def main():
         del os.environ["BODGE_AMD_REAL"]
         launch_c = perf_c["kernel_ms"] / max(1, perf_c["launches"])
         complex_pass = {
-            "value": r_local * args.gpus * args.steps / elapsed_c,
+            "value": r_local * (1 if args.mode == "slab" else args.gpus) * args.steps / elapsed_c,
             "unit": "steps/s",
             "launch_ms": launch_c,
             "bytes_per_launch": perf_c["bytes_per_launch"],
@@ -152,7 +174,7 @@ def main():
     if rank != 0:
         return
 
-    total_vectors = r_local * args.gpus
+    total_vectors = r_local * (1 if args.mode == "slab" else args.gpus)
     value = total_vectors * args.steps / elapsed
     launch_ms = perf["kernel_ms"] / max(1, perf["launches"])
     achieved = perf["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
@@ -169,20 +191,21 @@ def main():
         "warmup": args.warmup,
         "ms_per_step": 1e3 * elapsed / args.steps,
         "higher_is_better": True,
-        "scaling": "weak",
+        "scaling": "strong" if args.mode == "slab" else "weak",
         "vs_baseline": None,
         "dtype": "f64" if perf["real_arithmetic"] else "c128",
         "data": "synthetic",
         "config": {
-            "workload": f"CubicLattice({tuple(shape)}) s-wave+Zeeman, {2 * args.steps}-moment stochastic-trace "
-                        f"free_energy, {r_local} vectors/GPU, H replicated, vectors sharded",
+            "workload": f"CubicLattice({tuple(shape)}) {args.model}, {2 * args.steps}-moment stochastic-trace "
+                        + (f"free_energy, {r_local} vectors, x-plane slabs with halo exchange" if args.mode == "slab"
+                           else f"free_energy, {r_local} vectors/GPU, H replicated, vectors sharded"),
             "n_sites": int(system.lattice.size),
             "nnzb": int(indices.size),
             "moments": 2 * args.steps,
             "vectors_per_gpu": r_local,
             "vector_kind": args.vector_kind,
             "spectral_scale": scale,
-            "parallelism": f"vectors x{args.gpus}",
+            "parallelism": f"{args.mode} x{args.gpus}",
         },
         "roofline": {
             "bound": "hbm",
@@ -209,6 +232,18 @@ def main():
 
         bsr = system.matrix("bsr")
         cpu_rate, cpu_steps = cheb_ref.time_recurrence(bsr, scale, r_local, seconds=args.cpu_seconds, kind=kind)
+        # beside the headline port: the same loop on CSR (no in-block zeros), on real data when the
+        # GPU also ran real arithmetic, and forked over several cores - so the CPU side is not
+        # handicapped by storage format, dtype or thread count
+        extra = {}
+        short = max(3.0, args.cpu_seconds / 3)
+        extra["csr_1core_steps_per_s"] = cheb_ref.time_recurrence(bsr, scale, r_local, seconds=short, kind=kind, fmt="csr")[0]
+        if perf["real_arithmetic"]:
+            extra["csr_real_1core_steps_per_s"] = cheb_ref.time_recurrence(
+                bsr, scale, r_local, seconds=short, kind=kind, fmt="csr", real=True)[0]
+        procs = max(1, min(16, (os.cpu_count() or 2) // 2))
+        extra["bsr_processes"] = procs
+        extra["bsr_multiprocess_steps_per_s"] = cheb_ref.time_recurrence_processes(bsr, scale, r_local, procs, seconds=short)
         record["cpu_baseline"] = {
             "value": cpu_rate,
             "unit": "steps/s",
@@ -216,6 +251,7 @@ def main():
             "kind": "port",
             "sample": f"{cpu_steps} timed block-steps of the same {r_local} vectors on the same H "
                       f"(scipy.sparse BSR matvec + numpy axpy/dots, host has {os.cpu_count()} logical cores)",
+            "other_cpu_variants": extra,
         }
     else:
         record["cpu_baseline"] = None

@@ -52,6 +52,15 @@ def chebyshev_coefficients(func, n_moments: int, oversample: int = 4) -> np.ndar
     return coeff
 
 
+def dots_to_moments(d: np.ndarray, e: np.ndarray) -> np.ndarray:
+    """(steps, R) recurrence dots -> (2*steps, R) moments: μ_2n = 2 d_n - μ_0, μ_2n+1 = 2 e_n - μ_1."""
+    mu = np.empty((2 * d.shape[0],) + d.shape[1:])
+    mu[0::2] = 2 * d - d[0]
+    mu[1::2] = 2 * e - e[0]
+    mu[0], mu[1] = d[0], e[0]
+    return mu
+
+
 def jackson_kernel(n_moments: int) -> np.ndarray:
     m = np.arange(n_moments)
     q = np.pi / (n_moments + 1)

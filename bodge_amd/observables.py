@@ -43,6 +43,7 @@ def free_energy(
     scale: float | None = None,
     damping: bool = False,
     comm=None,
+    decomposition: str = "vectors",
 ) -> float:
     """Free energy of `system` at `temperature` (reference hamiltonian.py:254-321).
 
@@ -50,8 +51,13 @@ def free_energy(
     moments  Chebyshev order M (even); default from the analyticity strip of f at T
     trace    "exact" (all 4N unit vectors), "stochastic", or "auto"
     vectors  number of random vectors for the stochastic trace (default 64)
-    comm     optional `Communicator`: vectors are dealt round-robin to ranks and the
-             moment vector is all-reduced over RCCL
+    comm     optional `Communicator` (one process per GPU)
+    decomposition  how the ranks of `comm` share the work:
+             "vectors" - H replicated, each rank owns a contiguous share of the start
+                         vectors, one all-reduce of the moments (default);
+             "slab"    - each rank owns a slab of lattice planes, every rank advances all
+                         vectors on its rows, halo rows exchanged per step (RCCL send/recv),
+                         one all-reduce of the moments.  For matrices too large to replicate.
     """
     if temperature < 0:
         raise ValueError("Expected non-negative temperature!")
@@ -69,13 +75,31 @@ def free_energy(
     if method != "chebyshev":
         raise RuntimeError(f"Free-energy method '{method}' is not supported")
 
-    solver = system._solver()
+    if decomposition not in ("vectors", "slab"):
+        raise RuntimeError(f"Decomposition '{decomposition}' is not supported")
     scale = _scale_of(system) if scale is None else float(scale)
     if moments is None:
         moments = cheb.moments_for_free_energy(scale, temperature)
     moments += moments & 1
     if trace == "auto":
         trace = "exact" if dim <= EXACT_TRACE_LIMIT else "stochastic"
+
+    if decomposition == "slab" and comm is not None:
+        solver = _slab_solver(system, comm)
+        steps = moments // 2
+        if trace == "exact":
+            d, e = solver.dots_unit(scale, steps, np.arange(dim, dtype=np.int64))
+            total = 1
+        elif trace == "stochastic":
+            kind = {"rademacher": VEC_RADEMACHER, "z4": VEC_Z4}[vector_kind]
+            total = 64 if vectors is None else int(vectors)
+            d, e = solver.dots_random(scale, steps, total, seed=seed, first_id=0, kind=kind)
+        else:
+            raise RuntimeError(f"Trace mode '{trace}' is not supported")
+        mu = comm.allreduce_sum(cheb.dots_to_moments(d, e).sum(axis=1)) / total
+        return cheb.free_energy_series(mu, scale, temperature, damping=damping)
+
+    solver = system._solver()
 
     if trace == "exact":
         rows = np.arange(dim, dtype=np.int64)
@@ -93,6 +117,24 @@ def free_energy(
     else:
         raise RuntimeError(f"Trace mode '{trace}' is not supported")
     return cheb.free_energy_series(mu, scale, temperature, damping=damping)
+
+
+def _slab_solver(system, comm):
+    """This rank's slab of `system` on its GPU (rebuilt after every `with` block)."""
+    from . import slab
+    from .solver import DeviceSolver
+
+    cached = getattr(system, "_slab_device", None)
+    if cached is not None and cached[0] == system._revision and cached[1] is comm:
+        return cached[2]
+    if cached is not None:
+        cached[2].close()
+    indptr, indices, data = system.bsr_arrays()
+    bounds = slab.partition_rows(system.lattice.size, comm.n_ranks, slab.lattice_granule(system.lattice))
+    plan = slab.build_plan(indptr, indices, data, bounds, comm.rank)
+    solver = DeviceSolver.from_slab_plan(plan, comm=comm, device=comm.device)
+    system._slab_device = (system._revision, comm, solver)
+    return solver
 
 
 def shard_vectors(total: int, comm) -> tuple[int, int]:

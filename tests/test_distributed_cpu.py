@@ -65,3 +65,29 @@ def test_two_gloo_ranks_match_single_rank(api, tmp_path):
     mu = cheb_ref.moments(bsr, scale, moments, start).sum(axis=1) / total
     assert np.allclose(got["mu"], mu, rtol=0, atol=1e-12 * bsr.shape[0])
     assert np.isclose(got["free_energy"], chebyshev.free_energy_series(mu, scale, 0.5), rtol=1e-12)
+
+
+@pytest.mark.timeout(600)
+def test_two_gloo_ranks_slab_exchange_matches_single_rank(api, tmp_path):
+    """Slab mode on 2 CPU ranks: the product's SlabPlan drives gloo halo exchange; moments must
+    equal the undivided oracle run."""
+    total, moments = 3, 48
+    out = tmp_path / "slab.json"
+    cmd = [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+        os.path.join(ROOT, "tests", "_dist_worker.py"), str(out), str(total), str(moments), "slab",
+    ]
+    proc = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ, OMP_NUM_THREADS="1"), capture_output=True,
+                          text=True, timeout=540)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    got = json.loads(out.read_text())
+    ranks = [json.loads((tmp_path / f"slab.json.rank{r}").read_text()) for r in range(2)]
+    assert [r["rows"] for r in ranks] == [[0, 36], [36, 72]]
+    assert all(r["halo"] == 24 and r["peers"] == [1 - i] for i, r in enumerate(ranks))
+
+    system = systems.random_periodic(api, shape=(6, 4, 3), seed=5)
+    bsr = system.matrix("bsr")
+    start = cheb_ref.random_block(bsr.shape[0], 0, range(total), cheb_ref.VEC_Z4)
+    mu = cheb_ref.moments(bsr, got["scale"], moments, start).sum(axis=1) / total
+    assert np.allclose(got["mu"], mu, rtol=0, atol=1e-12 * bsr.shape[0])

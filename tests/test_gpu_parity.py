@@ -354,3 +354,22 @@ def test_slab_with_rccl_self_exchange(api, solver_cls):
     assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * bsr.shape[0])
     assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * bsr.shape[0])
     comm.close()
+
+
+def test_free_energy_with_communicator_both_decompositions(api, golden, hip_library):
+    """free_energy(comm=...) with a one-rank RCCL communicator: vector-sharded and slab routes."""
+    from bodge_amd.solver import Communicator
+
+    comm = Communicator(0, 1, 0, Communicator.new_unique_id())
+    system = _build(api, "snf")
+    for decomposition in ("vectors", "slab"):
+        exact = system.free_energy(1.0, method="chebyshev", trace="exact", moments=64, comm=comm,
+                                   decomposition=decomposition)
+        assert np.isclose(exact, golden.free_energy("snf", 1.0), rtol=1e-10, atol=0)
+    a = system.free_energy(1.0, method="chebyshev", trace="stochastic", moments=64, vectors=16, comm=comm)
+    b = system.free_energy(1.0, method="chebyshev", trace="stochastic", moments=64, vectors=16, comm=comm,
+                           decomposition="slab")
+    assert np.isclose(a, b, rtol=1e-12)
+    with pytest.raises(RuntimeError):
+        system.free_energy(1.0, method="chebyshev", comm=comm, decomposition="rows")
+    comm.close()
