@@ -181,7 +181,8 @@ def main():
     free_energy = chebyshev.free_energy_series(mu / total_vectors, scale, args.temperature)
 
     kernel_name = ("cheb_step_pipelined" if perf["pipelined"] else "cheb_step") + (
-        f"<{'Real' if perf['real_arithmetic'] else 'Complex'}Mode,{perf['lanes_per_row']}>")
+        f"<{'Real' if perf['real_arithmetic'] else 'Complex'}{'PH' if perf['ph_packed'] else ''}Mode,"
+        f"{perf['lanes_per_row']}>")
     record = {
         "metric": "Chebyshev SpMV vector-steps/s, 4Nx4N BdG H (BSR 4x4 blocks), fused recurrence + dots",
         "value": value,

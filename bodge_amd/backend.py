@@ -40,7 +40,7 @@ class Perf(C.Structure):
         ("pipelined", C.c_int32),
         ("real_arithmetic", C.c_int32),
         ("strip_rows", C.c_int32),
-        ("reserved", C.c_int32),
+        ("ph_packed", C.c_int32),
     ]
 
 

@@ -105,9 +105,9 @@ struct bdg_system {
     int lanes_override = 0;
     DeviceBuffer<int> indptr, indices;
     DeviceBuffer<double2> blocks;
-    DeviceBuffer<double> blocks_real;  // Re(blocks), built on first real-mode call
+    DeviceBuffer<double2> packed[4];   // re-packed blocks per storage mode, built on first use
     bool is_real = false;              // imag(H) == 0 everywhere (checked at upload)
-    bool real_ready = false;
+    bool is_ph = false;                // every block is [[A, B], [C, -conj(A)]] (checked at upload)
     DeviceBuffer<double2> vec_a, vec_b;
     DeviceBuffer<double> partial, dots;
     DeviceBuffer<int64_t> rows;
@@ -137,7 +137,26 @@ namespace {
 using StepKernel = void (*)(bdg::StepArgs);
 
 using bdg::ComplexMode;
+using bdg::ComplexPHMode;
 using bdg::RealMode;
+using bdg::RealPHMode;
+
+// Storage / arithmetic mode of a launch.  id indexes bdg_system::packed.
+struct ModeInfo {
+    int id;          // 0 complex full, 1 real full, 2 complex PH, 3 real PH
+    bool real, ph;
+    int per_lane;    // vectors per lane
+    int stride;      // LDS slots (16 B) per staged block
+    double block_bytes;  // HBM bytes per stored block, index included
+    double entry_bytes;  // HBM bytes per (site, vector) and launch: read t_n, read t_{n-1}, write t_{n+1}
+};
+
+ModeInfo mode_info(bool real, bool ph) {
+    if (real && ph) return {3, true, true, RealPHMode::kVec, RealPHMode::kBlockStride, 100.0, 96.0};
+    if (real) return {1, true, false, RealMode::kVec, RealMode::kBlockStride, 132.0, 96.0};
+    if (ph) return {2, false, true, ComplexPHMode::kVec, ComplexPHMode::kBlockStride, 196.0, 192.0};
+    return {0, false, false, ComplexMode::kVec, ComplexMode::kBlockStride, 260.0, 192.0};
+}
 
 template <typename Mode>
 StepKernel generic_kernel(int rl) {
@@ -151,39 +170,50 @@ StepKernel generic_kernel(int rl) {
     return nullptr;
 }
 
-StepKernel step_kernel(bool real, int rl) {
-    return real ? generic_kernel<RealMode>(rl) : generic_kernel<ComplexMode>(rl);
+StepKernel step_kernel(const ModeInfo& mode, int rl) {
+    switch (mode.id) {
+        case 1: return generic_kernel<RealMode>(rl);
+        case 2: return generic_kernel<ComplexPHMode>(rl);
+        case 3: return generic_kernel<RealPHMode>(rl);
+    }
+    return generic_kernel<ComplexMode>(rl);
 }
 
 // Pipelined kernels exist for rows of at most 3 / 5 / 7 blocks (the 1-D / 2-D /
 // 3-D cubic stencils) and 8..64 lanes per row (complex) or 4..32 (real, two
 // vectors per lane); anything else runs the generic form.
-template <int MAXB>
-StepKernel pipelined_for(bool real, int rl) {
+template <typename CMode, typename RMode, int MAXB>
+StepKernel pipelined_pair(bool real, int rl) {
     if (real) {
         switch (rl) {
-            case 4: return bdg::cheb_step_pipelined<RealMode, 4, MAXB>;
-            case 8: return bdg::cheb_step_pipelined<RealMode, 8, MAXB>;
-            case 16: return bdg::cheb_step_pipelined<RealMode, 16, MAXB>;
-            case 32: return bdg::cheb_step_pipelined<RealMode, 32, MAXB>;
+            case 4: return bdg::cheb_step_pipelined<RMode, 4, MAXB>;
+            case 8: return bdg::cheb_step_pipelined<RMode, 8, MAXB>;
+            case 16: return bdg::cheb_step_pipelined<RMode, 16, MAXB>;
+            case 32: return bdg::cheb_step_pipelined<RMode, 32, MAXB>;
         }
         return nullptr;
     }
     switch (rl) {
-        case 8: return bdg::cheb_step_pipelined<ComplexMode, 8, MAXB>;
-        case 16: return bdg::cheb_step_pipelined<ComplexMode, 16, MAXB>;
-        case 32: return bdg::cheb_step_pipelined<ComplexMode, 32, MAXB>;
-        case 64: return bdg::cheb_step_pipelined<ComplexMode, 64, MAXB>;
+        case 8: return bdg::cheb_step_pipelined<CMode, 8, MAXB>;
+        case 16: return bdg::cheb_step_pipelined<CMode, 16, MAXB>;
+        case 32: return bdg::cheb_step_pipelined<CMode, 32, MAXB>;
+        case 64: return bdg::cheb_step_pipelined<CMode, 64, MAXB>;
     }
     return nullptr;
 }
 
-StepKernel pipelined_kernel(bool real, int rl, int max_row_blocks, int* maxb_out) {
-    const char* mode = getenv("BODGE_AMD_KERNEL");
-    if (mode && std::string(mode) == "generic") return nullptr;
-    if (max_row_blocks <= 3) { *maxb_out = 3; return pipelined_for<3>(real, rl); }
-    if (max_row_blocks <= 5) { *maxb_out = 5; return pipelined_for<5>(real, rl); }
-    if (max_row_blocks <= 7) { *maxb_out = 7; return pipelined_for<7>(real, rl); }
+template <int MAXB>
+StepKernel pipelined_for(const ModeInfo& mode, int rl) {
+    return mode.ph ? pipelined_pair<ComplexPHMode, RealPHMode, MAXB>(mode.real, rl)
+                   : pipelined_pair<ComplexMode, RealMode, MAXB>(mode.real, rl);
+}
+
+StepKernel pipelined_kernel(const ModeInfo& mode, int rl, int max_row_blocks, int* maxb_out) {
+    const char* env = getenv("BODGE_AMD_KERNEL");
+    if (env && std::string(env) == "generic") return nullptr;
+    if (max_row_blocks <= 3) { *maxb_out = 3; return pipelined_for<3>(mode, rl); }
+    if (max_row_blocks <= 5) { *maxb_out = 5; return pipelined_for<5>(mode, rl); }
+    if (max_row_blocks <= 7) { *maxb_out = 7; return pipelined_for<7>(mode, rl); }
     return nullptr;
 }
 
@@ -195,20 +225,20 @@ struct StepPlan {
     size_t lds_bytes = 0;      // dynamic LDS to request at launch
     size_t lds_footprint = 0;  // what one workgroup occupies (reported)
     bool pipelined = false;
-    bool real = false;
+    ModeInfo mode{};
     StepKernel kernel = nullptr;
 };
 
-int make_plan(bdg_system* sys, int rl, bool real, StepPlan* plan) {
+int make_plan(bdg_system* sys, int rl, const ModeInfo& mode, StepPlan* plan) {
     plan->rl = rl;
-    plan->real = real;
-    const int block_stride = real ? RealMode::kBlockStride : ComplexMode::kBlockStride;
-    const int lane_doubles = 2 * (real ? RealMode::kVec : ComplexMode::kVec);
+    plan->mode = mode;
+    const int block_stride = mode.stride;
+    const int lane_doubles = 2 * mode.per_lane;
     const int rows_per_wave = bdg::kWave / rl;
     plan->rows_per_tile = rows_per_wave * bdg::kWavesPerBlock;
     plan->n_tiles = (int)((sys->nb + plan->rows_per_tile - 1) / plan->rows_per_tile);
     int maxb = 0;
-    plan->kernel = pipelined_kernel(real, rl, sys->max_row_blocks, &maxb);
+    plan->kernel = pipelined_kernel(mode, rl, sys->max_row_blocks, &maxb);
     if (plan->kernel) {
         plan->pipelined = true;
         plan->lds_bytes = 0;
@@ -216,7 +246,7 @@ int make_plan(bdg_system* sys, int rl, bool real, StepPlan* plan) {
                                   sizeof(double2) +
                               (size_t)bdg::kWavesPerBlock * rl * lane_doubles * sizeof(double);
     } else {
-        plan->kernel = step_kernel(real, rl);
+        plan->kernel = step_kernel(mode, rl);
         if (!plan->kernel) return fail(BDG_EINVAL, "unsupported lanes-per-row %d", rl);
         const size_t stage = (size_t)bdg::kWavesPerBlock * rows_per_wave * sys->max_row_blocks *
                              block_stride * sizeof(double2);
@@ -244,22 +274,31 @@ int make_plan(bdg_system* sys, int rl, bool real, StepPlan* plan) {
 // Algorithmic HBM bytes of one recurrence launch: every stored block and index
 // once, and per (site, vector) one read of t_n, one read of t_{n-1}, one write
 // of t_{n+1} (260 nnzb + 4 (nb+1) + 192 R nb).
-// Real mode stores and moves half of that: 128 B per block, 8 B per vector entry.
-double algorithmic_bytes(const bdg_system* sys, int vectors, bool real) {
-    const double block = real ? 132.0 : 260.0, entry = real ? 96.0 : 192.0;
-    return block * (double)sys->nnzb + 4.0 * (double)(sys->nb + 1) +
-           entry * (double)vectors * (double)sys->nb;
+// The other modes store and move less (real: half; particle-hole packed: 12 of 16 entries),
+// and are charged with their own byte counts.
+double algorithmic_bytes(const bdg_system* sys, int vectors, const ModeInfo& mode) {
+    return mode.block_bytes * (double)sys->nnzb + 4.0 * (double)(sys->nb + 1) +
+           mode.entry_bytes * (double)vectors * (double)sys->nb;
 }
 
-int ensure_real_blocks(bdg_system* sys) {
-    if (sys->real_ready) return BDG_OK;
-    const size_t count = (size_t)std::max<int64_t>(1, sys->nnzb) * 16;
-    if (int rc = sys->blocks_real.reserve(count)) return rc;
-    const int grid = (int)std::min<size_t>(8192, (count + 255) / 256);
-    bdg::extract_real<<<grid, 256, 0, sys->stream>>>(sys->blocks.ptr, sys->blocks_real.ptr,
-                                                     (int64_t)sys->nnzb * 16);
-    HIP_TRY(hipGetLastError());
-    sys->real_ready = true;
+// Blocks in the layout `mode` reads (built on the device from the uploaded copy, once).
+int ensure_blocks(bdg_system* sys, const ModeInfo& mode, const void** out) {
+    if (mode.id == 0) {
+        *out = sys->blocks.ptr;
+        return BDG_OK;
+    }
+    DeviceBuffer<double2>& buf = sys->packed[mode.id];
+    if (!buf.ptr) {
+        const int entries = mode.ph ? 12 : 16;
+        const size_t doubles = (size_t)std::max<int64_t>(1, sys->nnzb) * entries * (mode.real ? 1 : 2);
+        if (int rc = buf.reserve((doubles + 1) / 2)) return rc;
+        const int64_t total = sys->nnzb * entries;
+        const int grid = (int)std::min<int64_t>(8192, (total + 255) / 256 + 1);
+        bdg::pack_blocks<<<grid, 256, 0, sys->stream>>>(sys->blocks.ptr, buf.ptr, sys->nnzb, entries,
+                                                        mode.real ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+    }
+    *out = buf.ptr;
     return BDG_OK;
 }
 
@@ -448,6 +487,7 @@ struct Batch {
     StepPlan plan;
     bdg::StepArgs args{};
     bool real = false;
+    ModeInfo mode{};
     int rl = 0, rv = 0, n_active = 0, n_steps = 0, chunk = 1, strip_rows = 0;
     size_t width = 0, per_step = 0, vec_count = 0;
     double scale = 1.0;
@@ -469,7 +509,9 @@ struct Batch {
         const char* real_env = getenv("BODGE_AMD_REAL");
         real = sys->is_real && start_is_real && !(real_env && real_env[0] == '0');
         if (force_real >= 0) real = force_real != 0;
-        const int per_lane = real ? RealMode::kVec : ComplexMode::kVec;
+        const char* ph_env = getenv("BODGE_AMD_PH");
+        mode = mode_info(real, sys->is_ph && !(ph_env && ph_env[0] == '0'));
+        const int per_lane = mode.per_lane;
         // Fewer than 4 lanes per row would put 32-64 rows' blocks into one wave's LDS
         // region with no reuse; small batches run with zero-padded columns.
         rl = std::max(4, next_pow2((n_active + per_lane - 1) / per_lane));
@@ -477,9 +519,9 @@ struct Batch {
             sys->lanes_override * per_lane <= 64)
             rl = sys->lanes_override;
         rv = rl * per_lane;  // vector columns in the buffers
-        if (int rc = make_plan(sys, rl, real, &plan)) return rc;
-        if (real)
-            if (int rc = ensure_real_blocks(sys)) return rc;
+        if (int rc = make_plan(sys, rl, mode, &plan)) return rc;
+        const void* block_data = nullptr;
+        if (int rc = ensure_blocks(sys, mode, &block_data)) return rc;
 
         vec_count = (size_t)4 * sys->ncols * rl;  // 16-byte lane payloads
         if (int rc = sys->vec_a.reserve(vec_count)) return rc;
@@ -525,8 +567,7 @@ struct Batch {
         args = bdg::StepArgs{};
         args.indptr = sys->indptr.ptr;
         args.indices = sys->indices.ptr;
-        args.blocks = real ? static_cast<const void*>(sys->blocks_real.ptr)
-                           : static_cast<const void*>(sys->blocks.ptr);
+        args.blocks = block_data;
         args.nb = (int)sys->nb;
         args.ncols = (int)sys->ncols;
         args.n_tiles = plan.n_tiles;
@@ -638,10 +679,11 @@ struct Batch {
         p.kernel_ms += kernel_ms;
         p.launches += n_steps;
         p.vector_steps += (int64_t)n_steps * n_active;
-        p.bytes_per_launch = algorithmic_bytes(sys, rv, real);
+        p.bytes_per_launch = algorithmic_bytes(sys, rv, mode);
         p.lanes_per_row = rl;
         p.vectors_per_launch = rv;
         p.real_arithmetic = real ? 1 : 0;
+        p.ph_packed = mode.ph ? 1 : 0;
         p.strip_rows = strip_rows;
         p.grid = plan.grid;
         p.lds_bytes = (int32_t)plan.lds_footprint;
@@ -695,6 +737,7 @@ int run_group(bdg_group* group, double scale, int n_steps, int n_vectors, StartS
     const size_t n_members = group->members.size();
     bool all_real = true;
     for (bdg_system* m : group->members) all_real = all_real && m->is_real;
+    // (storage packing is per member: it changes what a member reads, not what it exchanges)
     const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
     const char* real_env = getenv("BODGE_AMD_REAL");
     const int force_real = (all_real && start_is_real && !(real_env && real_env[0] == '0')) ? 1 : 0;
@@ -800,6 +843,15 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     }
     bool is_real = true;
     for (int64_t q = 0; q < nnzb * 16 && is_real; ++q) is_real = data[2 * q + 1] == 0.0;
+    // particle-hole form: lower-right 2x2 == -conj(upper-left 2x2), exactly, in every block
+    bool is_ph = true;
+    for (int64_t k = 0; k < nnzb && is_ph; ++k)
+        for (int i = 0; i < 2 && is_ph; ++i)
+            for (int j = 0; j < 2; ++j) {
+                const double* a = data + 2 * (k * 16 + i * 4 + j);
+                const double* d = data + 2 * (k * 16 + (i + 2) * 4 + (j + 2));
+                if (d[0] != -a[0] || d[1] != a[1]) is_ph = false;
+            }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
         (void)hipGetLastError();
@@ -816,6 +868,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     sys->nnzb = nnzb;
     sys->max_row_blocks = std::max(1, max_row);
     sys->is_real = is_real;
+    sys->is_ph = is_ph;
     hipDeviceProp_t prop;
     auto cleanup = [&](int rc) {
         bdg_destroy(sys);
@@ -948,7 +1001,7 @@ int bdg_destroy(bdg_system* sys) {
     sys->indptr.release();
     sys->indices.release();
     sys->blocks.release();
-    sys->blocks_real.release();
+    for (auto& buf : sys->packed) buf.release();
     sys->vec_a.release();
     sys->vec_b.release();
     sys->partial.release();
@@ -980,7 +1033,7 @@ int bdg_set_lattice_shape(bdg_system* sys, int32_t lx, int32_t ly, int32_t lz) {
 
 int bdg_set_lanes_per_row(bdg_system* sys, int32_t lanes) {
     if (!sys) return fail(BDG_EINVAL, "null system handle");
-    if (lanes != 0 && !step_kernel(false, lanes)) return fail(BDG_EINVAL, "lanes must be 4, 8, 16, 32 or 64");
+    if (lanes != 0 && !step_kernel(mode_info(false, false), lanes)) return fail(BDG_EINVAL, "lanes must be 4, 8, 16, 32 or 64");
     sys->lanes_override = lanes;
     return BDG_OK;
 }
@@ -991,7 +1044,7 @@ int bdg_spmv(bdg_system* sys, const double* x, double* y) {
     HIP_TRY(hipSetDevice(sys->device));
     constexpr int kCols = 4;  // narrowest kernel configuration; columns 1..3 stay zero
     StepPlan plan;
-    if (int rc = make_plan(sys, kCols, /*real=*/false, &plan)) return rc;
+    if (int rc = make_plan(sys, kCols, mode_info(false, false), &plan)) return rc;
     const size_t n = (size_t)4 * sys->nb;
     if (int rc = sys->vec_a.reserve(n * kCols)) return rc;
     if (int rc = sys->vec_b.reserve(n * kCols)) return rc;

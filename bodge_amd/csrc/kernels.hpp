@@ -247,6 +247,76 @@ struct RealMode {
     }
 };
 
+// Particle-hole packed storage.  Every block the assembly produces has the Nambu form
+//   [[ A, B ], [ C, -conj(A) ]]   (reference hamiltonian.py:106-118: H_ij -> (+H, -H*),
+// Δ_ij -> upper right, Δ_ji^† -> lower left), so the lower-right 2x2 need not be stored:
+// 12 of 16 entries, order A00 A01 A10 A11 | B00 B01 B10 B11 | C00 C01 C10 C11.  Checked
+// block by block at upload; matrices that violate it use the full modes.
+struct ComplexPHMode {
+    static constexpr int kVec = 1;
+    static constexpr int kSlotsPerBlock = 12;
+    static constexpr int kBlockStride = 13;
+    __device__ static inline void cfma(double2& acc, const double2 m, const double2 x) {
+        acc.x = fma(m.x, x.x, acc.x);
+        acc.x = fma(-m.y, x.y, acc.x);
+        acc.y = fma(m.x, x.y, acc.y);
+        acc.y = fma(m.y, x.x, acc.y);
+    }
+    // acc -= conj(m) * x
+    __device__ static inline void cfms_conj(double2& acc, const double2 m, const double2 x) {
+        acc.x = fma(-m.x, x.x, acc.x);
+        acc.x = fma(-m.y, x.y, acc.x);
+        acc.y = fma(-m.x, x.y, acc.y);
+        acc.y = fma(m.y, x.x, acc.y);
+    }
+    __device__ static inline void mac_row(double2 acc[4], const double2* blk, const double2 x[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double2 a0 = blk[2 * i], a1 = blk[2 * i + 1];
+            const double2 b0 = blk[4 + 2 * i], b1 = blk[4 + 2 * i + 1];
+            const double2 c0 = blk[8 + 2 * i], c1 = blk[8 + 2 * i + 1];
+            cfma(acc[i], a0, x[0]);
+            cfma(acc[i], a1, x[1]);
+            cfma(acc[i], b0, x[2]);
+            cfma(acc[i], b1, x[3]);
+            cfma(acc[2 + i], c0, x[0]);
+            cfma(acc[2 + i], c1, x[1]);
+            cfms_conj(acc[2 + i], a0, x[2]);
+            cfms_conj(acc[2 + i], a1, x[3]);
+        }
+    }
+    __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
+        ComplexMode::dots(dot, c, n);
+    }
+};
+
+struct RealPHMode {
+    static constexpr int kVec = 2;
+    static constexpr int kSlotsPerBlock = 6;
+    static constexpr int kBlockStride = 7;
+    __device__ static inline void rfma(double2& acc, const double m, const double2 x) {
+        acc.x = fma(m, x.x, acc.x);
+        acc.y = fma(m, x.y, acc.y);
+    }
+    __device__ static inline void mac_row(double2 acc[4], const double2* blk, const double2 x[4]) {
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const double2 a = blk[i], b = blk[2 + i], c = blk[4 + i];  // row i of A, B, C
+            rfma(acc[i], a.x, x[0]);
+            rfma(acc[i], a.y, x[1]);
+            rfma(acc[i], b.x, x[2]);
+            rfma(acc[i], b.y, x[3]);
+            rfma(acc[2 + i], c.x, x[0]);
+            rfma(acc[2 + i], c.y, x[1]);
+            rfma(acc[2 + i], -a.x, x[2]);
+            rfma(acc[2 + i], -a.y, x[3]);
+        }
+    }
+    __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
+        RealMode::dots(dot, c, n);
+    }
+};
+
 // Wave reduction over the site lanes, then over the 4 waves through `red`,
 // one partial per workgroup: partial[block][vector][{d, e}].
 template <typename Mode, int RL>
@@ -542,12 +612,26 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
     reduce_dots<Mode, RL>(dot, red, a.partial, lane, wave);
 }
 
-// real[k][e] = Re blocks[k][e]   (device-side conversion for RealMode)
-__global__ void extract_real(const double2* __restrict__ blocks, double* __restrict__ real,
-                             int64_t count) {
-    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < count;
-         idx += (int64_t)gridDim.x * blockDim.x)
-        real[idx] = blocks[idx].x;
+// Device-side re-packing of the uploaded complex 4x4 blocks for the other storage modes.
+// `entries` = 16 (full) or 12 (particle-hole packed); real_out writes doubles, else double2.
+__device__ inline int packed_source(int entries, int e) {
+    if (entries == 16) return e;
+    const int group = e >> 2, within = e & 3;          // A, B, C groups of four
+    const int row = (within >> 1) + (group == 2 ? 2 : 0);
+    const int col = (within & 1) + (group == 1 ? 2 : 0);
+    return row * 4 + col;
+}
+
+__global__ void pack_blocks(const double2* __restrict__ blocks, void* __restrict__ out, int64_t nnzb,
+                            int entries, int real_out) {
+    const int64_t total = nnzb * entries;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t k = idx / entries;
+        const double2 v = blocks[k * 16 + packed_source(entries, (int)(idx % entries))];
+        if (real_out) static_cast<double*>(out)[idx] = v.x;
+        else static_cast<double2*>(out)[idx] = v;
+    }
 }
 
 // ------------------------------------------------------------------------ K2

@@ -1,0 +1,42 @@
+"""Interleaved A/B timing of recurrence-kernel variants selected by environment variables.
+
+usage: python3 scratch/kbench.py "NAME=ENV1=V1,ENV2=V2" "NAME2=..." [--lattice 1000,1000,1] [--vectors 8] [--rounds 5]
+"""
+import os, sys, time
+sys.path.insert(0, ".")
+import numpy as np
+import bench
+from bodge_amd import chebyshev
+from bodge_amd.solver import DeviceSolver
+
+args = [a for a in sys.argv[1:] if not a.startswith("--")]
+opts = dict(zip(sys.argv[1:], sys.argv[2:]))
+shape = [int(v) for v in opts.get("--lattice", "1000,1000,1").split(",")]
+vectors = int(opts.get("--vectors", "8"))
+rounds = int(opts.get("--rounds", "5"))
+steps = int(opts.get("--steps", "40"))
+model = opts.get("--model", "swave")
+variants = []
+for a in args:
+    name, _, envs = a.partition("=")
+    variants.append((name, dict(e.split("=") for e in envs.split(",") if e)))
+system = bench.build_system(shape, model)
+indptr, indices, data = system.bsr_arrays()
+scale = chebyshev.spectral_bound(indptr, data)
+solver = DeviceSolver(indptr, indices, data)
+solver.set_lattice_shape(shape)
+results = {name: [] for name, _ in variants}
+for rnd in range(rounds + 1):
+    for name, env in variants:
+        for k, v in env.items():
+            os.environ[k] = v
+        solver.dots_random(scale, steps, vectors, seed=rnd)
+        p = solver.perf()
+        for k in env:
+            del os.environ[k]
+        if rnd:
+            results[name].append((p["kernel_ms"] / p["launches"], p["bytes_per_launch"], p))
+for name, _ in variants:
+    ms = np.array([r[0] for r in results[name]]); b = results[name][0][1]; p = results[name][0][2]
+    print(f"{name:28s} median {np.median(ms):.4f} ms  min {ms.min():.4f}  -> {b/np.median(ms)/1e6:7.1f} GB/s (best {b/ms.min()/1e6:7.1f})"
+          f"  grid {p['grid']} lds {p['lds_bytes']} rl {p['lanes_per_row']} real {p['real_arithmetic']} pipe {p['pipelined']}")

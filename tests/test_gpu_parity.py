@@ -170,6 +170,44 @@ def test_strip_ordered_tiles_do_not_change_results(api, solver_cls, monkeypatch,
         assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * mu0)
 
 
+@pytest.mark.parametrize("name,n_vectors,kind", [
+    ("random357", 6, cheb_ref.VEC_Z4),          # complex blocks, periodic
+    ("complex235", 3, cheb_ref.VEC_RADEMACHER),  # complex H with real start vectors
+    ("swave20", 9, cheb_ref.VEC_RADEMACHER),    # real
+    ("dwave8", 64, cheb_ref.VEC_RADEMACHER),    # real, 3-D
+])
+def test_particle_hole_packed_storage_is_exact(api, solver_cls, monkeypatch, name, n_vectors, kind):
+    """Blocks built by the Hamiltonian have the form [[A,B],[C,-A*]]; storing 12 of 16 entries
+    must give bit-identical dot products (same products, same order)."""
+    system = _build(api, name)
+    scale = cheb_ref.spectral_bound(system.matrix("bsr"))
+    with solver_cls.from_hamiltonian(system) as dev:
+        packed = dev.dots_random(scale, 16, n_vectors, seed=3, kind=kind)
+        assert dev.perf()["ph_packed"] == 1
+        monkeypatch.setenv("BODGE_AMD_PH", "0")
+        full = dev.dots_random(scale, 16, n_vectors, seed=3, kind=kind)
+        assert dev.perf()["ph_packed"] == 0
+    assert np.array_equal(packed[0], full[0]) and np.array_equal(packed[1], full[1])
+
+
+def test_matrix_without_particle_hole_form_uses_full_storage(api, solver_cls):
+    """A hand-made BSR matrix (Hermitian, but blocks not of Nambu form) must not be packed."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(3)
+    blocks = rng.standard_normal((3, 4, 4)) + 1j * rng.standard_normal((3, 4, 4))
+    diag0, diag1 = blocks[0] + blocks[0].conj().T, blocks[1] + blocks[1].conj().T
+    data = np.array([diag0, blocks[2], blocks[2].conj().T, diag1])
+    indptr, indices = np.array([0, 2, 4], dtype=np.int32), np.array([0, 1, 0, 1], dtype=np.int32)
+    mat = sp.bsr_matrix((data, indices, indptr), shape=(8, 8))
+    scale = 1.01 * np.abs(mat.toarray()).sum(axis=1).max()
+    ref = cheb_ref.recurrence_dots(mat, scale, 20, cheb_ref.random_block(8, 1, range(4), cheb_ref.VEC_Z4))
+    with solver_cls(indptr, indices, data) as dev:
+        got = dev.dots_random(scale, 10, 4, seed=1, kind=cheb_ref.VEC_Z4)
+        assert dev.perf()["ph_packed"] == 0 and dev.perf()["real_arithmetic"] == 0
+    assert np.allclose(got[0], ref[0], atol=1e-12) and np.allclose(got[1], ref[1], atol=1e-12)
+
+
 @pytest.mark.parametrize("name,kind,lane_options", [
     ("dwave8", cheb_ref.VEC_RADEMACHER, (4, 8, 16, 32)),  # real arithmetic: two vectors per lane
     ("random357", cheb_ref.VEC_Z4, (4, 8, 16, 32, 64)),   # complex arithmetic
