@@ -147,29 +147,33 @@ def main():
         elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
     perf = solver.perf()
 
-    # Second pass with the complex kernels forced (only differs when the real-valued
-    # specialisation was selected above): reported beside the headline, never as `value`.
-    complex_pass = None
-    if perf["real_arithmetic"]:
-        os.environ["BODGE_AMD_REAL"] = "0"
+    # Further passes with optimisations switched off, reported beside the headline and never as
+    # `value`: blocks streamed from HBM instead of the LDS dictionary, and complex arithmetic.
+    def alternative(env):
+        for k, v in env.items():
+            os.environ[k] = v
         if comm is not None:
             comm.barrier()
         t0 = time.perf_counter()
         run(args.steps)
-        elapsed_c = time.perf_counter() - t0
+        dt = time.perf_counter() - t0
         if comm is not None:
-            elapsed_c = float(comm.allreduce_max(np.array([elapsed_c]))[0])
-        perf_c = solver.perf()
-        del os.environ["BODGE_AMD_REAL"]
-        launch_c = perf_c["kernel_ms"] / max(1, perf_c["launches"])
-        complex_pass = {
-            "value": r_local * (1 if args.mode == "slab" else args.gpus) * args.steps / elapsed_c,
+            dt = float(comm.allreduce_max(np.array([dt]))[0])
+        pf = solver.perf()
+        for k in env:
+            del os.environ[k]
+        launch = pf["kernel_ms"] / max(1, pf["launches"])
+        return {
+            "value": r_local * (1 if args.mode == "slab" else args.gpus) * args.steps / dt,
             "unit": "steps/s",
-            "launch_ms": launch_c,
-            "bytes_per_launch": perf_c["bytes_per_launch"],
-            "achieved_GBps": perf_c["bytes_per_launch"] / (launch_c * 1e-3) / 1e9,
-            "frac": perf_c["bytes_per_launch"] / (launch_c * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "launch_ms": launch,
+            "bytes_per_launch": pf["bytes_per_launch"],
+            "achieved_GBps": pf["bytes_per_launch"] / (launch * 1e-3) / 1e9,
+            "frac": pf["bytes_per_launch"] / (launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
         }
+
+    streamed_pass = alternative({"BODGE_AMD_DICT": "0"}) if perf["dict_blocks"] else None
+    complex_pass = alternative({"BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"}) if perf["real_arithmetic"] else None
 
     if rank != 0:
         return
@@ -180,7 +184,8 @@ def main():
     achieved = perf["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
     free_energy = chebyshev.free_energy_series(mu / total_vectors, scale, args.temperature)
 
-    kernel_name = ("cheb_step_pipelined" if perf["pipelined"] else "cheb_step") + (
+    kernel_name = ("cheb_step_dict" if perf["dict_blocks"] else
+                   "cheb_step_pipelined" if perf["pipelined"] else "cheb_step") + (
         f"<{'Real' if perf['real_arithmetic'] else 'Complex'}{'PH' if perf['ph_packed'] else ''}Mode,"
         f"{perf['lanes_per_row']}>")
     record = {
@@ -221,10 +226,12 @@ def main():
             "grid": perf["grid"],
             "lds_bytes": perf["lds_bytes"],
             "strip_rows": perf["strip_rows"],
+            "distinct_blocks": perf["dict_blocks"],
         },
         "free_energy_wall_s": elapsed,
         "free_energy_estimate": free_energy,
         "host_assembly_s": t_build,
+        "streamed_blocks_kernels": streamed_pass,
         "complex128_kernels": complex_pass,
     }
 

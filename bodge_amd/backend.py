@@ -41,6 +41,8 @@ class Perf(C.Structure):
         ("real_arithmetic", C.c_int32),
         ("strip_rows", C.c_int32),
         ("ph_packed", C.c_int32),
+        ("dict_blocks", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

@@ -20,7 +20,9 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <string_view>
 #include <tuple>
+#include <unordered_map>
 #include <vector>
 
 #include "kernels.hpp"
@@ -108,6 +110,11 @@ struct bdg_system {
     DeviceBuffer<double2> packed[4];   // re-packed blocks per storage mode, built on first use
     bool is_real = false;              // imag(H) == 0 everywhere (checked at upload)
     bool is_ph = false;                // every block is [[A, B], [C, -conj(A)]] (checked at upload)
+    // dictionary form: the distinct blocks and one id per stored block (0 entries = not used)
+    int n_unique = 0;
+    DeviceBuffer<int> dict_ids;
+    DeviceBuffer<double2> dict_full;      // n_unique x 16 complex entries
+    DeviceBuffer<double2> dict_table[4];  // packed per storage mode, built on first use
     DeviceBuffer<double2> vec_a, vec_b;
     DeviceBuffer<double> partial, dots;
     DeviceBuffer<int64_t> rows;
@@ -208,6 +215,47 @@ StepKernel pipelined_for(const ModeInfo& mode, int rl) {
                    : pipelined_pair<ComplexMode, RealMode, MAXB>(mode.real, rl);
 }
 
+template <typename CMode, typename RMode, int MAXB>
+StepKernel dict_pair(bool real, int rl) {
+    if (real) {
+        switch (rl) {
+            case 4: return bdg::cheb_step_dict<RMode, 4, MAXB>;
+            case 8: return bdg::cheb_step_dict<RMode, 8, MAXB>;
+            case 16: return bdg::cheb_step_dict<RMode, 16, MAXB>;
+            case 32: return bdg::cheb_step_dict<RMode, 32, MAXB>;
+        }
+        return nullptr;
+    }
+    switch (rl) {
+        case 4: return bdg::cheb_step_dict<CMode, 4, MAXB>;
+        case 8: return bdg::cheb_step_dict<CMode, 8, MAXB>;
+        case 16: return bdg::cheb_step_dict<CMode, 16, MAXB>;
+        case 32: return bdg::cheb_step_dict<CMode, 32, MAXB>;
+        case 64: return bdg::cheb_step_dict<CMode, 64, MAXB>;
+    }
+    return nullptr;
+}
+
+template <int MAXB>
+StepKernel dict_for(const ModeInfo& mode, int rl) {
+    return mode.ph ? dict_pair<ComplexPHMode, RealPHMode, MAXB>(mode.real, rl)
+                   : dict_pair<ComplexMode, RealMode, MAXB>(mode.real, rl);
+}
+
+constexpr size_t kDictLdsLimit = 32 * 1024;  // bytes of LDS the block table may take per workgroup
+
+// Dictionary kernel if the matrix has few enough distinct blocks for the table to sit in LDS.
+StepKernel dict_kernel(const bdg_system* sys, const ModeInfo& mode, int rl) {
+    const char* env = getenv("BODGE_AMD_DICT");
+    if (env && env[0] == '0') return nullptr;
+    if (sys->n_unique <= 0 || (size_t)sys->n_unique * mode.stride * sizeof(double2) > kDictLdsLimit)
+        return nullptr;
+    if (sys->max_row_blocks <= 3) return dict_for<3>(mode, rl);
+    if (sys->max_row_blocks <= 5) return dict_for<5>(mode, rl);
+    if (sys->max_row_blocks <= 7) return dict_for<7>(mode, rl);
+    return nullptr;
+}
+
 StepKernel pipelined_kernel(const ModeInfo& mode, int rl, int max_row_blocks, int* maxb_out) {
     const char* env = getenv("BODGE_AMD_KERNEL");
     if (env && std::string(env) == "generic") return nullptr;
@@ -225,6 +273,7 @@ struct StepPlan {
     size_t lds_bytes = 0;      // dynamic LDS to request at launch
     size_t lds_footprint = 0;  // what one workgroup occupies (reported)
     bool pipelined = false;
+    bool dictionary = false;
     ModeInfo mode{};
     StepKernel kernel = nullptr;
 };
@@ -238,8 +287,15 @@ int make_plan(bdg_system* sys, int rl, const ModeInfo& mode, StepPlan* plan) {
     plan->rows_per_tile = rows_per_wave * bdg::kWavesPerBlock;
     plan->n_tiles = (int)((sys->nb + plan->rows_per_tile - 1) / plan->rows_per_tile);
     int maxb = 0;
-    plan->kernel = pipelined_kernel(mode, rl, sys->max_row_blocks, &maxb);
+    plan->kernel = dict_kernel(sys, mode, rl);
     if (plan->kernel) {
+        plan->dictionary = true;
+        // table of distinct blocks + 4 own t_n entries per lane (16 KiB per workgroup)
+        const size_t table = (size_t)sys->n_unique * block_stride * sizeof(double2) +
+                             (size_t)bdg::kBlockThreads * 4 * sizeof(double2);
+        const size_t reduce = (size_t)bdg::kWavesPerBlock * rl * lane_doubles * sizeof(double);
+        plan->lds_bytes = plan->lds_footprint = std::max(table, reduce);
+    } else if ((plan->kernel = pipelined_kernel(mode, rl, sys->max_row_blocks, &maxb))) {
         plan->pipelined = true;
         plan->lds_bytes = 0;
         plan->lds_footprint = (size_t)bdg::kWavesPerBlock * rows_per_wave * maxb * block_stride *
@@ -276,9 +332,28 @@ int make_plan(bdg_system* sys, int rl, const ModeInfo& mode, StepPlan* plan) {
 // of t_{n+1} (260 nnzb + 4 (nb+1) + 192 R nb).
 // The other modes store and move less (real: half; particle-hole packed: 12 of 16 entries),
 // and are charged with their own byte counts.
-double algorithmic_bytes(const bdg_system* sys, int vectors, const ModeInfo& mode) {
-    return mode.block_bytes * (double)sys->nnzb + 4.0 * (double)(sys->nb + 1) +
+// In the dictionary form a stored block costs one packed word (column | id, 4 B); the table
+// of distinct blocks is read once per workgroup from L2 and is charged once.
+double algorithmic_bytes(const bdg_system* sys, int vectors, const ModeInfo& mode, bool dictionary) {
+    const double per_block = dictionary ? 4.0 : mode.block_bytes;
+    const double table = dictionary ? (mode.block_bytes - 4.0) * sys->n_unique : 0.0;
+    return per_block * (double)sys->nnzb + 4.0 * (double)(sys->nb + 1) + table +
            mode.entry_bytes * (double)vectors * (double)sys->nb;
+}
+
+// Table of distinct blocks in the layout `mode` reads.
+int ensure_dict_table(bdg_system* sys, const ModeInfo& mode, const void** out) {
+    DeviceBuffer<double2>& buf = sys->dict_table[mode.id];
+    if (!buf.ptr) {
+        const int entries = mode.ph ? 12 : 16;
+        const size_t doubles = (size_t)sys->n_unique * entries * (mode.real ? 1 : 2);
+        if (int rc = buf.reserve((doubles + 1) / 2)) return rc;
+        bdg::pack_blocks<<<(sys->n_unique * entries + 255) / 256, 256, 0, sys->stream>>>(
+            sys->dict_full.ptr, buf.ptr, sys->n_unique, entries, mode.real ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+    }
+    *out = buf.ptr;
+    return BDG_OK;
 }
 
 // Blocks in the layout `mode` reads (built on the device from the uploaded copy, once).
@@ -299,6 +374,26 @@ int ensure_blocks(bdg_system* sys, const ModeInfo& mode, const void** out) {
         HIP_TRY(hipGetLastError());
     }
     *out = buf.ptr;
+    return BDG_OK;
+}
+
+// Matrix-side kernel arguments for `plan` (block data or dictionary, sizes).  Every launch of
+// a step kernel goes through here so that no pointer the chosen kernel reads is left unset.
+int matrix_args(bdg_system* sys, const StepPlan& plan, bdg::StepArgs* args) {
+    *args = bdg::StepArgs{};
+    args->indptr = sys->indptr.ptr;
+    args->indices = sys->indices.ptr;
+    if (plan.dictionary) {
+        if (int rc = ensure_dict_table(sys, plan.mode, &args->dict_table)) return rc;
+        args->dict_ids = sys->dict_ids.ptr;
+        args->n_unique = sys->n_unique;
+    } else if (int rc = ensure_blocks(sys, plan.mode, &args->blocks)) {
+        return rc;
+    }
+    args->nb = (int)sys->nb;
+    args->ncols = (int)sys->ncols;
+    args->n_tiles = plan.n_tiles;
+    args->max_row_blocks = sys->max_row_blocks;
     return BDG_OK;
 }
 
@@ -520,8 +615,7 @@ struct Batch {
             rl = sys->lanes_override;
         rv = rl * per_lane;  // vector columns in the buffers
         if (int rc = make_plan(sys, rl, mode, &plan)) return rc;
-        const void* block_data = nullptr;
-        if (int rc = ensure_blocks(sys, mode, &block_data)) return rc;
+        if (int rc = matrix_args(sys, plan, &args)) return rc;
 
         vec_count = (size_t)4 * sys->ncols * rl;  // 16-byte lane payloads
         if (int rc = sys->vec_a.reserve(vec_count)) return rc;
@@ -564,14 +658,6 @@ struct Batch {
         bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)vec_count);
         HIP_TRY(hipGetLastError());
 
-        args = bdg::StepArgs{};
-        args.indptr = sys->indptr.ptr;
-        args.indices = sys->indices.ptr;
-        args.blocks = block_data;
-        args.nb = (int)sys->nb;
-        args.ncols = (int)sys->ncols;
-        args.n_tiles = plan.n_tiles;
-        args.max_row_blocks = sys->max_row_blocks;
         // bytes of t_n per block row that neighbouring rows re-read: 4 entries per vector
         if (int rc = prepare_tile_order(sys, plan.rows_per_tile, plan.n_tiles,
                                         (real ? 32.0 : 64.0) * rv, &args.tile_order, &strip_rows))
@@ -679,11 +765,12 @@ struct Batch {
         p.kernel_ms += kernel_ms;
         p.launches += n_steps;
         p.vector_steps += (int64_t)n_steps * n_active;
-        p.bytes_per_launch = algorithmic_bytes(sys, rv, mode);
+        p.bytes_per_launch = algorithmic_bytes(sys, rv, mode, plan.dictionary);
         p.lanes_per_row = rl;
         p.vectors_per_launch = rv;
         p.real_arithmetic = real ? 1 : 0;
         p.ph_packed = mode.ph ? 1 : 0;
+        p.dict_blocks = plan.dictionary ? sys->n_unique : 0;
         p.strip_rows = strip_rows;
         p.grid = plan.grid;
         p.lds_bytes = (int32_t)plan.lds_footprint;
@@ -852,6 +939,35 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
                 const double* d = data + 2 * (k * 16 + (i + 2) * 4 + (j + 2));
                 if (d[0] != -a[0] || d[1] != a[1]) is_ph = false;
             }
+    // Distinct blocks (exact, bitwise).  Gives up as soon as there are too many to be useful.
+    constexpr int kMaxDistinct = 256;  // table index shares a 32-bit word with the 24-bit column
+    std::vector<int> ids;
+    std::vector<double> distinct;  // n_unique x 32 doubles
+    {
+        const char* env = getenv("BODGE_AMD_DICT");
+        bool wanted = !(env && env[0] == '0') && nnzb > 0 && ncols <= (1 << 24);
+        if (wanted) {
+            std::unordered_map<std::string_view, int> seen;
+            ids.resize((size_t)nnzb);
+            for (int64_t k = 0; k < nnzb; ++k) {
+                std::string_view key(reinterpret_cast<const char*>(data + 32 * k), 256);
+                auto it = seen.find(key);
+                if (it == seen.end()) {
+                    if ((int)seen.size() == kMaxDistinct) {
+                        wanted = false;
+                        break;
+                    }
+                    it = seen.emplace(key, (int)seen.size()).first;
+                    distinct.insert(distinct.end(), data + 32 * k, data + 32 * (k + 1));
+                }
+                ids[(size_t)k] = (int)((unsigned)indices[k] | ((unsigned)it->second << 24));
+            }
+        }
+        if (!wanted) {
+            ids.clear();
+            distinct.clear();
+        }
+    }
     int n_dev = 0;
     if (hipGetDeviceCount(&n_dev) != hipSuccess || n_dev == 0) {
         (void)hipGetLastError();
@@ -889,6 +1005,15 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
           hipMemcpy(sys->blocks.ptr, data, sizeof(double2) * 16 * nnzb, hipMemcpyHostToDevice) !=
               hipSuccess)))
         return cleanup(fail(BDG_EDEVICE, "upload of the BSR arrays failed"));
+    if (!ids.empty()) {
+        sys->n_unique = (int)(distinct.size() / 32);
+        if (int rc = sys->dict_ids.reserve(ids.size())) return cleanup(rc);
+        if (int rc = sys->dict_full.reserve((size_t)sys->n_unique * 16)) return cleanup(rc);
+        if (hipMemcpy(sys->dict_ids.ptr, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice) != hipSuccess ||
+            hipMemcpy(sys->dict_full.ptr, distinct.data(), sizeof(double) * distinct.size(),
+                      hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup(fail(BDG_EDEVICE, "upload of the block dictionary failed"));
+    }
     *out = sys;
     return BDG_OK;
 }
@@ -1002,6 +1127,9 @@ int bdg_destroy(bdg_system* sys) {
     sys->indices.release();
     sys->blocks.release();
     for (auto& buf : sys->packed) buf.release();
+    for (auto& buf : sys->dict_table) buf.release();
+    sys->dict_ids.release();
+    sys->dict_full.release();
     sys->vec_a.release();
     sys->vec_b.release();
     sys->partial.release();
@@ -1059,17 +1187,11 @@ int bdg_spmv(bdg_system* sys, const double* x, double* y) {
         bdg::fill_zero<<<grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)(n * kCols));
         bdg::planar_from_sitemajor<<<grid, 256, 0, st>>>(host_order.ptr, sys->vec_a.ptr, sys->nb, kCols, 0);
         bdg::StepArgs args{};
-        args.indptr = sys->indptr.ptr;
-        args.indices = sys->indices.ptr;
-        args.blocks = sys->blocks.ptr;
+        if (int rc = matrix_args(sys, plan, &args)) return rc;
         args.cur = sys->vec_a.ptr;
         args.prev = sys->vec_b.ptr;
         args.partial = sys->partial.ptr;
         args.coef = 1.0;
-        args.nb = (int)sys->nb;
-        args.ncols = (int)sys->nb;
-        args.n_tiles = plan.n_tiles;
-        args.max_row_blocks = sys->max_row_blocks;
         plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
         bdg::sitemajor_from_planar<<<grid, 256, 0, st>>>(sys->vec_b.ptr, host_order.ptr, sys->nb, kCols, 0);
         HIP_TRY(hipGetLastError());

@@ -185,6 +185,9 @@ struct StepArgs {
     double2* prev;        // t_{n-1} in, t_{n+1} out (same site, same thread: in place)
     double* partial;      // [gridDim.x][RL * kVec][2]
     const int* tile_order;  // optional permutation of workgroup tiles (nullptr = natural order)
+    const int* dict_ids;    // dictionary form: per stored block, column | table index << 24
+    const void* dict_table; // dictionary form: the distinct blocks, packed for the mode
+    int n_unique;
     double coef;
     int nb;       // block rows owned (computed)
     int ncols;    // block rows of the vector buffers (owned + halo); == nb without slabs
@@ -610,6 +613,147 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
     }
 
     reduce_dots<Mode, RL>(dot, red, a.partial, lane, wave);
+}
+
+// ---------------------------------------------------------- K1, dictionary form
+// Lattice Hamiltonians repeat a handful of distinct blocks (one per kind of site and of
+// bond) millions of times.  When the upload finds few distinct blocks the matrix is kept as
+// a table of those blocks plus one 32-bit word per stored block (column in the low 24 bits,
+// table index in the high 8); the table is copied into LDS once per workgroup and the
+// per-launch matrix stream shrinks from 96..256 B to 4 B per block.  Arithmetic, order of
+// operations and results are those of the other forms (same Mode::mac_row on the same numbers).
+//
+// With the matrix stream gone the launch is bound by the t_n traffic, so this form also trims
+// the gathers: every lane loads the t_n entries of its OWN row once (they are needed for the
+// dot products anyway) and parks them in a wave-private LDS slot; a block whose column is the
+// own row or a row held by a neighbouring lane of the same wave (column = row ± 1 for lattice
+// neighbours along the fastest axis) is served from there instead of from L2.  The test is
+// made per block on the actual column index, so any sparsity pattern stays correct.
+// Row metadata of the next tile is prefetched while the current one computes.
+template <typename Mode, int RL, int MAXB>
+__global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
+    extern __shared__ double2 lds[];
+    constexpr int RW = kWave / RL;
+    constexpr int SPB = Mode::kSlotsPerBlock;
+    constexpr int STRIDE = Mode::kBlockStride;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int s = lane / RL;
+    const int r = lane % RL;
+
+    // LDS: [table: n_unique x STRIDE slots][per wave: 64 lanes x 4 own entries]
+    const double2* table = static_cast<const double2*>(a.dict_table);
+    for (int e = threadIdx.x; e < a.n_unique * SPB; e += kBlockThreads)
+        lds[(e / SPB) * STRIDE + (e % SPB)] = table[e];
+    double2* share = lds + a.n_unique * STRIDE + wave * (kWave * 4);
+    __syncthreads();
+
+    const int xcd = blockIdx.x & 7;
+    const int slot = blockIdx.x >> 3;
+    const int slots = gridDim.x >> 3;
+    const int t_lo = (int)(((int64_t)a.n_tiles * xcd) >> 3);
+    const int t_hi = (int)(((int64_t)a.n_tiles * (xcd + 1)) >> 3);
+    auto first_row = [&](int t) {
+        if (t >= t_hi) return a.nb;
+        const int tile = a.tile_order ? a.tile_order[t] : t;
+        return (tile * kWavesPerBlock + wave) * RW;
+    };
+    // one word per stored block: column in the low 24 bits, table index in the high 8
+    struct RowMeta {
+        int len;
+        unsigned word[MAXB];
+    };
+    auto col_of = [](unsigned w) { return (size_t)(w & 0xFFFFFFu); };
+    auto id_of = [](unsigned w) { return (int)(w >> 24); };
+    auto load_meta = [&](int row0, RowMeta& m) {
+        const int i = row0 + s;
+        int kbeg = 0, kend = 0;
+        if (i < a.nb) {
+            kbeg = a.indptr[i];
+            kend = a.indptr[i + 1];
+        }
+        m.len = kend - kbeg;
+#pragma unroll
+        for (int q = 0; q < MAXB; ++q) m.word[q] = (q < m.len) ? (unsigned)a.dict_ids[kbeg + q] : 0u;
+    };
+
+    double dot[4] = {0.0, 0.0, 0.0, 0.0};
+    int pos = t_lo + slot;
+    int row0 = first_row(pos);
+    RowMeta meta;
+    load_meta(row0, meta);
+    for (; pos < t_hi; pos += slots) {
+        const int row0_n = first_row(pos + slots);
+        RowMeta meta_n;
+        load_meta(row0_n, meta_n);
+
+        const int i = row0 + s;
+        const bool valid = i < a.nb;
+        // own entries of t_n: registers (dot products, diagonal block) and LDS (neighbour lanes)
+        double2 own[4];
+#pragma unroll
+        for (int be = 0; be < 4; ++be)
+            own[be] = valid ? a.cur[vslot(be, (size_t)i, r, a.ncols, RL)] : make_double2(0.0, 0.0);
+#pragma unroll
+        for (int be = 0; be < 4; ++be) share[lane * 4 + be] = own[be];
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+        if (valid) {
+            // rows held by this wave: i - s .. i - s + RW - 1 (those below nb); offset of the
+            // lane that owns column c, or kWave if the column has to come from memory
+            auto source = [&](unsigned w) {
+                const long d = (long)col_of(w) - (long)i;
+                const long ss = (long)s + d;
+                return (ss >= 0 && ss < RW && (long)i + d < a.nb) ? (int)d : (int)kWave;
+            };
+            double2 acc[4], x[4], xn[4];
+#pragma unroll
+            for (int al = 0; al < 4; ++al) acc[al] = make_double2(0.0, 0.0);
+            if (meta.len > 0 && source(meta.word[0]) == kWave) {
+#pragma unroll
+                for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, col_of(meta.word[0]), r, a.ncols, RL)];
+            }
+#pragma unroll
+            for (int q = 0; q < MAXB; ++q) {
+                if (q < meta.len) {
+                    const int src = source(meta.word[q]);
+                    if (src == kWave) {
+#pragma unroll
+                        for (int be = 0; be < 4; ++be) x[be] = xn[be];
+                    } else {
+#pragma unroll
+                        for (int be = 0; be < 4; ++be) x[be] = share[(lane + src * RL) * 4 + be];
+                    }
+                    if (q + 1 < MAXB && q + 1 < meta.len && source(meta.word[q + 1 < MAXB ? q + 1 : 0]) == kWave) {
+#pragma unroll
+                        for (int be = 0; be < 4; ++be)
+                            xn[be] = a.cur[vslot(be, col_of(meta.word[q + 1 < MAXB ? q + 1 : 0]), r, a.ncols, RL)];
+                    }
+                    Mode::mac_row(acc, lds + id_of(meta.word[q]) * STRIDE, x);
+                }
+            }
+#pragma unroll
+            for (int al = 0; al < 4; ++al) {
+                const size_t slot_own = vslot(al, (size_t)i, r, a.ncols, RL);
+                const double2 p = a.prev[slot_own];
+                double2 nx;
+                nx.x = fma(a.coef, acc[al].x, -p.x);
+                nx.y = fma(a.coef, acc[al].y, -p.y);
+                a.prev[slot_own] = nx;
+                Mode::dots(dot, own[al], nx);
+            }
+        }
+        // the next tile overwrites `share`; same-wave LDS ops are ordered
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        row0 = row0_n;
+        meta = meta_n;
+    }
+
+    __syncthreads();  // table / share reads finished: the reduction reuses the front of the LDS
+    reduce_dots<Mode, RL>(dot, reinterpret_cast<double*>(lds), a.partial, lane, wave);
 }
 
 // Device-side re-packing of the uploaded complex 4x4 blocks for the other storage modes.

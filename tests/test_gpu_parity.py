@@ -16,6 +16,16 @@ from oracle import cheb_ref, dense_ref
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True, params=["dictionary", "streamed"])
+def block_storage(request, monkeypatch):
+    """Every test runs twice: with the block dictionary (used whenever a matrix has few distinct
+    blocks, i.e. for most lattice systems here) and with it disabled, so that the streamed
+    (pipelined / generic) kernels keep their coverage."""
+    if request.param == "streamed":
+        monkeypatch.setenv("BODGE_AMD_DICT", "0")
+    return request.param
+
+
 @pytest.fixture(scope="module")
 def solver_cls(hip_library):
     from bodge_amd.solver import DeviceSolver
@@ -188,6 +198,32 @@ def test_particle_hole_packed_storage_is_exact(api, solver_cls, monkeypatch, nam
         full = dev.dots_random(scale, 16, n_vectors, seed=3, kind=kind)
         assert dev.perf()["ph_packed"] == 0
     assert np.array_equal(packed[0], full[0]) and np.array_equal(packed[1], full[1])
+
+
+def test_dictionary_form_matches_streamed_form(api, solver_cls, monkeypatch, block_storage):
+    """Few distinct blocks -> table in LDS + 8 B per stored block; must agree with the streamed
+    kernels to round-off (same products per row; only the cross-workgroup sum order differs)."""
+    if block_storage == "streamed":
+        pytest.skip("compares both forms itself")
+    for name, n_vectors, kind in [("swave20", 8, cheb_ref.VEC_RADEMACHER), ("dwave8", 16, cheb_ref.VEC_RADEMACHER),
+                                  ("chain128", 5, cheb_ref.VEC_Z4), ("snf", 64, cheb_ref.VEC_Z4)]:
+        system = _build(api, name)
+        scale = cheb_ref.spectral_bound(system.matrix("bsr"))
+        with solver_cls.from_hamiltonian(system) as dev:
+            table = dev.dots_random(scale, 16, n_vectors, seed=3, kind=kind)
+            n_unique = dev.perf()["dict_blocks"]
+            assert 0 < n_unique < 64, name
+            monkeypatch.setenv("BODGE_AMD_DICT", "0")
+            streamed = dev.dots_random(scale, 16, n_vectors, seed=3, kind=kind)
+            assert dev.perf()["dict_blocks"] == 0
+            monkeypatch.delenv("BODGE_AMD_DICT")
+        assert np.allclose(table[0], streamed[0], rtol=1e-13, atol=0)
+        assert np.allclose(table[1], streamed[1], rtol=1e-12, atol=1e-12 * system.shape[0])
+    # every block distinct: the dictionary is not built and the streamed kernels run
+    system = _build(api, "random357")
+    with solver_cls.from_hamiltonian(system) as dev:
+        dev.dots_random(1.0 + cheb_ref.spectral_bound(system.matrix("bsr")), 2, 8, kind=cheb_ref.VEC_Z4)
+        assert dev.perf()["dict_blocks"] == 0 and dev.perf()["pipelined"] == 1
 
 
 def test_matrix_without_particle_hole_form_uses_full_storage(api, solver_cls):
