@@ -14,6 +14,7 @@
 #include <rocsolver/rocsolver.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
@@ -94,6 +95,7 @@ struct bdg_system {
     int device = 0;
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::vector<hipEvent_t> ev_pool;  // extra (start, stop) pairs: one per reduction chunk of a call
     int64_t nb = 0, nnzb = 0;
     int64_t ncols = 0;       // block rows of the vector buffers: nb owned + halo
     int64_t row_offset = 0;  // global block row of local row 0 (slab mode)
@@ -117,6 +119,8 @@ struct bdg_system {
     DeviceBuffer<double2> dict_table[4];  // packed per storage mode, built on first use
     DeviceBuffer<double2> vec_a, vec_b;
     DeviceBuffer<double> partial, dots;
+    double* host_dots = nullptr;  // pinned staging for the dot products (sized like `dots`)
+    size_t host_dots_count = 0;
     DeviceBuffer<int64_t> rows;
     // lattice geometry hint (rows = z + lz*(y + ly*x)) and the cached strip-major tile order
     int shape[3] = {0, 0, 0};
@@ -589,7 +593,7 @@ struct Batch {
     double2* cur = nullptr;
     double2* prev = nullptr;
     float kernel_ms = 0.f;
-    bool timing_open = false;
+    int n_chunks = 0;
 
     int begin(bdg_system* system, double scale_in, int steps, int active, const StartSpec& start,
               int force_real /* -1 auto, 0 complex, 1 real */) {
@@ -621,11 +625,21 @@ struct Batch {
         if (int rc = sys->vec_a.reserve(vec_count)) return rc;
         if (int rc = sys->vec_b.reserve(vec_count)) return rc;
         width = (size_t)2 * rv;
-        // keep the partial buffer below 256 MiB by reducing in chunks of steps
+        // Dot partials are reduced every `chunk` launches.  Buffer sizes do not depend on
+        // n_steps (up to 1024), so a short warm-up call leaves nothing to allocate later.
         per_step = (size_t)plan.grid * width;
-        chunk = (int)std::max<size_t>(1, std::min<size_t>(n_steps, (32u << 20) / per_step));
-        if (int rc = sys->partial.reserve((size_t)chunk * per_step)) return rc;
-        if (int rc = sys->dots.reserve((size_t)n_steps * width)) return rc;
+        constexpr int kChunk = 64;
+        chunk = std::min(n_steps, kChunk);
+        if (int rc = sys->partial.reserve((size_t)2 * kChunk * per_step)) return rc;
+        const size_t dots_count = (size_t)std::max(n_steps, 1024) * width;
+        if (int rc = sys->dots.reserve(dots_count)) return rc;
+        if (sys->host_dots_count < dots_count) {
+            if (sys->host_dots) (void)hipHostFree(sys->host_dots);
+            sys->host_dots = nullptr;
+            sys->host_dots_count = 0;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sys->host_dots), dots_count * sizeof(double), 0));
+            sys->host_dots_count = dots_count;
+        }
         if (sys->send_total > 0)
             if (int rc = sys->send_buf.reserve((size_t)sys->send_total * 4 * rl)) return rc;
         if (sys->recv_total > 0)
@@ -665,7 +679,7 @@ struct Batch {
         cur = sys->vec_a.ptr;
         prev = sys->vec_b.ptr;
         kernel_ms = 0.f;
-        timing_open = false;
+        n_chunks = 0;
         return BDG_OK;
     }
 
@@ -719,27 +733,28 @@ struct Batch {
         HIP_TRY(hipSetDevice(sys->device));
         hipStream_t st = sys->stream;
         const int in_chunk = n % chunk;
-        if (in_chunk == 0) {
-            HIP_TRY(hipEventRecord(sys->ev_start, st));
-            timing_open = true;
+        const int chunk_id = n / chunk;
+        // one event pair per chunk, read back in finish(): the host never waits inside the loop
+        while ((int)sys->ev_pool.size() < 2 * (chunk_id + 1)) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreate(&ev));
+            sys->ev_pool.push_back(ev);
         }
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id], st));
         args.cur = cur;
         args.prev = prev;
         args.coef = (n == 0 ? 1.0 : 2.0) / scale;
-        args.partial = sys->partial.ptr + (size_t)in_chunk * per_step;
+        args.partial = sys->partial.ptr + ((size_t)(chunk_id & 1) * chunk + in_chunk) * per_step;
         plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
         std::swap(cur, prev);
         if (in_chunk == chunk - 1 || n == n_steps - 1) {
             const int s0 = n - in_chunk;
-            HIP_TRY(hipEventRecord(sys->ev_stop, st));
-            bdg::reduce_partials<<<in_chunk + 1, (unsigned)std::max<size_t>(64, width), 0, st>>>(
-                sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, plan.grid, (int)width);
+            HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id + 1], st));
+            bdg::reduce_partials<<<in_chunk + 1, 256, 0, st>>>(
+                sys->partial.ptr + (size_t)(chunk_id & 1) * chunk * per_step,
+                sys->dots.ptr + (size_t)s0 * width, plan.grid, (int)width);
             HIP_TRY(hipGetLastError());
-            HIP_TRY(hipEventSynchronize(sys->ev_stop));
-            float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, sys->ev_start, sys->ev_stop));
-            kernel_ms += ms;
-            timing_open = false;
+            n_chunks = chunk_id + 1;
         }
         return BDG_OK;
     }
@@ -748,10 +763,15 @@ struct Batch {
     // accumulate = true adds to what is there (summing the slabs of a group).
     int finish(double* d_out, double* e_out, int ld, int col0, bool accumulate, bool first_batch) {
         HIP_TRY(hipSetDevice(sys->device));
-        std::vector<double> host((size_t)n_steps * width);
-        HIP_TRY(hipMemcpyAsync(host.data(), sys->dots.ptr, host.size() * sizeof(double),
+        double* host = sys->host_dots;  // pinned: a pageable target costs ~8 ms on its first use
+        HIP_TRY(hipMemcpyAsync(host, sys->dots.ptr, (size_t)n_steps * width * sizeof(double),
                                hipMemcpyDeviceToHost, sys->stream));
         HIP_TRY(hipStreamSynchronize(sys->stream));
+        for (int c = 0; c < n_chunks; ++c) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, sys->ev_pool[2 * c], sys->ev_pool[2 * c + 1]));
+            kernel_ms += ms;
+        }
         for (int n = 0; n < n_steps; ++n)
             for (int r = 0; r < n_active; ++r) {
                 double& d = d_out[(size_t)n * ld + col0 + r];
@@ -799,16 +819,25 @@ StartSpec batch_start(const StartSpec& start, int col) {
 int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, StartSpec start,
                    double* d_out, double* e_out) {
     if (int rc = check_recurrence_args(sys, scale, n_steps, n_vectors, d_out, e_out)) return rc;
+    const bool trace = getenv("BODGE_AMD_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     for (int col = 0; col < n_vectors; col += 64) {
         Batch batch;
+        const auto t0 = now();
         if (int rc = batch.begin(sys, scale, n_steps, std::min(64, n_vectors - col),
                                  batch_start(start, col), -1))
             return rc;
+        const auto t1 = now();
         for (int n = 0; n < n_steps; ++n) {
             if (int rc = batch.exchange_rccl()) return rc;
             if (int rc = batch.step(n)) return rc;
         }
+        const auto t2 = now();
         if (int rc = batch.finish(d_out, e_out, n_vectors, col, false, col == 0)) return rc;
+        if (trace)
+            fprintf(stderr, "[bdg] begin %.3f ms, steps %.3f ms (kernels %.3f), finish %.3f ms\n", ms(t0, t1),
+                    ms(t1, t2), batch.kernel_ms, ms(t2, now()));
     }
     return BDG_OK;
 }
@@ -1005,6 +1034,20 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
           hipMemcpy(sys->blocks.ptr, data, sizeof(double2) * 16 * nnzb, hipMemcpyHostToDevice) !=
               hipSuccess)))
         return cleanup(fail(BDG_EDEVICE, "upload of the BSR arrays failed"));
+    // First use of the device-to-host copy path for more than a few KB costs ~7 ms
+    // (measured in the first 256-launch call).  Take it here: allocate the dot-product
+    // buffers now and pull them once.
+    {
+        const size_t dots_count = (size_t)1024 * 128;  // 1024 launches x 64 vectors x {d, e}
+        if (int rc = sys->dots.reserve(dots_count)) return cleanup(rc);
+        if (hipHostMalloc(reinterpret_cast<void**>(&sys->host_dots), dots_count * sizeof(double), 0) != hipSuccess)
+            return cleanup(fail(BDG_ENOMEM, "pinned host allocation failed"));
+        sys->host_dots_count = dots_count;
+        if (hipMemcpyAsync(sys->host_dots, sys->dots.ptr, dots_count * sizeof(double), hipMemcpyDeviceToHost,
+                           sys->stream) != hipSuccess ||
+            hipStreamSynchronize(sys->stream) != hipSuccess)
+            return cleanup(fail(BDG_EDEVICE, "device-to-host warm-up copy failed"));
+    }
     if (!ids.empty()) {
         sys->n_unique = (int)(distinct.size() / 32);
         if (int rc = sys->dict_ids.reserve(ids.size())) return cleanup(rc);
@@ -1135,12 +1178,15 @@ int bdg_destroy(bdg_system* sys) {
     sys->partial.release();
     sys->dots.release();
     sys->rows.release();
+    if (sys->host_dots) (void)hipHostFree(sys->host_dots);
+    sys->host_dots = nullptr;
     sys->tile_order.release();
     sys->send_rows.release();
     sys->send_buf.release();
     sys->recv_buf.release();
     if (sys->ev_start) (void)hipEventDestroy(sys->ev_start);
     if (sys->ev_stop) (void)hipEventDestroy(sys->ev_stop);
+    for (hipEvent_t ev : sys->ev_pool) (void)hipEventDestroy(ev);
     if (sys->stream) (void)hipStreamDestroy(sys->stream);
     delete sys;
     return BDG_OK;

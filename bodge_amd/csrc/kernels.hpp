@@ -779,16 +779,29 @@ __global__ void pack_blocks(const double2* __restrict__ blocks, void* __restrict
 }
 
 // ------------------------------------------------------------------------ K2
-// out[step][c] = Σ_g partial[step][g][c] in ascending g, c < width (= 2*RL).
-__global__ void reduce_partials(const double* __restrict__ partial, double* __restrict__ out,
-                                int groups, int width) {
+// out[step][c] = Σ_g partial[step][g][c], c < width (<= 128).  One block of 256 threads per
+// step: thread t sums groups t/width, t/width + 256/width, ... for column t%width, then the
+// 256/width partial sums of a column are added in ascending order.  The summation tree is
+// fixed by (groups, width) alone, so results are bit-reproducible run to run.
+__global__ __launch_bounds__(256) void reduce_partials(const double* __restrict__ partial,
+                                                       double* __restrict__ out, int groups, int width) {
+    __shared__ double scratch[256];
     const int step = blockIdx.x;
-    const int c = threadIdx.x;
-    if (c >= width) return;
-    const double* p = partial + (size_t)step * groups * width + c;
+    const int c = threadIdx.x % width;
+    const int lane_group = threadIdx.x / width;
+    const int n_lane_groups = 256 / width;
     double tot = 0.0;
-    for (int g = 0; g < groups; ++g) tot += p[(size_t)g * width];
-    out[(size_t)step * width + c] = tot;
+    if (lane_group < n_lane_groups) {
+        const double* p = partial + (size_t)step * groups * width + c;
+        for (int g = lane_group; g < groups; g += n_lane_groups) tot += p[(size_t)g * width];
+    }
+    scratch[threadIdx.x] = tot;
+    __syncthreads();
+    if ((int)threadIdx.x < width) {
+        double sum = 0.0;
+        for (int k = 0; k < n_lane_groups; ++k) sum += scratch[k * width + threadIdx.x];
+        out[(size_t)step * width + threadIdx.x] = sum;
+    }
 }
 
 // ------------------------------------------------------------------------ K5
