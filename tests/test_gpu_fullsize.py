@@ -1,0 +1,128 @@
+"""Parity at BASELINE.json's full sizes, where no CPU reference finishes in test time.
+
+The CPU oracle needs ~0.6 s per block-step at 10^6 sites, so here it checks a few steps of a
+few vectors directly, and the rest is covered by properties that do not depend on size:
+exact norms of the start vectors, additivity over start vectors, equality of the kernel forms
+(dictionary / streamed, real / complex arithmetic, packed / full blocks, strip order), bit
+reproducibility, and the closed-form free energy of a diagonal Hamiltonian.
+"""
+
+import os
+
+import numpy as np
+import pytest
+
+from oracle import cheb_ref
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big(api, hip_library):
+    """configs[2]: CubicLattice((1000,1000,1)), s-wave + Zeeman, open boundaries (4M x 4M)."""
+    from bodge_amd import chebyshev
+    from bodge_amd.solver import DeviceSolver
+
+    lattice = api.CubicLattice((1000, 1000, 1))
+    system = api.Hamiltonian(lattice)
+    with system as (H, Δ):
+        H.set_sites(3.0 * api.σ0 - 0.05 * api.σ3)
+        Δ.set_sites(-0.1 * api.jσ2)
+        H.set_bonds(-1.0 * api.σ0)
+    indptr, indices, data = system.bsr_arrays()
+    assert indices.size == 4_996_000  # 5 L^2 - 4 L
+    scale = chebyshev.spectral_bound(indptr, data)
+    solver = DeviceSolver(indptr, indices, data)
+    solver.set_lattice_shape(lattice.shape)
+    yield system, solver, scale
+    solver.close()
+
+
+def _with_env(solver, env, *args, **kwargs):
+    os.environ.update(env)
+    try:
+        out = solver.dots_random(*args, **kwargs)
+        return out, solver.perf()
+    finally:
+        for k in env:
+            del os.environ[k]
+
+
+def test_first_steps_match_oracle_at_full_size(big):
+    system, solver, scale = big
+    bsr = system.matrix("bsr")
+    steps, vectors = 3, 2
+    ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(bsr.shape[0], 1, range(vectors)))
+    got = solver.dots_random(scale, steps, vectors, seed=1)
+    assert np.allclose(got[0], ref[0], rtol=1e-13) and np.allclose(got[1], ref[1], rtol=1e-12, atol=1e-6)
+
+
+def test_size_independent_properties(big):
+    system, solver, scale = big
+    n = system.shape[0]
+    steps = 24
+    (d, e), perf = _with_env(solver, {}, scale, steps, 8, seed=0)
+    assert perf["dict_blocks"] > 0 and perf["real_arithmetic"] == 1 and perf["ph_packed"] == 1
+    # |v|^2 = 4N exactly for ±1 vectors, and <t_n|t_n> <= |v|^2 because |T_n| <= 1 on the spectrum
+    assert np.array_equal(d[0], np.full(8, float(n)))
+    assert np.all(d <= n * (1 + 1e-12)) and np.all(d > 0)
+    # bit reproducible
+    (d2, e2), _ = _with_env(solver, {}, scale, steps, 8, seed=0)
+    assert np.array_equal(d, d2) and np.array_equal(e, e2)
+    # additive over start vectors: columns do not interact (any batch split gives the same columns)
+    (da, ea), _ = _with_env(solver, {}, scale, steps, 3, seed=0, first_id=0)
+    (db, eb), _ = _with_env(solver, {}, scale, steps, 5, seed=0, first_id=3)
+    assert np.allclose(np.hstack([da, db]), d, rtol=1e-13) and np.allclose(np.hstack([ea, eb]), e, rtol=1e-12, atol=1e-6)
+    # every kernel form computes the same numbers
+    for env, check in [
+        ({"BODGE_AMD_DICT": "0"}, lambda p: p["dict_blocks"] == 0 and p["pipelined"] == 1),
+        ({"BODGE_AMD_DICT": "0", "BODGE_AMD_PH": "0"}, lambda p: p["ph_packed"] == 0),
+        ({"BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"}, lambda p: p["real_arithmetic"] == 0),
+        ({"BODGE_AMD_DICT": "0", "BODGE_AMD_KERNEL": "generic"}, lambda p: p["pipelined"] == 0),
+        ({"BODGE_AMD_L2_BUDGET": "65536"}, lambda p: 0 < p["strip_rows"] < 1000),
+    ]:
+        (dx, ex), perf = _with_env(solver, env, scale, steps, 8, seed=0)
+        assert check(perf), (env, perf)
+        assert np.allclose(dx, d, rtol=1e-13), env
+        assert np.allclose(ex, e, rtol=1e-12, atol=1e-6), env
+
+
+def test_stochastic_free_energy_is_stable_and_in_range(big, api):
+    """512-moment stochastic-trace F of configs[2]: two disjoint sets of vectors must agree to the
+    stochastic error, and F/N must sit near the 20x20 reference value per site."""
+    system, solver, scale = big
+    from bodge_amd import chebyshev
+
+    n_sites = system.lattice.size
+    f = []
+    for first in (0, 8):
+        mu = solver.moments_random(scale, 512, 8, seed=0, first_id=first) / 8
+        f.append(chebyshev.free_energy_series(mu, scale, 0.5) / n_sites)
+    assert abs(f[0] - f[1]) < 2e-4  # ~ sigma / sqrt(R * 4N)
+    assert -3.20 < f[0] < -3.10     # golden 20x20+Zeeman: F(0.5)/400 = -3.1433 (finite-size edges)
+
+
+def test_diagonal_hamiltonian_has_closed_form_free_energy(api, hip_library):
+    """No hopping: every site carries the same 4x4 block with eigenvalues ±(sqrt(μ²+Δ²) ± m), so F
+    is known in closed form at any size.  The four unit vectors of one site give that site's
+    trace exactly; the stochastic estimate over the whole lattice must agree to its noise level."""
+    from bodge_amd import chebyshev
+
+    lattice = api.CubicLattice((300, 300, 1))
+    system = api.Hamiltonian(lattice)
+    mu_, gap, m, temperature = 1.3, 0.4, 0.2, 0.35
+    with system as (H, Δ):
+        H.set_sites(mu_ * api.σ0 - m * api.σ3)
+        Δ.set_sites(-gap * api.jσ2)
+    eps = np.array([np.hypot(mu_, gap) + m, np.hypot(mu_, gap) - m])
+    exact = lattice.size * np.sum(-eps / 2 - temperature * np.log1p(np.exp(-eps / temperature)))
+
+    solver = system._solver()
+    indptr, _, data = system.bsr_arrays()
+    scale = chebyshev.spectral_bound(indptr, data)
+    site = lattice[(150, 7, 0)]
+    mu_site = solver.moments_unit(scale, 256, np.arange(4 * site, 4 * site + 4)).sum(axis=1)
+    assert np.isclose(lattice.size * chebyshev.free_energy_series(mu_site, scale, temperature), exact, rtol=1e-12)
+
+    estimate = system.free_energy(temperature, method="chebyshev", trace="stochastic", vectors=8, moments=256)
+    assert np.isclose(estimate, exact, rtol=5e-3)
