@@ -78,6 +78,12 @@ def spectral_bound(bsr: sp.bsr_matrix, pad: float = 1.01) -> float:
 
 
 # ------------------------------------------------------------------------ moments
+def _column_dots(a: np.ndarray, b: np.ndarray) -> np.ndarray:
+    """Re <a_r|b_r> per column with pairwise (not sequential) summation: at 4·10^6 rows a
+    running sum loses ~1e-11 relative, which is the size of the tolerances used here."""
+    return np.sum(np.ascontiguousarray((a.conj() * b).real.T), axis=1)
+
+
 def recurrence_dots(bsr, scale: float, n_moments: int, start: np.ndarray):
     """Run M/2 recurrence steps on the columns of `start`; return (d, e) of shape (M/2, R)."""
     if n_moments % 2 or n_moments < 2:
@@ -87,12 +93,12 @@ def recurrence_dots(bsr, scale: float, n_moments: int, start: np.ndarray):
     t_cur = (bsr @ t_prev) * (1.0 / scale)
     d = np.empty((steps, t_prev.shape[1]))
     e = np.empty_like(d)
-    d[0] = np.einsum("ir,ir->r", t_prev.conj(), t_prev).real
-    e[0] = np.einsum("ir,ir->r", t_cur.conj(), t_prev).real
+    d[0] = _column_dots(t_prev, t_prev)
+    e[0] = _column_dots(t_cur, t_prev)
     for n in range(1, steps):
         t_next = (bsr @ t_cur) * (2.0 / scale) - t_prev
-        d[n] = np.einsum("ir,ir->r", t_cur.conj(), t_cur).real
-        e[n] = np.einsum("ir,ir->r", t_next.conj(), t_cur).real
+        d[n] = _column_dots(t_cur, t_cur)
+        e[n] = _column_dots(t_next, t_cur)
         t_prev, t_cur = t_cur, t_next
     return d, e
 

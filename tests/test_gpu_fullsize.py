@@ -54,7 +54,8 @@ def test_first_steps_match_oracle_at_full_size(big):
     steps, vectors = 3, 2
     ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(bsr.shape[0], 1, range(vectors)))
     got = solver.dots_random(scale, steps, vectors, seed=1)
-    assert np.allclose(got[0], ref[0], rtol=1e-13) and np.allclose(got[1], ref[1], rtol=1e-12, atol=1e-6)
+    mu0 = bsr.shape[0]
+    assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * mu0) and np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * mu0)
 
 
 def test_size_independent_properties(big):
