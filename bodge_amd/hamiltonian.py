@@ -174,6 +174,17 @@ class Hamiltonian:
             worst = max(worst, float(np.abs(diff).max()))
         return worst
 
+    def has_symmetric_spectrum(self, tol: float = 0.0) -> bool:
+        """True if H = -τx H* τx, i.e. every block is [[A, B], [-B*, -A*]]: the spectrum is then
+        symmetric about zero.  The assembly guarantees the diagonal part (ref :106-108); the
+        off-diagonal part holds when the pairing obeys fermionic antisymmetry Δ_ij = -Δ_ji^T
+        (singlet on-site terms, odd-parity triplet bond terms).  The Chebyshev free energy
+        relies on it; the dense path and the LDOS do not."""
+        data = self._data
+        a = np.abs(data[:, 2:4, 2:4] + data[:, 0:2, 0:2].conj()).max(initial=0.0)
+        b = np.abs(data[:, 2:4, 0:2] + data[:, 0:2, 2:4].conj()).max(initial=0.0)
+        return bool(max(a, b) <= tol)
+
     # ------------------------------------------------------------------ export
     def matrix(self, format: str = "dense"):
         if format == "bsr":

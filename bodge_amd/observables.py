@@ -64,6 +64,12 @@ def free_energy(
     dim = system.shape[0]
     if method == "auto":
         method = "dense" if dim <= DENSE_AUTO_LIMIT else "chebyshev"
+    if method == "chebyshev" and not system.has_symmetric_spectrum(1e-12):
+        # Σ_{ε>0} g(ε) equals a trace of a smooth function only for a ±-symmetric spectrum
+        raise RuntimeError(
+            "The Chebyshev free energy needs a particle-hole symmetric Hamiltonian "
+            "(pairing terms with Δ_ij = -Δ_ji^T); use method='dense' for this matrix."
+        )
 
     if method == "dense":
         eps, _ = system._solver().eigh(vectors=False)

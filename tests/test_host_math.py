@@ -1,0 +1,111 @@
+"""Host-side scalar work of the product (`bodge_amd.chebyshev`, no GPU, no oracle import for the
+thing under test): fed with *exact* moments built from a dense spectrum, the series must return
+the reference observables.  Exact moments: μ_m = Σ_k T_m(ε_k / a) = Σ_k cos(m arccos(ε_k / a))."""
+
+import numpy as np
+import pytest
+
+import systems
+from bodge_amd import chebyshev
+
+
+def _spectrum(api, name):
+    spec = systems.CATALOG[name]
+    system = spec["build"](api, **spec["kwargs"])
+    dense = np.asarray(system.matrix("dense"))
+    vals, vecs = np.linalg.eigh(dense)
+    indptr, _, data = system.bsr_arrays()
+    return system, vals, vecs, chebyshev.spectral_bound(indptr, data)
+
+
+def _trace_moments(vals, scale, n):
+    theta = np.arccos(vals / scale)
+    return np.cos(np.arange(n)[:, None] * theta[None, :]).sum(axis=1)
+
+
+@pytest.mark.parametrize("name,temperature", [("barrier", 0.1), ("complex235", 1.0), ("complex235", 0.01),
+                                              ("snf", 0.1), ("chain128", 0.01), ("swave20_zeeman", 0.1)])
+def test_free_energy_series_from_exact_moments(api, golden, name, temperature):
+    _, vals, _, scale = _spectrum(api, name)
+    assert scale > np.abs(vals).max()
+    moments = chebyshev.moments_for_free_energy(scale, temperature)
+    value = chebyshev.free_energy_series(_trace_moments(vals, scale, moments), scale, temperature)
+    assert np.isclose(value, golden.free_energy(name, temperature), rtol=1e-11, atol=0)
+
+
+def test_default_moment_rule_is_sufficient(api, golden):
+    _, vals, _, scale = _spectrum(api, "snf")
+    for temperature in (0.1, 1.0):
+        m = chebyshev.moments_for_free_energy(scale, temperature)
+        assert m % 2 == 0 and 32 <= m <= 4096
+        value = chebyshev.free_energy_series(_trace_moments(vals, scale, m), scale, temperature)
+        assert np.isclose(value, golden.free_energy("snf", temperature), rtol=1e-10, atol=0)
+    assert chebyshev.moments_for_free_energy(scale, 0.0) == 4096
+
+
+def test_zero_temperature_series_converges_algebraically(api, golden):
+    """f = -|ε|/4 is not analytic: the error falls like 1/M (no 1e-10 at T = 0 from Chebyshev)."""
+    _, vals, _, scale = _spectrum(api, "barrier")
+    exact = -0.5 * vals[vals > 0].sum()
+    errs = [abs(chebyshev.free_energy_series(_trace_moments(vals, scale, m), scale, 0.0) / exact - 1)
+            for m in (256, 1024, 4096)]
+    assert errs[0] > errs[1] > errs[2] and errs[2] < 1e-4
+    damped = chebyshev.free_energy_series(_trace_moments(vals, scale, 1024), scale, 0.0, damping=True)
+    assert abs(damped / exact - 1) < 1e-2
+
+
+def test_resolvent_series_from_exact_moments(api, golden):
+    system, vals, vecs, scale = _spectrum(api, "ldos16")
+    site, energies = systems.CATALOG["ldos16"]["ldos"][0]
+    i = system.lattice[site]
+    eps = np.unique(np.abs(np.array(energies, dtype=float)))
+    gam = np.gradient(eps)
+    m = chebyshev.moments_for_resolvent(scale, gam.min())
+    theta = np.arccos(vals / scale)
+    cosines = np.cos(np.arange(m)[:, None] * theta[None, :])
+    rho = {}
+    for e, g in zip(eps, gam):
+        diag = []
+        for a in range(4):
+            weights = np.abs(vecs[4 * i + a, :]) ** 2
+            diag.append(chebyshev.resolvent_series(cosines @ weights, scale, e + 1j * g))
+        rho[+e] = -np.imag(diag[0] + diag[1]) / np.pi
+        rho[-e] = -np.imag(diag[2] + diag[3]) / np.pi
+    got = np.array([rho[e] for e in np.array(energies, dtype=float)])
+    assert np.allclose(got, golden.ldos("ldos16", 0), rtol=1e-10, atol=1e-13)
+
+
+def test_dots_to_moments_and_coefficients():
+    rng = np.random.default_rng(0)
+    d, e = rng.random((6, 3)), rng.random((6, 3))
+    mu = chebyshev.dots_to_moments(d, e)
+    assert mu.shape == (12, 3)
+    assert np.array_equal(mu[0], d[0]) and np.array_equal(mu[1], e[0])
+    assert np.allclose(mu[6], 2 * d[3] - d[0]) and np.allclose(mu[7], 2 * e[3] - e[0])
+    # coefficients of a polynomial are recovered exactly: 3 T_0 - 2 T_2 + 0.5 T_5
+    coeff = chebyshev.chebyshev_coefficients(lambda x: 3 - 2 * (2 * x**2 - 1) + 0.5 * (16 * x**5 - 20 * x**3 + 5 * x), 8)
+    assert np.allclose(coeff, [3, 0, -2, 0, 0, 0.5, 0, 0], atol=1e-14)
+    kernel = chebyshev.jackson_kernel(64)
+    assert np.isclose(kernel[0], 1.0) and np.all(np.diff(kernel) < 0) and kernel[-1] > 0
+
+
+def test_spectral_bound_on_index_arrays(api, golden):
+    for name in ("swave20", "random357", "dwave8", "complex235"):
+        spec = systems.CATALOG[name]
+        indptr, _, data = spec["build"](api, **spec["kwargs"]).bsr_arrays()
+        bound = chebyshev.spectral_bound(indptr, data)
+        assert golden.values[name]["e_max"] < bound < 2.5 * golden.values[name]["e_max"]
+    assert chebyshev.spectral_bound(np.array([0, 0]), np.zeros((0, 4, 4))) == 1.0
+
+
+def test_trace_form_needs_a_symmetric_spectrum(api, golden):
+    """The random test matrix has on-site triplet pairing (Δ_ii ≠ -Δ_ii^T): Hermitian, but its
+    spectrum is not ±-symmetric, so Σ_{ε>0} g(ε) is not the trace of the even function f."""
+    system, vals, _, scale = _spectrum(api, "random357")
+    assert not system.has_symmetric_spectrum(1e-12)
+    assert not np.allclose(np.sort(vals), np.sort(-vals), atol=1e-8)
+    with pytest.raises(RuntimeError, match="particle-hole"):
+        system.free_energy(0.5, method="chebyshev")
+    for name in ("swave20", "complex235", "dwave8", "pwave31", "chain128"):
+        spec = systems.CATALOG[name]
+        assert spec["build"](api, **spec["kwargs"]).has_symmetric_spectrum(1e-12), name
