@@ -189,6 +189,10 @@ struct StepArgs {
     const void* dict_table; // dictionary form: the distinct blocks, packed for the mode
     int n_unique;
     double coef;
+    // optional per-column scalars (Lanczos): t_next[col] = col_coef[col] * (H t_cur)[col]
+    //                                                    - col_pscale[col] * t_prev[col]
+    const double* col_coef;
+    const double* col_pscale;
     int nb;       // block rows owned (computed)
     int ncols;    // block rows of the vector buffers (owned + halo); == nb without slabs
     int n_tiles;  // workgroup tiles of 4 * (64/RL) block rows
@@ -200,6 +204,24 @@ struct StepArgs {
 // (RealMode, used when imag(H) == 0 and the start vectors are real: every t_n
 // is then real and half the bytes of both the matrix and the vectors vanish).
 // Memory access structure is the same in both: 16 B per lane everywhere.
+// Per-lane scalars of the update t_next = c * (H t_cur) - s * t_prev, one pair per payload
+// component: a complex payload belongs to one column, a real payload to two.
+struct LaneScalars {
+    double2 c, s;
+};
+template <int PER_LANE>
+__device__ inline LaneScalars lane_scalars(double coef, const double* col_coef, const double* col_pscale, int r) {
+    LaneScalars out;
+    out.c = make_double2(coef, coef);
+    out.s = make_double2(1.0, 1.0);
+    if (col_coef) {
+        const int c0 = PER_LANE * r, c1 = PER_LANE * r + (PER_LANE - 1);
+        out.c = make_double2(col_coef[c0], col_coef[c1]);
+        out.s = make_double2(col_pscale[c0], col_pscale[c1]);
+    }
+    return out;
+}
+
 struct ComplexMode {
     static constexpr int kVec = 1;          // vectors per lane
     static constexpr int kSlotsPerBlock = 16;  // 16-byte staging slots holding one 4x4 block
@@ -358,6 +380,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
     const int wave = threadIdx.x / kWave;
     const int s = lane / RL;
     const int r = lane % RL;
+    const LaneScalars ls = lane_scalars<Mode::kVec>(a.coef, a.col_coef, a.col_pscale, r);
     const int region = RW * a.max_row_blocks * STRIDE;
     double2* stage = lds + wave * region;
     const double2* all_blocks = static_cast<const double2*>(a.blocks);
@@ -431,8 +454,8 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
                 const double2 p = a.prev[own];
                 const double2 c = a.cur[own];
                 double2 nx;
-                nx.x = fma(a.coef, acc[al].x, -p.x);
-                nx.y = fma(a.coef, acc[al].y, -p.y);
+                nx.x = fma(ls.c.x, acc[al].x, -(ls.s.x * p.x));
+                nx.y = fma(ls.c.y, acc[al].y, -(ls.s.y * p.y));
                 a.prev[own] = nx;
                 Mode::dots(dot, c, nx);
             }
@@ -475,6 +498,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int s = lane / RL;
     const int r = lane % RL;
+    const LaneScalars ls = lane_scalars<Mode::kVec>(a.coef, a.col_coef, a.col_pscale, r);
     double2* stage = lds + wave * (NBLK * STRIDE);
     const double2* all_blocks = static_cast<const double2*>(a.blocks);
 
@@ -590,8 +614,8 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
                 const double2 p = a.prev[own];
                 const double2 c = a.cur[own];
                 double2 nx;
-                nx.x = fma(a.coef, acc[al].x, -p.x);
-                nx.y = fma(a.coef, acc[al].y, -p.y);
+                nx.x = fma(ls.c.x, acc[al].x, -(ls.s.x * p.x));
+                nx.y = fma(ls.c.y, acc[al].y, -(ls.s.y * p.y));
                 a.prev[own] = nx;
                 Mode::dots(dot, c, nx);
             }
@@ -640,6 +664,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int s = lane / RL;
     const int r = lane % RL;
+    const LaneScalars ls = lane_scalars<Mode::kVec>(a.coef, a.col_coef, a.col_pscale, r);
 
     // LDS: [table: n_unique x STRIDE slots][per wave: 64 lanes x 4 own entries]
     const double2* table = static_cast<const double2*>(a.dict_table);
@@ -739,8 +764,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
                 const size_t slot_own = vslot(al, (size_t)i, r, a.ncols, RL);
                 const double2 p = a.prev[slot_own];
                 double2 nx;
-                nx.x = fma(a.coef, acc[al].x, -p.x);
-                nx.y = fma(a.coef, acc[al].y, -p.y);
+                nx.x = fma(ls.c.x, acc[al].x, -(ls.s.x * p.x));
+                nx.y = fma(ls.c.y, acc[al].y, -(ls.s.y * p.y));
                 a.prev[slot_own] = nx;
                 Mode::dots(dot, own[al], nx);
             }
@@ -775,6 +800,123 @@ __global__ void pack_blocks(const double2* __restrict__ blocks, void* __restrict
         const double2 v = blocks[k * 16 + packed_source(entries, (int)(idx % entries))];
         if (real_out) static_cast<double*>(out)[idx] = v.x;
         else static_cast<double2*>(out)[idx] = v;
+    }
+}
+
+// -------------------------------------------------------------- Lanczos helpers
+// w = rbuf - g[col] * v, written over rbuf; per-column |w|^2 over the owned rows.
+// PER_LANE = 1: complex payloads (column = r); 2: real payloads (columns 2r, 2r+1).
+// partial[block][column]; fixed summation order (bit reproducible).
+template <int PER_LANE>
+__global__ __launch_bounds__(256) void lanczos_combine(double2* __restrict__ rbuf,
+                                                       const double2* __restrict__ v,
+                                                       const double* __restrict__ g, int64_t nb,
+                                                       int64_t ncols, int rl, double* __restrict__ partial) {
+    __shared__ double scratch[2][256];
+    const int r = threadIdx.x % rl;  // 256 and the grid stride are multiples of rl: r is fixed per thread
+    const double g0 = g[PER_LANE * r], g1 = g[PER_LANE * r + (PER_LANE - 1)];
+    double n0 = 0.0, n1 = 0.0;
+    const int64_t total = 4 * ncols * rl;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        int alpha;
+        int64_t site;
+        vpair(idx / rl, ncols, alpha, site);
+        if (site >= nb) continue;  // halo rows are refreshed by the exchange, never combined
+        const double2 a = rbuf[idx], b = v[idx];
+        double2 w;
+        w.x = fma(-g0, b.x, a.x);
+        w.y = fma(-g1, b.y, a.y);
+        rbuf[idx] = w;
+        n0 = fma(w.x, w.x, n0);
+        n1 = fma(w.y, w.y, n1);
+    }
+    scratch[0][threadIdx.x] = n0;
+    scratch[1][threadIdx.x] = n1;
+    __syncthreads();
+    if ((int)threadIdx.x < rl) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int k = threadIdx.x; k < 256; k += rl) {
+            t0 += scratch[0][k];
+            t1 += scratch[1][k];
+        }
+        double* out = partial + (size_t)blockIdx.x * rl * PER_LANE;
+        if (PER_LANE == 1) out[r] = t0 + t1;
+        else {
+            out[2 * r] = t0;
+            out[2 * r + 1] = t1;
+        }
+    }
+}
+
+// Device-side scalar bookkeeping of the Lanczos process on H^2 (one thread per column).
+//   phase 0 (after the norms of W_{j+1} are reduced into `sums`):
+//       beta_next = sqrt(sums); coef_a = 1 / beta_next; pscale_b = beta_next / beta_cur
+//   phase 1 (after step b's dots, alpha_j = |U|^2, are reduced into `sums` with stride 2):
+//       alpha = sums[2 col]; g = alpha / beta_cur
+struct LanczosScalars {
+    double* beta_hist;   // [iter][cols]
+    double* alpha_hist;  // [iter][cols]
+    double* coef_a;      // 1 / beta_j              (step a: U = H W_j / beta_j)
+    double* pscale_a;    // zeros
+    double* coef_b;      // ones
+    double* pscale_b;    // beta_j / beta_{j-1}     (step b)
+    double* g;           // alpha_j / beta_j        (combine)
+};
+
+__global__ void lanczos_scalars(LanczosScalars z, const double* __restrict__ sums, int cols, int iter,
+                                int phase) {
+    const int c = threadIdx.x;
+    if (c >= cols) return;
+    if (phase == 0) {  // norms of the new vector W_iter are in sums[c]
+        const double beta = sqrt(sums[c]);
+        const double prev = iter > 0 ? z.beta_hist[(size_t)(iter - 1) * cols + c] : 0.0;
+        z.beta_hist[(size_t)iter * cols + c] = beta;
+        z.coef_a[c] = beta > 0.0 ? 1.0 / beta : 0.0;
+        z.pscale_a[c] = 0.0;
+        z.coef_b[c] = 1.0;
+        z.pscale_b[c] = prev > 0.0 ? beta / prev : 0.0;
+    } else {  // alpha_iter = |H v_iter|^2 is the d dot of step b
+        const double alpha = sums[2 * c];
+        const double beta = z.beta_hist[(size_t)iter * cols + c];
+        z.alpha_hist[(size_t)iter * cols + c] = alpha;
+        z.g[c] = beta > 0.0 ? alpha / beta : 0.0;
+    }
+}
+
+// per-column |v|^2 over the owned rows (start of the process): partial[block][column]
+template <int PER_LANE>
+__global__ __launch_bounds__(256) void column_norms(const double2* __restrict__ v, int64_t nb, int64_t ncols,
+                                                    int rl, double* __restrict__ partial) {
+    __shared__ double scratch[2][256];
+    const int r = threadIdx.x % rl;
+    double n0 = 0.0, n1 = 0.0;
+    const int64_t total = 4 * ncols * rl;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        int alpha;
+        int64_t site;
+        vpair(idx / rl, ncols, alpha, site);
+        if (site >= nb) continue;
+        const double2 a = v[idx];
+        n0 = fma(a.x, a.x, n0);
+        n1 = fma(a.y, a.y, n1);
+    }
+    scratch[0][threadIdx.x] = n0;
+    scratch[1][threadIdx.x] = n1;
+    __syncthreads();
+    if ((int)threadIdx.x < rl) {
+        double t0 = 0.0, t1 = 0.0;
+        for (int k = threadIdx.x; k < 256; k += rl) {
+            t0 += scratch[0][k];
+            t1 += scratch[1][k];
+        }
+        double* out = partial + (size_t)blockIdx.x * rl * PER_LANE;
+        if (PER_LANE == 1) out[r] = t0 + t1;
+        else {
+            out[2 * r] = t0;
+            out[2 * r + 1] = t1;
+        }
     }
 }
 

@@ -258,6 +258,14 @@ class Hamiltonian:
 
         return free_energy(self, temperature, **options)
 
+    def lowest_eigenvalues(self, k: int = 1, **options) -> Matrix:
+        """The k smallest distinct positive eigenvalues (the gap and the levels above it) by a
+        Lanczos process on the GPU - for lattices where `diagonalize()` does not fit.  Not part
+        of the reference API; see `bodge_amd.observables.lowest_eigenvalues`."""
+        from .observables import lowest_eigenvalues
+
+        return lowest_eigenvalues(self, k, **options)
+
     def ldos(self, site: Coord, energies, **options) -> Matrix:
         """Local density of states at `site` for the given energies (ref :324-387)."""
         from .observables import ldos

@@ -171,6 +171,20 @@ class DeviceSolver:
         )
         return mu
 
+    def lanczos_begin(self, n_vectors: int, seed: int = 0, first_id: int = 0, kind: int = VEC_RADEMACHER,
+                      max_iter: int = 10000) -> None:
+        """Start n_vectors independent Lanczos processes on H^2 (see `lanczos_advance`)."""
+        backend.check(self._lib.bdg_lanczos_begin(self._handle, n_vectors, seed, first_id, kind, max_iter))
+        self._lanczos_vectors = n_vectors
+
+    def lanczos_advance(self, n_iter: int):
+        """Run n_iter more iterations; returns (alpha, beta) of shape (n_iter, n_vectors): diagonal and
+        off-diagonal (beta_{j+1}) of the tridiagonal representation of H^2."""
+        alpha = np.empty((n_iter, self._lanczos_vectors))
+        beta = np.empty((n_iter, self._lanczos_vectors))
+        backend.check(self._lib.bdg_lanczos_advance(self._handle, n_iter, backend.as_f64p(alpha), backend.as_f64p(beta)))
+        return alpha, beta
+
     def eigh(self, vectors: bool = True):
         """All eigenvalues ascending (and eigenvectors as columns) from rocSOLVER zheevd."""
         w = np.empty(self.dim)

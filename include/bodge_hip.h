@@ -142,6 +142,19 @@ int bdg_cheb_moments(bdg_system* sys, bdg_comm* comm, double scale, int32_t n_mo
 int bdg_cheb_diag_moments(bdg_system* sys, double scale, int32_t n_moments, int32_t n_vectors,
                           const int64_t* rows, double* mu_out);
 
+/*
+ * Lanczos process on H^2 (eigenvalues of H closest to zero, i.e. the excitation gap, for
+ * matrices beyond dense reach).  `begin` prepares n_vectors (<= 64) independent processes from
+ * counter-based start vectors; `advance` runs n_iter more iterations and returns, per
+ * iteration j and vector r, alpha[j*n_vectors + r] = <v_j|H^2|v_j> and
+ * beta[j*n_vectors + r] = beta_{j+1} (the tridiagonal matrix of H^2 in the Lanczos basis;
+ * its lowest eigenvalues converge to the squares of the smallest |eigenvalues| of H).
+ * At most max_iter iterations in total.  Whole matrices only (not slabs).
+ */
+int bdg_lanczos_begin(bdg_system* sys, int32_t n_vectors, uint64_t seed, uint64_t first_vec_id,
+                      int32_t vec_kind, int32_t max_iter);
+int bdg_lanczos_advance(bdg_system* sys, int32_t n_iter, double* alpha_out, double* beta_out);
+
 /* Write the counter-based start vector (4*nb complex entries) to a host buffer. */
 int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t vec_kind,
                       double* v_out);
