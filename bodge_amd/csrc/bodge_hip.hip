@@ -631,7 +631,7 @@ struct Batch {
         per_step = (size_t)plan.grid * width;
         constexpr int kChunk = 64;
         chunk = std::min(n_steps, kChunk);
-        if (int rc = sys->partial.reserve((size_t)2 * kChunk * per_step)) return rc;
+        if (int rc = sys->partial.reserve((size_t)kChunk * per_step)) return rc;
         const size_t dots_count = (size_t)std::max(n_steps, 1024) * width;
         if (int rc = sys->dots.reserve(dots_count)) return rc;
         if (sys->host_dots_count < dots_count) {
@@ -745,15 +745,14 @@ struct Batch {
         args.cur = cur;
         args.prev = prev;
         args.coef = (n == 0 ? 1.0 : 2.0) / scale;
-        args.partial = sys->partial.ptr + ((size_t)(chunk_id & 1) * chunk + in_chunk) * per_step;
+        args.partial = sys->partial.ptr + (size_t)in_chunk * per_step;
         plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
         std::swap(cur, prev);
         if (in_chunk == chunk - 1 || n == n_steps - 1) {
             const int s0 = n - in_chunk;
             HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id + 1], st));
             bdg::reduce_partials<<<in_chunk + 1, 256, 0, st>>>(
-                sys->partial.ptr + (size_t)(chunk_id & 1) * chunk * per_step,
-                sys->dots.ptr + (size_t)s0 * width, plan.grid, (int)width);
+                sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, plan.grid, (int)width);
             HIP_TRY(hipGetLastError());
             n_chunks = chunk_id + 1;
         }

@@ -238,7 +238,11 @@ def ldos(system, site, energies, *, moments: int | None = None, scale: float | N
 
     The broadening follows the reference exactly: ε = unique(|E|), Γ = gradient(ε),
     evaluated with the same numpy calls so that its one-ulp quirks carry over.
+    `site` may also be a list of coordinates: all sites share the recurrence launches (16
+    sites = 64 unit start vectors per batch) and the result has one row per site.
     """
+    single = len(site) == 3 and all(isinstance(c, (int, np.integer)) for c in site)
+    sites = [tuple(site)] if single else [tuple(s) for s in site]
     energies = np.array(energies, dtype=float)
     eps = np.unique(np.abs(energies))
     gam = np.gradient(eps)
@@ -247,13 +251,16 @@ def ldos(system, site, energies, *, moments: int | None = None, scale: float | N
         moments = cheb.moments_for_resolvent(scale, float(np.min(gam)), digits)
     moments += moments & 1
 
-    i = system.lattice[tuple(site)]
-    rows = np.array([4 * i + a for a in range(4)], dtype=np.int64)
-    mu = system._solver().moments_unit(scale, moments, rows)  # (M, 4)
+    index = np.array([system.lattice[s] for s in sites], dtype=np.int64)
+    rows = (4 * index[:, None] + np.arange(4)[None, :]).reshape(-1)
+    mu = system._solver().moments_unit(scale, moments, rows)  # (M, 4 * n_sites)
 
-    rho = {}
-    for e, g in zip(eps, gam):
-        diag = [cheb.resolvent_series(mu[:, a], scale, e + 1j * g) for a in range(4)]
-        rho[+e] = -np.imag(diag[0] + diag[1]) / np.pi
-        rho[-e] = -np.imag(diag[2] + diag[3]) / np.pi
-    return np.array([rho[e] for e in energies])
+    out = np.empty((len(sites), energies.size))
+    for n in range(len(sites)):
+        rho = {}
+        for e, g in zip(eps, gam):
+            diag = [cheb.resolvent_series(mu[:, 4 * n + a], scale, e + 1j * g) for a in range(4)]
+            rho[+e] = -np.imag(diag[0] + diag[1]) / np.pi
+            rho[-e] = -np.imag(diag[2] + diag[3]) / np.pi
+        out[n] = [rho[e] for e in energies]
+    return out[0] if single else out

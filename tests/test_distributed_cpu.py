@@ -91,3 +91,23 @@ def test_two_gloo_ranks_slab_exchange_matches_single_rank(api, tmp_path):
     start = cheb_ref.random_block(bsr.shape[0], 0, range(total), cheb_ref.VEC_Z4)
     mu = cheb_ref.moments(bsr, got["scale"], moments, start).sum(axis=1) / total
     assert np.allclose(got["mu"], mu, rtol=0, atol=1e-12 * bsr.shape[0])
+
+
+@pytest.mark.timeout(600)
+def test_rccl_rendezvous_under_torchrun(tmp_path):
+    """The unique-id hand-off that precedes ncclCommInitRank, run by 4 real ranks started the way
+    the driver starts bench.py (torch.distributed.run): every rank must receive rank 0's 128 bytes."""
+    cmd = [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4",
+        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+        os.path.join(ROOT, "tests", "_rdzv_worker.py"), str(tmp_path),
+    ]
+    env = dict(os.environ, BODGE_AMD_RDZV_DIR=str(tmp_path))
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    ranks = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(4)]
+    assert [r["rank"] for r in ranks] == [0, 1, 2, 3] and all(r["world"] == 4 and r["len"] == 128 for r in ranks)
+    assert [r["device"] for r in ranks] == [0, 1, 2, 3]  # LOCAL_RANK -> device
+    assert len({r["uid"] for r in ranks}) == 1, "ranks disagree on the unique id"
+    assert len({r["ppid"] for r in ranks}) == 1  # the rendezvous file name relies on a common parent
+    assert not [f for f in os.listdir(tmp_path) if f.endswith(".id")], "rendezvous file was not cleaned up"

@@ -353,6 +353,17 @@ def test_ldos_matches_reference(api, golden, name):
         assert np.allclose(rho, golden.ldos(name, n), rtol=1e-9, atol=1e-12)
 
 
+def test_ldos_of_many_sites_in_one_call(api, golden):
+    """A list of sites shares the launches (16 sites per batch); rows must equal per-site calls."""
+    system = _build(api, "ldos16")
+    sites = [(8, 8, 0), (0, 3, 0)] + [(x, 5, 0) for x in range(16)]
+    energies = list(np.linspace(-0.3, 0.3, 7))
+    table = system.ldos(sites, energies)
+    assert table.shape == (18, 7)
+    assert np.allclose(table[0], golden.ldos("ldos16", 0), rtol=1e-9, atol=1e-12)
+    assert np.allclose(table[9], system.ldos((7, 5, 0), energies), rtol=1e-12)
+
+
 def test_ldos_is_positive_everywhere(api):
     """ref tests/test_hamiltonian.py:467-500 on a seeded random periodic metal."""
     system = systems.random_periodic(api, shape=(5, 5, 2), seed=21)
