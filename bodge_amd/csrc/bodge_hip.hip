@@ -182,6 +182,39 @@ StepKernel generic_kernel(int rl) {
     return nullptr;
 }
 
+template <typename Mode>
+StepKernel generic_cols_kernel(int rl) {
+    switch (rl) {
+        case 4: return bdg::cheb_step<Mode, 4, true>;
+        case 8: return bdg::cheb_step<Mode, 8, true>;
+        case 16: return bdg::cheb_step<Mode, 16, true>;
+        case 32: return bdg::cheb_step<Mode, 32, true>;
+        case 64: return bdg::cheb_step<Mode, 64, true>;
+    }
+    return nullptr;
+}
+
+// Kernels taking per-column scalars (Lanczos): every (mode, lanes) in the generic form, and the
+// dictionary form for 4 lanes per row (the usual 4..8 start vectors).
+StepKernel step_cols_kernel(const ModeInfo& mode, int rl) {
+    switch (mode.id) {
+        case 1: return generic_cols_kernel<RealMode>(rl);
+        case 2: return generic_cols_kernel<ComplexPHMode>(rl);
+        case 3: return generic_cols_kernel<RealPHMode>(rl);
+    }
+    return generic_cols_kernel<ComplexMode>(rl);
+}
+
+template <int MAXB>
+StepKernel dict_cols_for(const ModeInfo& mode) {
+    switch (mode.id) {
+        case 1: return bdg::cheb_step_dict<RealMode, 4, MAXB, true>;
+        case 2: return bdg::cheb_step_dict<ComplexPHMode, 4, MAXB, true>;
+        case 3: return bdg::cheb_step_dict<RealPHMode, 4, MAXB, true>;
+    }
+    return bdg::cheb_step_dict<ComplexMode, 4, MAXB, true>;
+}
+
 StepKernel step_kernel(const ModeInfo& mode, int rl) {
     switch (mode.id) {
         case 1: return generic_kernel<RealMode>(rl);
@@ -283,7 +316,7 @@ struct StepPlan {
     StepKernel kernel = nullptr;
 };
 
-int make_plan(bdg_system* sys, int rl, const ModeInfo& mode, StepPlan* plan) {
+int make_plan(bdg_system* sys, int rl, const ModeInfo& mode, StepPlan* plan, bool col_scalars = false) {
     plan->rl = rl;
     plan->mode = mode;
     const int block_stride = mode.stride;
@@ -293,6 +326,14 @@ int make_plan(bdg_system* sys, int rl, const ModeInfo& mode, StepPlan* plan) {
     plan->n_tiles = (int)((sys->nb + plan->rows_per_tile - 1) / plan->rows_per_tile);
     int maxb = 0;
     plan->kernel = dict_kernel(sys, mode, rl);
+    if (col_scalars) {  // Lanczos: same kernel families, instantiations with per-column scalars
+        if (plan->kernel && rl == 4)
+            plan->kernel = sys->max_row_blocks <= 3   ? dict_cols_for<3>(mode)
+                           : sys->max_row_blocks <= 5 ? dict_cols_for<5>(mode)
+                                                      : dict_cols_for<7>(mode);
+        else
+            plan->kernel = nullptr;
+    }
     if (plan->kernel) {
         plan->dictionary = true;
         // table of distinct blocks + 4 own t_n entries per lane (16 KiB per workgroup)
@@ -300,14 +341,14 @@ int make_plan(bdg_system* sys, int rl, const ModeInfo& mode, StepPlan* plan) {
                              (size_t)bdg::kBlockThreads * 4 * sizeof(double2);
         const size_t reduce = (size_t)bdg::kWavesPerBlock * rl * lane_doubles * sizeof(double);
         plan->lds_bytes = plan->lds_footprint = std::max(table, reduce);
-    } else if ((plan->kernel = pipelined_kernel(mode, rl, sys->max_row_blocks, &maxb))) {
+    } else if (!col_scalars && (plan->kernel = pipelined_kernel(mode, rl, sys->max_row_blocks, &maxb))) {
         plan->pipelined = true;
         plan->lds_bytes = 0;
         plan->lds_footprint = (size_t)bdg::kWavesPerBlock * rows_per_wave * maxb * block_stride *
                                   sizeof(double2) +
                               (size_t)bdg::kWavesPerBlock * rl * lane_doubles * sizeof(double);
     } else {
-        plan->kernel = step_kernel(mode, rl);
+        plan->kernel = col_scalars ? step_cols_kernel(mode, rl) : step_kernel(mode, rl);
         if (!plan->kernel) return fail(BDG_EINVAL, "unsupported lanes-per-row %d", rl);
         const size_t stage = (size_t)bdg::kWavesPerBlock * rows_per_wave * sys->max_row_blocks *
                              block_stride * sizeof(double2);
@@ -597,7 +638,7 @@ struct Batch {
     int n_chunks = 0;
 
     int begin(bdg_system* system, double scale_in, int steps, int active, const StartSpec& start,
-              int force_real /* -1 auto, 0 complex, 1 real */) {
+              int force_real /* -1 auto, 0 complex, 1 real */, bool col_scalars = false) {
         sys = system;
         scale = scale_in;
         n_steps = steps;
@@ -619,7 +660,7 @@ struct Batch {
             sys->lanes_override * per_lane <= 64)
             rl = sys->lanes_override;
         rv = rl * per_lane;  // vector columns in the buffers
-        if (int rc = make_plan(sys, rl, mode, &plan)) return rc;
+        if (int rc = make_plan(sys, rl, mode, &plan, col_scalars)) return rc;
         if (int rc = matrix_args(sys, plan, &args)) return rc;
 
         vec_count = (size_t)4 * sys->ncols * rl;  // 16-byte lane payloads
@@ -965,7 +1006,7 @@ int lanczos_begin(bdg_system* sys, int n_vectors, const StartSpec& start, int ma
     LanczosState* lz = new LanczosState();
     sys->lanczos = lz;
     Batch& b = lz->batch;
-    if (int rc = b.begin(sys, 1.0, 1, n_vectors, start, -1)) return rc;  // W_0 in vec_a, zeros in vec_b
+    if (int rc = b.begin(sys, 1.0, 1, n_vectors, start, -1, /*col_scalars=*/true)) return rc;  // W_0 in vec_a
     lz->cols = b.rv;
     lz->n_active = n_vectors;
     lz->max_iter = max_iter;

@@ -370,7 +370,7 @@ __device__ inline void reduce_dots(double dot[4], double* red, double* partial, 
 // the block elements it needs as LDS broadcasts (the RL lanes of a row read the
 // same address).  No workgroup barrier inside the tile loop: LDS traffic of one
 // wave is ordered, and nothing is shared between waves until the dot reduction.
-template <typename Mode, int RL>
+template <typename Mode, int RL, bool COLS = false>
 __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
     extern __shared__ double2 lds[];
     constexpr int RW = kWave / RL;  // block rows per wave
@@ -380,7 +380,6 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
     const int wave = threadIdx.x / kWave;
     const int s = lane / RL;
     const int r = lane % RL;
-    const LaneScalars ls = lane_scalars<Mode::kVec>(a.coef, a.col_coef, a.col_pscale, r);
     const int region = RW * a.max_row_blocks * STRIDE;
     double2* stage = lds + wave * region;
     const double2* all_blocks = static_cast<const double2*>(a.blocks);
@@ -448,6 +447,10 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
                 Mode::mac_row(acc, stage + (k - kb0) * STRIDE, x);
             }
 
+            // COLS instantiations (Lanczos) fetch per-column scalars here, once per tile; the
+            // Chebyshev instantiations compile to the plain coef * acc - prev
+            const LaneScalars ls = COLS ? lane_scalars<Mode::kVec>(a.coef, a.col_coef, a.col_pscale, r)
+                                        : lane_scalars<Mode::kVec>(a.coef, nullptr, nullptr, r);
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
                 const size_t own = vslot(al, (size_t)i, r, a.ncols, RL);
@@ -498,7 +501,6 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int s = lane / RL;
     const int r = lane % RL;
-    const LaneScalars ls = lane_scalars<Mode::kVec>(a.coef, a.col_coef, a.col_pscale, r);
     double2* stage = lds + wave * (NBLK * STRIDE);
     const double2* all_blocks = static_cast<const double2*>(a.blocks);
 
@@ -608,6 +610,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
                     Mode::mac_row(acc, blk + q * STRIDE, x);
                 }
             }
+            const LaneScalars ls = lane_scalars<Mode::kVec>(a.coef, nullptr, nullptr, r);
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
                 const size_t own = vslot(al, (size_t)i, r, a.ncols, RL);
@@ -654,7 +657,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
 // neighbours along the fastest axis) is served from there instead of from L2.  The test is
 // made per block on the actual column index, so any sparsity pattern stays correct.
 // Row metadata of the next tile is prefetched while the current one computes.
-template <typename Mode, int RL, int MAXB>
+template <typename Mode, int RL, int MAXB, bool COLS = false>
 __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
     extern __shared__ double2 lds[];
     constexpr int RW = kWave / RL;
@@ -664,7 +667,6 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int s = lane / RL;
     const int r = lane % RL;
-    const LaneScalars ls = lane_scalars<Mode::kVec>(a.coef, a.col_coef, a.col_pscale, r);
 
     // LDS: [table: n_unique x STRIDE slots][per wave: 64 lanes x 4 own entries]
     const double2* table = static_cast<const double2*>(a.dict_table);
@@ -759,6 +761,10 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
                     Mode::mac_row(acc, lds + id_of(meta.word[q]) * STRIDE, x);
                 }
             }
+            // COLS instantiations (Lanczos) fetch per-column scalars here, once per tile; the
+            // Chebyshev instantiations compile to the plain coef * acc - prev
+            const LaneScalars ls = COLS ? lane_scalars<Mode::kVec>(a.coef, a.col_coef, a.col_pscale, r)
+                                        : lane_scalars<Mode::kVec>(a.coef, nullptr, nullptr, r);
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
                 const size_t slot_own = vslot(al, (size_t)i, r, a.ncols, RL);

@@ -1,0 +1,42 @@
+"""Regression guard on the compiled recurrence kernels (no GPU: hipcc cross-compiles).
+
+The hot kernels sit right at register-file steps (128 VGPRs = 4 waves/SIMD, 168 = 3); an edit
+that adds a few live registers silently costs an occupancy level or spills, which measured
+10-30 % on the MI355X.  This test pins what the measured numbers rely on.
+"""
+
+import os
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+
+@pytest.fixture(scope="module")
+def resources():
+    if shutil.which("hipcc") is None:
+        pytest.skip("hipcc not available")
+    import kernel_resources
+
+    return kernel_resources.collect()
+
+
+def _row(resources, name):
+    matches = [row for key, row in resources.items() if key.startswith(f"void bdg::{name}(")]
+    assert len(matches) == 1, (name, [k for k in resources if name.split("<")[0] in k][:5])
+    return matches[0]
+
+
+@pytest.mark.timeout(600)
+def test_headline_kernels_do_not_spill_and_keep_their_occupancy(resources):
+    headline = _row(resources, "cheb_step_dict<bdg::RealPHMode, 4, 5, false>")
+    assert headline["scratch"] == 0 and headline["vgpr"] <= 128 and headline["occupancy"] >= 4
+    for mode, lanes in (("RealPHMode", 4), ("ComplexPHMode", 8), ("RealMode", 4), ("ComplexMode", 8)):
+        row = _row(resources, f"cheb_step_pipelined<bdg::{mode}, {lanes}, 5>")
+        assert row["scratch"] == 0 and row["vgpr"] <= 168 and row["occupancy"] >= 3, (mode, row)
+    for lanes in (4, 8, 16, 32, 64):
+        row = _row(resources, f"cheb_step<bdg::ComplexMode, {lanes}, false>")
+        assert row["scratch"] == 0 and row["occupancy"] >= 4, (lanes, row)
