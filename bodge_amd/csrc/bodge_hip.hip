@@ -104,6 +104,12 @@ struct bdg_system {
     DeviceBuffer<double2> send_buf, recv_buf;
     int64_t send_total = 0, recv_total = 0;
     bdg_comm* slab_comm = nullptr;  // RCCL transport for the halo exchange (not owned)
+    // overlap of the halo exchange with the rows that do not need it
+    std::vector<uint8_t> row_needs_halo;  // host: block row reads at least one halo column
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_step_done = nullptr, ev_halo_ready = nullptr;
+    DeviceBuffer<int> tiles_interior, tiles_boundary;
+    int split_rows_per_tile = 0, n_interior = 0, n_boundary = 0;
     void* lanczos = nullptr;  // LanczosState of a run in progress (defined with the driver)
     int max_row_blocks = 0;
     int num_cus = 0;
@@ -667,9 +673,10 @@ struct Batch {
         if (int rc = sys->vec_a.reserve(vec_count)) return rc;
         if (int rc = sys->vec_b.reserve(vec_count)) return rc;
         width = (size_t)2 * rv;
+        if (int rc = prepare_overlap()) return rc;
         // Dot partials are reduced every `chunk` launches.  Buffer sizes do not depend on
         // n_steps (up to 1024), so a short warm-up call leaves nothing to allocate later.
-        per_step = (size_t)plan.grid * width;
+        per_step = (size_t)(overlapped ? grid_interior + grid_boundary : plan.grid) * width;
         constexpr int kChunk = 64;
         chunk = std::min(n_steps, kChunk);
         if (int rc = sys->partial.reserve((size_t)kChunk * per_step)) return rc;
@@ -726,28 +733,143 @@ struct Batch {
     }
 
     // Halo exchange, split so that a same-process group can interleave its members.
-    int pack() {
+    int pack(hipStream_t st = nullptr) {
         if (sys->send_total == 0) return BDG_OK;
+        if (!st) st = sys->stream;
         HIP_TRY(hipSetDevice(sys->device));
         const int64_t total = sys->send_total * 4 * rl;
-        bdg::halo_pack<<<(unsigned)std::min<int64_t>(2048, (total + 255) / 256), 256, 0, sys->stream>>>(
+        bdg::halo_pack<<<(unsigned)std::min<int64_t>(2048, (total + 255) / 256), 256, 0, st>>>(
             cur, sys->send_rows.ptr, sys->send_total, sys->ncols, rl, sys->send_buf.ptr);
         HIP_TRY(hipGetLastError());
         return BDG_OK;
     }
-    int unpack() {
+    int unpack(hipStream_t st = nullptr) {
+        if (!st) st = sys->stream;
         HIP_TRY(hipSetDevice(sys->device));
         for (const ExchangePeer& peer : sys->peers) {
             if (peer.recv_count == 0) continue;
             const int64_t total = peer.recv_count * 4 * rl;
-            bdg::halo_unpack<<<(unsigned)std::min<int64_t>(2048, (total + 255) / 256), 256, 0,
-                               sys->stream>>>(cur, peer.recv_col, peer.recv_count, sys->ncols, rl,
-                                              sys->recv_buf.ptr + (size_t)peer.recv_begin * 4 * rl);
+            bdg::halo_unpack<<<(unsigned)std::min<int64_t>(2048, (total + 255) / 256), 256, 0, st>>>(
+                cur, peer.recv_col, peer.recv_count, sys->ncols, rl,
+                sys->recv_buf.ptr + (size_t)peer.recv_begin * 4 * rl);
         }
         HIP_TRY(hipGetLastError());
         return BDG_OK;
     }
-    // RCCL transport: grouped send/recv of the packed rows on the compute stream.
+
+    // ---- overlap: rows that read no halo column ("interior") do not have to wait for the
+    // exchange.  The workgroup tiles are split into two lists; per launch of the recurrence
+    //   comm stream   : wait(previous step) -> pack -> ncclSend/Recv -> unpack -> ev_halo_ready
+    //   compute stream: K1(interior tiles) -> wait(ev_halo_ready) -> K1(boundary tiles) -> ev_step_done
+    // so the transfer hides behind the interior launch.  Hazards: the exchange only reads owned
+    // rows of t_n and writes halo rows of the same buffer, which nothing but the boundary launch of
+    // this step reads; both launches write owned rows of the other buffer.
+    int grid_interior = 0, grid_boundary = 0;
+    bool overlapped = false;
+
+    int prepare_overlap() {
+        overlapped = false;
+        const char* env = getenv("BODGE_AMD_OVERLAP");
+        if (sys->peers.empty() || !sys->slab_comm || sys->row_needs_halo.empty() || (env && env[0] == '0'))
+            return BDG_OK;
+        if (sys->split_rows_per_tile != plan.rows_per_tile) {
+            std::vector<int> interior, boundary;
+            for (int t = 0; t < plan.n_tiles; ++t) {
+                bool needs = false;
+                const int64_t r0 = (int64_t)t * plan.rows_per_tile;
+                for (int64_t i = r0; i < std::min<int64_t>(sys->nb, r0 + plan.rows_per_tile); ++i)
+                    needs = needs || sys->row_needs_halo[(size_t)i];
+                (needs ? boundary : interior).push_back(t);
+            }
+            if (int rc = sys->tiles_interior.reserve(std::max<size_t>(1, interior.size()))) return rc;
+            if (int rc = sys->tiles_boundary.reserve(std::max<size_t>(1, boundary.size()))) return rc;
+            if (!interior.empty())
+                HIP_TRY(hipMemcpy(sys->tiles_interior.ptr, interior.data(), sizeof(int) * interior.size(),
+                                  hipMemcpyHostToDevice));
+            if (!boundary.empty())
+                HIP_TRY(hipMemcpy(sys->tiles_boundary.ptr, boundary.data(), sizeof(int) * boundary.size(),
+                                  hipMemcpyHostToDevice));
+            sys->n_interior = (int)interior.size();
+            sys->n_boundary = (int)boundary.size();
+            sys->split_rows_per_tile = plan.rows_per_tile;
+        }
+        if (sys->n_interior == 0 || sys->n_boundary == 0) return BDG_OK;  // nothing to hide behind
+        if (!sys->comm_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&sys->comm_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&sys->ev_step_done, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&sys->ev_halo_ready, hipEventDisableTiming));
+        }
+        auto grid_for = [&](int tiles) { return std::max(8, (std::min(tiles, plan.grid) + 7) / 8 * 8); };
+        grid_interior = grid_for(sys->n_interior);
+        grid_boundary = grid_for(sys->n_boundary);
+        overlapped = true;
+        return BDG_OK;
+    }
+
+    int rccl_transfer(hipStream_t st) {
+        bdg_comm* comm = sys->slab_comm;
+        RcclApi* api = nullptr;
+        if (int rc = load_rccl(&api)) return rc;
+        NCCL_TRY(api, api->group_start());
+        for (const ExchangePeer& peer : sys->peers) {
+            const size_t unit = (size_t)4 * rl * 2;  // doubles per exchanged block row
+            if (peer.send_count > 0)
+                NCCL_TRY(api, api->send(sys->send_buf.ptr + (size_t)peer.send_begin * 4 * rl,
+                                        (size_t)peer.send_count * unit, ncclDouble, peer.rank, comm->comm, st));
+            if (peer.recv_count > 0)
+                NCCL_TRY(api, api->recv(sys->recv_buf.ptr + (size_t)peer.recv_begin * 4 * rl,
+                                        (size_t)peer.recv_count * unit, ncclDouble, peer.rank, comm->comm, st));
+        }
+        NCCL_TRY(api, api->group_end());
+        return BDG_OK;
+    }
+
+    int step_overlapped(int n) {
+        HIP_TRY(hipSetDevice(sys->device));
+        hipStream_t st = sys->stream, cs = sys->comm_stream;
+        const int in_chunk = n % chunk;
+        const int chunk_id = n / chunk;
+        while ((int)sys->ev_pool.size() < 2 * (chunk_id + 1)) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreate(&ev));
+            sys->ev_pool.push_back(ev);
+        }
+        // exchange of t_n on the communication stream, after everything that produced t_n
+        HIP_TRY(hipEventRecord(sys->ev_step_done, st));
+        HIP_TRY(hipStreamWaitEvent(cs, sys->ev_step_done, 0));
+        if (int rc = pack(cs)) return rc;
+        if (int rc = rccl_transfer(cs)) return rc;
+        if (int rc = unpack(cs)) return rc;
+        HIP_TRY(hipEventRecord(sys->ev_halo_ready, cs));
+
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id], st));
+        args.cur = cur;
+        args.prev = prev;
+        args.coef = (n == 0 ? 1.0 : 2.0) / scale;
+        double* slot = sys->partial.ptr + (size_t)in_chunk * per_step;
+        bdg::StepArgs part = args;
+        part.tile_order = sys->tiles_interior.ptr;
+        part.n_tiles = sys->n_interior;
+        part.partial = slot;
+        plan.kernel<<<grid_interior, bdg::kBlockThreads, plan.lds_bytes, st>>>(part);
+        HIP_TRY(hipStreamWaitEvent(st, sys->ev_halo_ready, 0));
+        part.tile_order = sys->tiles_boundary.ptr;
+        part.n_tiles = sys->n_boundary;
+        part.partial = slot + (size_t)grid_interior * width;
+        plan.kernel<<<grid_boundary, bdg::kBlockThreads, plan.lds_bytes, st>>>(part);
+        std::swap(cur, prev);
+        if (in_chunk == chunk - 1 || n == n_steps - 1) {
+            const int s0 = n - in_chunk;
+            HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id + 1], st));
+            bdg::reduce_partials<<<in_chunk + 1, 256, 0, st>>>(sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width,
+                                                              grid_interior + grid_boundary, (int)width);
+            HIP_TRY(hipGetLastError());
+            n_chunks = chunk_id + 1;
+        }
+        return BDG_OK;
+    }
+
+    // RCCL transport without overlap: grouped send/recv of the packed rows on the compute stream.
     int exchange_rccl() {
         if (sys->peers.empty()) return BDG_OK;
         bdg_comm* comm = sys->slab_comm;
@@ -871,6 +993,10 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
             return rc;
         const auto t1 = now();
         for (int n = 0; n < n_steps; ++n) {
+            if (batch.overlapped) {
+                if (int rc = batch.step_overlapped(n)) return rc;
+                continue;
+            }
             if (int rc = batch.exchange_rccl()) return rc;
             if (int rc = batch.step(n)) return rc;
         }
@@ -1188,6 +1314,12 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     sys->row_offset = row_offset;
     sys->nnzb = nnzb;
     sys->max_row_blocks = std::max(1, max_row);
+    if (ncols > nb) {
+        sys->row_needs_halo.assign((size_t)nb, 0);
+        for (int64_t i = 0; i < nb; ++i)
+            for (int k = indptr[i]; k < indptr[i + 1]; ++k)
+                if (indices[k] >= nb) sys->row_needs_halo[(size_t)i] = 1;
+    }
     sys->is_real = is_real;
     sys->is_ph = is_ph;
     hipDeviceProp_t prop;
@@ -1359,6 +1491,11 @@ int bdg_destroy(bdg_system* sys) {
     sys->host_dots = nullptr;
     sys->tile_order.release();
     sys->send_rows.release();
+    sys->tiles_interior.release();
+    sys->tiles_boundary.release();
+    if (sys->comm_stream) (void)hipStreamDestroy(sys->comm_stream);
+    if (sys->ev_step_done) (void)hipEventDestroy(sys->ev_step_done);
+    if (sys->ev_halo_ready) (void)hipEventDestroy(sys->ev_halo_ready);
     sys->send_buf.release();
     sys->recv_buf.release();
     if (sys->ev_start) (void)hipEventDestroy(sys->ev_start);

@@ -426,18 +426,25 @@ def test_slab_with_rccl_self_exchange(api, solver_cls):
     from bodge_amd import slab
     from bodge_amd.solver import Communicator
 
-    system = systems.random_periodic(api, shape=(6, 4, 3), seed=5)
+    system = systems.random_periodic(api, shape=(40, 4, 3), seed=5)  # 480 rows: interior and boundary tiles
     indptr, indices, data = system.bsr_arrays()
     plan = slab.build_plan(indptr, indices, data, np.array([0, system.lattice.size]), 0, self_exchange=True)
     assert plan.halo_rows == 24
     bsr = system.matrix("bsr")
     scale = cheb_ref.spectral_bound(bsr)
     comm = Communicator(0, 1, 0, Communicator.new_unique_id())
-    with solver_cls.from_slab_plan(plan, comm=comm) as dev:
-        got = dev.dots_random(scale, 16, 5, seed=8, kind=cheb_ref.VEC_Z4)
     ref = cheb_ref.recurrence_dots(bsr, scale, 32, cheb_ref.random_block(bsr.shape[0], 8, range(5), cheb_ref.VEC_Z4))
-    assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * bsr.shape[0])
-    assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * bsr.shape[0])
+    import os
+
+    for overlap in ("1", "0"):  # exchange hidden behind the interior rows / exchange then compute
+        os.environ["BODGE_AMD_OVERLAP"] = overlap
+        try:
+            with solver_cls.from_slab_plan(plan, comm=comm) as dev:
+                got = dev.dots_random(scale, 16, 5, seed=8, kind=cheb_ref.VEC_Z4)
+        finally:
+            del os.environ["BODGE_AMD_OVERLAP"]
+        assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * bsr.shape[0])
+        assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * bsr.shape[0])
     comm.close()
 
 
