@@ -716,13 +716,16 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
 
         const int i = row0 + s;
         const bool valid = i < a.nb;
-        // own entries of t_n: registers (dot products, diagonal block) and LDS (neighbour lanes)
-        double2 own[4];
+        // own entries of t_n go to LDS: read back by this lane (diagonal block, dot products) and
+        // by neighbouring lanes; not kept in registers (the kernel sits at the 128-VGPR step)
+        {
+            double2 own[4];
 #pragma unroll
-        for (int be = 0; be < 4; ++be)
-            own[be] = valid ? a.cur[vslot(be, (size_t)i, r, a.ncols, RL)] : make_double2(0.0, 0.0);
+            for (int be = 0; be < 4; ++be)
+                own[be] = valid ? a.cur[vslot(be, (size_t)i, r, a.ncols, RL)] : make_double2(0.0, 0.0);
 #pragma unroll
-        for (int be = 0; be < 4; ++be) share[lane * 4 + be] = own[be];
+            for (int be = 0; be < 4; ++be) share[lane * 4 + be] = own[be];
+        }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
@@ -773,7 +776,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
                 nx.x = fma(ls.c.x, acc[al].x, -(ls.s.x * p.x));
                 nx.y = fma(ls.c.y, acc[al].y, -(ls.s.y * p.y));
                 a.prev[slot_own] = nx;
-                Mode::dots(dot, own[al], nx);
+                Mode::dots(dot, share[lane * 4 + al], nx);
             }
         }
         // the next tile overwrites `share`; same-wave LDS ops are ordered
