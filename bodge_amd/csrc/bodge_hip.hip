@@ -119,6 +119,7 @@ struct bdg_system {
     DeviceBuffer<double2> packed[4];   // re-packed blocks per storage mode, built on first use
     bool is_real = false;              // imag(H) == 0 everywhere (checked at upload)
     bool is_ph = false;                // every block is [[A, B], [C, -conj(A)]] (checked at upload)
+    double gershgorin = 0.0;           // max over scalar rows of sum |H_rc| (bound on |H|)
     // dictionary form: the distinct blocks and one id per stored block (0 entries = not used)
     int n_unique = 0;
     DeviceBuffer<int> dict_ids;
@@ -1207,6 +1208,68 @@ int lanczos_advance(bdg_system* sys, int n_iter, double* alpha_out, double* beta
     return BDG_OK;
 }
 
+// ------------------------------------------------------------- dense eigensolver
+// One-sided Jacobi on the GPU for matrices up to kJacobiLimit (no external library: the first
+// use of rocSOLVER on a fresh machine pages in ~1 GB and was measured at 1.5-7.5 minutes).
+constexpr int64_t kJacobiLimit = 4096;
+
+int eigh_jacobi(bdg_system* sys, double* w_out, double* z_out) {
+    const int64_t n = 4 * sys->nb;
+    hipStream_t st = sys->stream;
+    DeviceBuffer<double2> G, V;
+    DeviceBuffer<double> eig;
+    DeviceBuffer<int> counter;
+    auto body = [&]() -> int {
+        if (int rc = G.reserve((size_t)n * n)) return rc;
+        if (z_out)
+            if (int rc = V.reserve((size_t)n * n)) return rc;
+        if (int rc = eig.reserve((size_t)n)) return rc;
+        if (int rc = counter.reserve(1)) return rc;
+        const double shift = 1.5 * sys->gershgorin + 1.0;  // spectrum of G in [0.5 b + 1, 2.5 b + 1]
+        HIP_TRY(hipMemsetAsync(G.ptr, 0, sizeof(double2) * n * n, st));
+        bdg::scatter_dense<<<(unsigned)sys->nb, 128, 0, st>>>(sys->indptr.ptr, sys->indices.ptr,
+                                                               sys->blocks.ptr, G.ptr, (int)sys->nb);
+        bdg::jacobi_setup<<<(unsigned)std::min<int64_t>(4096, (n * n + 255) / 256), 256, 0, st>>>(
+            G.ptr, z_out ? V.ptr : nullptr, (int)n, shift);
+        HIP_TRY(hipGetLastError());
+        const int max_sweeps = 40;
+        int sweep = 0;
+        for (; sweep < max_sweeps; ++sweep) {
+            HIP_TRY(hipMemsetAsync(counter.ptr, 0, sizeof(int), st));
+            for (int round = 0; round < n - 1; ++round)
+                bdg::jacobi_round<<<(unsigned)(n / 2), 256, 0, st>>>(G.ptr, z_out ? V.ptr : nullptr, (int)n,
+                                                                      round, 1e-15, counter.ptr);
+            int rotations = 0;
+            HIP_TRY(hipMemcpyAsync(&rotations, counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
+            HIP_TRY(hipStreamSynchronize(st));
+            if (rotations == 0) break;
+        }
+        if (sweep == max_sweeps) return fail(BDG_ELIBRARY, "Jacobi eigensolver did not converge in %d sweeps", max_sweeps);
+        bdg::jacobi_eigenvalues<<<(unsigned)n, 256, 0, st>>>(G.ptr, (int)n, shift, eig.ptr);
+        HIP_TRY(hipGetLastError());
+        std::vector<double> vals((size_t)n);
+        HIP_TRY(hipMemcpyAsync(vals.data(), eig.ptr, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        std::vector<int64_t> order((size_t)n);
+        for (int64_t i = 0; i < n; ++i) order[(size_t)i] = i;
+        std::sort(order.begin(), order.end(), [&](int64_t a, int64_t b) { return vals[(size_t)a] < vals[(size_t)b]; });
+        for (int64_t i = 0; i < n; ++i) w_out[i] = vals[(size_t)order[(size_t)i]];
+        if (z_out) {
+            std::vector<double> cols((size_t)2 * n * n);
+            HIP_TRY(hipMemcpy(cols.data(), V.ptr, sizeof(double2) * n * n, hipMemcpyDeviceToHost));
+            for (int64_t i = 0; i < n; ++i)
+                memcpy(z_out + 2 * n * i, cols.data() + 2 * n * order[(size_t)i], sizeof(double) * 2 * n);
+        }
+        return BDG_OK;
+    };
+    const int rc = body();
+    G.release();
+    V.release();
+    eig.release();
+    counter.release();
+    return rc;
+}
+
 }  // namespace
 
 // =========================================================================== ABI
@@ -1261,6 +1324,14 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     }
     bool is_real = true;
     for (int64_t q = 0; q < nnzb * 16 && is_real; ++q) is_real = data[2 * q + 1] == 0.0;
+    double gershgorin = 0.0;
+    for (int64_t i = 0; i < nb; ++i) {
+        double row_sum[4] = {0.0, 0.0, 0.0, 0.0};
+        for (int k = indptr[i]; k < indptr[i + 1]; ++k)
+            for (int e = 0; e < 16; ++e)
+                row_sum[e >> 2] += std::hypot(data[2 * ((int64_t)k * 16 + e)], data[2 * ((int64_t)k * 16 + e) + 1]);
+        for (double v : row_sum) gershgorin = std::max(gershgorin, v);
+    }
     // particle-hole form: lower-right 2x2 == -conj(upper-left 2x2), exactly, in every block
     bool is_ph = true;
     for (int64_t k = 0; k < nnzb && is_ph; ++k)
@@ -1322,6 +1393,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     }
     sys->is_real = is_real;
     sys->is_ph = is_ph;
+    sys->gershgorin = gershgorin;
     hipDeviceProp_t prop;
     auto cleanup = [&](int rc) {
         bdg_destroy(sys);
@@ -1650,9 +1722,14 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     if (!sys || !w_out) return fail(BDG_EINVAL, "null argument");
     if (sys->ncols != sys->nb) return fail(BDG_EINVAL, "bdg_eigh_dense needs a whole (square) matrix, not a slab");
     HIP_TRY(hipSetDevice(sys->device));
+    const int64_t n = 4 * sys->nb;
+    {
+        const char* forced = getenv("BODGE_AMD_EIGH");
+        const bool own = forced ? std::string(forced) == "jacobi" : n <= kJacobiLimit;
+        if (own) return eigh_jacobi(sys, w_out, z_out);
+    }
     SolverApi* api = nullptr;
     if (int rc = load_solver(&api)) return rc;
-    const int64_t n = 4 * sys->nb;
     if (n > 46000) return fail(BDG_EINVAL, "dense path limited to 4*nb <= 46000 (32-bit LAPACK sizes)");
     DeviceBuffer<double2> dense;
     DeviceBuffer<double> eig, offdiag;
@@ -1711,7 +1788,7 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
         if (api->set_stream(handle, sys->stream) != rocblas_status_success)
             return fail(BDG_ELIBRARY, "rocblas_set_stream failed");
         const char* forced = getenv("BODGE_AMD_EIGH");
-        if (forced && *forced) return attempt(forced);
+        if (forced && *forced && std::string(forced) != "rocsolver") return attempt(forced);
         // zheevd is the fast driver, but on ROCm 7.2 / gfx950 its eigenvectors come back
         // NaN for spectra with exact degeneracies (measured: profiles/r01_eigh_probe.log);
         // eigenvalues are unaffected.  Verify, and redo with the Jacobi driver if needed.

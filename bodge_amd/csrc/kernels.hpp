@@ -15,7 +15,8 @@
 // K2  reduce_partials fixed-order sum of the per-workgroup dot partials (bit reproducible).
 // K3  fill_random / fill_unit / zero   start vectors from a counter-based generator.
 // K4  halo_pack / halo_unpack   t_n rows exchanged between row slabs (multi-GPU slab mode).
-// K5  scatter_dense   BSR -> dense column-major for the rocSOLVER path.
+// K5  scatter_dense   BSR -> dense column-major for the dense eigensolvers.
+// K6  jacobi_*        one-sided Jacobi eigensolver for small Hermitian matrices (no rocSOLVER load).
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -968,6 +969,119 @@ __global__ void scatter_dense(const int* __restrict__ indptr, const int* __restr
         const int64_t col = 4 * (int64_t)indices[k] + (el & 3);
         dense[col * n + row] = blocks[(size_t)k * 16 + el];
     }
+}
+
+// ------------------------------------------------------------------------ K6
+// Dense Hermitian eigensolver for small matrices: one-sided (Hestenes) Jacobi on the columns
+// of G = A = H + shift*I (positive definite for shift > |H|), accumulating the rotations in V.
+// At convergence the columns of G are orthogonal, G = A V, so column p of V is an eigenvector
+// and |g_p| - shift its eigenvalue.  One launch = one round of the round-robin tournament:
+// n/2 disjoint column pairs, one workgroup per pair (no races, no atomics on the data).
+//   c = g_p^H g_q = |c| e^{iφ},  ζ = (|g_q|² - |g_p|²) / (2|c|),  t = sign(ζ) / (|ζ| + sqrt(1+ζ²))
+//   g_p' = cs g_p - sn e^{-iφ} g_q,   g_q' = sn e^{iφ} g_p + cs g_q          (same for V)
+__device__ inline void jacobi_pair(int n, int round, int k, int& p, int& q) {
+    // circle method: player n-1 stays, the others rotate
+    const int m = n - 1;
+    if (k == 0) {
+        p = m;
+        q = round % m;
+    } else {
+        p = (round + k) % m;
+        q = (round - k + m) % m;
+    }
+}
+
+__global__ __launch_bounds__(256) void jacobi_round(double2* __restrict__ G, double2* __restrict__ V, int n,
+                                                    int round, double tol, int* __restrict__ rotations) {
+    __shared__ double red[4][256];
+    __shared__ double rot[4];  // cs, sn, cos φ, sin φ  (sn = 0: skip)
+    int p, q;
+    jacobi_pair(n, round, blockIdx.x, p, q);
+    double2* gp = G + (size_t)p * n;
+    double2* gq = G + (size_t)q * n;
+    double a = 0.0, b = 0.0, cr = 0.0, ci = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const double2 x = gp[i], y = gq[i];
+        a = fma(x.x, x.x, fma(x.y, x.y, a));
+        b = fma(y.x, y.x, fma(y.y, y.y, b));
+        cr = fma(x.x, y.x, fma(x.y, y.y, cr));   // Re conj(x) y
+        ci = fma(x.x, y.y, fma(-x.y, y.x, ci));  // Im conj(x) y
+    }
+    red[0][threadIdx.x] = a;
+    red[1][threadIdx.x] = b;
+    red[2][threadIdx.x] = cr;
+    red[3][threadIdx.x] = ci;
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) red[c][threadIdx.x] += red[c][threadIdx.x + stride];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const double aa = red[0][0], bb = red[1][0], re = red[2][0], im = red[3][0];
+        const double mag = sqrt(re * re + im * im);
+        if (mag <= tol * sqrt(aa * bb) || mag == 0.0) {
+            rot[1] = 0.0;
+        } else {
+            const double zeta = (bb - aa) / (2.0 * mag);
+            const double t = (zeta >= 0.0 ? 1.0 : -1.0) / (fabs(zeta) + sqrt(1.0 + zeta * zeta));
+            const double cs = 1.0 / sqrt(1.0 + t * t);
+            rot[0] = cs;
+            rot[1] = cs * t;
+            rot[2] = re / mag;
+            rot[3] = im / mag;
+            atomicAdd(rotations, 1);
+        }
+    }
+    __syncthreads();
+    const double sn = rot[1];
+    if (sn == 0.0) return;
+    const double cs = rot[0], er = rot[2], ei = rot[3];
+    // s1 = sn e^{-iφ} (multiplies column q into p), s2 = sn e^{iφ} (multiplies column p into q)
+    const double s1r = sn * er, s1i = -sn * ei, s2r = sn * er, s2i = sn * ei;
+    for (int pass = 0; pass < 2; ++pass) {
+        double2* xp = pass == 0 ? gp : (V ? V + (size_t)p * n : nullptr);
+        double2* xq = pass == 0 ? gq : (V ? V + (size_t)q * n : nullptr);
+        if (!xp) break;
+        for (int i = threadIdx.x; i < n; i += 256) {
+            const double2 x = xp[i], y = xq[i];
+            double2 nx, ny;
+            nx.x = cs * x.x - (s1r * y.x - s1i * y.y);
+            nx.y = cs * x.y - (s1r * y.y + s1i * y.x);
+            ny.x = (s2r * x.x - s2i * x.y) + cs * y.x;
+            ny.y = (s2r * x.y + s2i * x.x) + cs * y.y;
+            xp[i] = nx;
+            xq[i] = ny;
+        }
+    }
+}
+
+// G += shift * I;  V = I (if given)
+__global__ void jacobi_setup(double2* __restrict__ G, double2* __restrict__ V, int n, double shift) {
+    const int64_t total = (int64_t)n * n;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const bool diag = (idx / n) == (idx % n);
+        if (diag) G[idx].x += shift;
+        if (V) V[idx] = make_double2(diag ? 1.0 : 0.0, 0.0);
+    }
+}
+
+// eig[p] = |g_p| - shift, one block per column
+__global__ __launch_bounds__(256) void jacobi_eigenvalues(const double2* __restrict__ G, int n, double shift,
+                                                          double* __restrict__ eig) {
+    __shared__ double red[256];
+    const double2* g = G + (size_t)blockIdx.x * n;
+    double a = 0.0;
+    for (int i = threadIdx.x; i < n; i += 256) a = fma(g[i].x, g[i].x, fma(g[i].y, g[i].y, a));
+    red[threadIdx.x] = a;
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) red[threadIdx.x] += red[threadIdx.x + stride];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) eig[blockIdx.x] = sqrt(red[0]) - shift;
 }
 
 // planar [4][nb][rv] column r  <->  site-major [nb][4]

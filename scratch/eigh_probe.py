@@ -2,7 +2,7 @@ import os, sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np
 import bodge_amd as ba, systems
-for algo in ("evd", "ev", "evj"):
+for algo in ("jacobi", "evd", "evj"):
     os.environ["BODGE_AMD_EIGH"] = algo
     for name in ("complex235", "barrier", "random357", "snf", "swave20"):
         s = systems.CATALOG[name]["build"](ba, **systems.CATALOG[name]["kwargs"])

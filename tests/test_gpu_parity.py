@@ -7,6 +7,8 @@ Tolerances (fp64 throughout):
 * eigenvalues                   1e-10 absolute (pattern of ref tests/test_hamiltonian.py:411-413)
 """
 
+import os
+
 import numpy as np
 import pytest
 
@@ -336,6 +338,29 @@ def test_diagonalize_matches_reference(api, golden, name):
             assert np.allclose(shaped[n, site, :], vecs[4 * site : 4 * site + 4, n])
     with pytest.raises(Exception):
         system.diagonalize(format="foo")
+
+
+@pytest.mark.skipif(os.environ.get("BODGE_AMD_TEST_ROCSOLVER") != "1",
+                    reason="first rocSOLVER use pages in ~1 GB (1.5-7.5 min on a fresh box); set "
+                           "BODGE_AMD_TEST_ROCSOLVER=1 to run; profiles/r01_eigh_probe.log has a recorded run")
+@pytest.mark.parametrize("name", ["complex235", "barrier"])
+def test_rocsolver_route_used_above_4096(api, golden, monkeypatch, name):
+    """The library route taken for 4N > 4096, forced here on small systems: zheevd, and its
+    NaN-eigenvector defect on degenerate spectra (barrier) caught and repaired with zheevj."""
+    monkeypatch.setenv("BODGE_AMD_EIGH", "evd")
+    system = _build(api, name)
+    vals, vecs = system.diagonalize(format="raw")
+    assert np.allclose(vals, golden.eigenvalues(name), rtol=0, atol=1e-10)
+    if name == "complex235":
+        dense = np.asarray(system.matrix("dense"))
+        assert np.allclose(dense @ vecs, vecs * vals, atol=1e-9)
+    else:
+        assert np.isnan(vecs).any()  # forced evd shows the defect; the default route checks and falls back
+    monkeypatch.delenv("BODGE_AMD_EIGH")
+    monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")
+    vals2, vecs2 = system.diagonalize(format="raw")
+    dense = np.asarray(system.matrix("dense"))
+    assert np.isfinite(vecs2).all() and np.allclose(dense @ vecs2, vecs2 * vals2, atol=1e-9)
 
 
 def test_diagonalize_counts_2n_states(api):
