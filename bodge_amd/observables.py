@@ -2,15 +2,17 @@
 
 Routing (all device-side; there is no CPU path):
 
-* dense    BSR -> dense scatter kernel + rocSOLVER `zheevd` on the GPU.  Exact,
-           O((4N)^3); what the reference's `cuda=True` branch does with CuPy
-           (ref hamiltonian.py:206-221, :287-295).
+* dense    BSR -> dense scatter kernel + Hermitian eigensolver on the GPU (own
+           one-sided Jacobi kernels up to 4N = 4096, rocSOLVER `zheevd` above).
+           Exact, O((4N)^3); what the reference's `cuda=True` branch does with
+           CuPy (ref hamiltonian.py:206-221, :287-295).
 * chebyshev  kernel-polynomial expansion on the BSR matrix, O(N·M): the
            recurrence kernel advances R start vectors together; exact trace
            (every unit vector) for small systems, stochastic trace otherwise.
 
 `method="auto"` picks dense while the matrix is small enough for it to be
-both exact and quick (4N <= DENSE_AUTO_LIMIT), Chebyshev beyond that.
+both exact and quick (4N <= DENSE_AUTO_LIMIT, served by the library-free Jacobi
+kernels; up to DENSE_AUTO_LIMIT_T0 at T = 0), Chebyshev beyond that.
 """
 
 from __future__ import annotations
@@ -20,7 +22,8 @@ import numpy as np
 from . import chebyshev as cheb
 from .backend import VEC_RADEMACHER, VEC_Z4
 
-DENSE_AUTO_LIMIT = 8192  # largest 4N routed to zheevd by method="auto"
+DENSE_AUTO_LIMIT = 4096  # largest 4N routed to the dense eigensolver by method="auto" (own Jacobi kernels)
+DENSE_AUTO_LIMIT_T0 = 16384  # at T = 0 the Chebyshev series converges only algebraically: stay dense longer
 EXACT_TRACE_LIMIT = 16384  # largest 4N for which "auto" uses every unit vector
 
 
@@ -63,7 +66,8 @@ def free_energy(
         raise ValueError("Expected non-negative temperature!")
     dim = system.shape[0]
     if method == "auto":
-        method = "dense" if dim <= DENSE_AUTO_LIMIT else "chebyshev"
+        limit = DENSE_AUTO_LIMIT_T0 if temperature == 0 else DENSE_AUTO_LIMIT
+        method = "dense" if dim <= limit else "chebyshev"
     if method == "chebyshev" and not system.has_symmetric_spectrum(1e-12):
         # Σ_{ε>0} g(ε) equals a trace of a smooth function only for a ±-symmetric spectrum
         raise RuntimeError(
