@@ -12,4 +12,6 @@ container where `/root/reference` exists; outputs in `tests/golden/*.json|npz`).
 `oracle.cheb_ref` (the Chebyshev path, which the reference does not contain) is
 pinned transitively: its exact-trace free energy and its resolvent LDOS must
 reproduce those same goldens to the tolerances stated in `tests/test_oracle.py`.
+`oracle.cheb_c` (C + OpenMP recurrence step, the multi-threaded CPU baseline) is
+checked against `oracle.cheb_ref` there as well.
 """

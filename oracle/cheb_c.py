@@ -1,0 +1,115 @@
+"""ctypes wrapper of oracle/cheb_c.c (C + OpenMP restatement of the recurrence).
+
+TEST INFRASTRUCTURE ONLY - see oracle/__init__.py.  `build()` compiles the shared object into
+oracle/_build/ (git-ignored; it travels with the tree like the HIP library).
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import shutil
+import subprocess
+import time
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+SOURCE = os.path.join(HERE, "cheb_c.c")
+LIBRARY = os.path.join(HERE, "_build", "libcheb_c.so")
+_lib = None
+
+
+def build(force: bool = False) -> str:
+    if not force and os.path.exists(LIBRARY) and os.path.getmtime(LIBRARY) >= os.path.getmtime(SOURCE):
+        return LIBRARY
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        raise RuntimeError("gcc not found")
+    os.makedirs(os.path.dirname(LIBRARY), exist_ok=True)
+    tmp = f"{LIBRARY}.{os.getpid()}.tmp"
+    subprocess.run([gcc, "-O3", "-mavx2", "-mfma", "-fopenmp", "-shared", "-fPIC", "-o", tmp, SOURCE], check=True)
+    os.replace(tmp, LIBRARY)
+    return LIBRARY
+
+
+def load():
+    global _lib
+    if _lib is None:
+        build()
+        _lib = C.CDLL(LIBRARY)
+        f64p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
+        for name in ("cheb_c_step_complex", "cheb_c_step_real"):
+            fn = getattr(_lib, name)
+            fn.restype = None
+            fn.argtypes = [C.c_int64, i32p, i32p, f64p, C.c_int, C.c_double, f64p, f64p, f64p, f64p]
+        _lib.cheb_c_threads.restype = C.c_int
+        _lib.cheb_c_set_threads.argtypes = [C.c_int]
+    return _lib
+
+
+def threads() -> int:
+    return load().cheb_c_threads()
+
+
+def set_threads(n: int) -> None:
+    load().cheb_c_set_threads(int(n))
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class Recurrence:
+    """State of one run: t_cur, t_prev as (4N, R) arrays; `step(coef)` advances in place."""
+
+    def __init__(self, bsr, start: np.ndarray, real: bool = False):
+        self.lib = load()
+        self.nb = bsr.shape[0] // 4
+        self.indptr = np.ascontiguousarray(bsr.indptr, dtype=np.int32)
+        self.indices = np.ascontiguousarray(bsr.indices, dtype=np.int32)
+        self.real = real
+        if real:
+            self.blocks = np.ascontiguousarray(bsr.data.real, dtype=np.float64)
+            self.cur = np.array(start.real, dtype=np.float64, order="C")
+        else:
+            self.blocks = np.ascontiguousarray(bsr.data, dtype=np.complex128)
+            self.cur = np.array(start, dtype=np.complex128, order="C")  # private copy: steps overwrite it
+        self.prev = np.zeros_like(self.cur)
+        self.R = self.cur.shape[1]
+
+    def step(self, coef: float):
+        d, e = np.empty(self.R), np.empty(self.R)
+        fn = self.lib.cheb_c_step_real if self.real else self.lib.cheb_c_step_complex
+        view = (lambda a: a) if self.real else (lambda a: a.view(np.float64))
+        fn(self.nb, _p(self.indptr, C.c_int32), _p(self.indices, C.c_int32), _p(view(self.blocks), C.c_double),
+           self.R, float(coef), _p(view(self.cur), C.c_double), _p(view(self.prev), C.c_double),
+           _p(d, C.c_double), _p(e, C.c_double))
+        self.cur, self.prev = self.prev, self.cur  # t_next was written over t_prev
+        return d, e
+
+
+def recurrence_dots(bsr, scale: float, n_moments: int, start: np.ndarray, real: bool = False):
+    """Same contract as cheb_ref.recurrence_dots, computed by the C code."""
+    steps = n_moments // 2
+    run = Recurrence(bsr, start, real)
+    d, e = np.empty((steps, run.R)), np.empty((steps, run.R))
+    for n in range(steps):
+        d[n], e[n] = run.step((1.0 if n == 0 else 2.0) / scale)
+    return d, e
+
+
+def time_recurrence(bsr, scale, start, seconds: float = 8.0, real: bool = False, warmup: int = 2):
+    """(vector_steps_per_second, block_steps_timed, threads) of the OpenMP recurrence on this host."""
+    run = Recurrence(bsr, start, real)
+    run.step(1.0 / scale)
+    done, t0 = 0, None
+    while True:
+        if done == warmup:
+            t0 = time.perf_counter()
+        run.step(2.0 / scale)
+        done += 1
+        if t0 is not None and time.perf_counter() - t0 >= seconds:
+            break
+    elapsed = time.perf_counter() - t0
+    return (done - warmup) * run.R / elapsed, done - warmup, threads()

@@ -151,3 +151,26 @@ def test_spectral_bound_encloses_spectrum(api, golden):
         bound = cheb_ref.spectral_bound(spec["build"](api, **spec["kwargs"]).matrix("bsr"))
         assert bound > golden.values[name]["e_max"]
         assert bound < 2.5 * golden.values[name]["e_max"]
+
+
+@pytest.mark.parametrize("name", ["random357", "complex235", "swave20_zeeman"])
+def test_c_restatement_matches_numpy_oracle(api, name):
+    """oracle/cheb_c.c (the multi-threaded CPU baseline) reproduces the numpy recurrence."""
+    from oracle import cheb_c
+
+    spec = systems.CATALOG[name]
+    bsr = spec["build"](api, **spec["kwargs"]).matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    start = cheb_ref.random_block(bsr.shape[0], 5, range(6), cheb_ref.VEC_Z4)
+    keep = start.copy()
+    d_ref, e_ref = cheb_ref.recurrence_dots(bsr, scale, 48, start)
+    for threads in (1, 3):
+        cheb_c.set_threads(threads)
+        d, e = cheb_c.recurrence_dots(bsr, scale, 48, start)
+        assert np.array_equal(start, keep)
+        assert np.abs(d - d_ref).max() < 1e-11 and np.abs(e - e_ref).max() < 1e-11
+    if not np.iscomplexobj(bsr.data) or np.abs(bsr.data.imag).max() == 0:
+        real_start = cheb_ref.random_block(bsr.shape[0], 5, range(6))
+        d_ref, e_ref = cheb_ref.recurrence_dots(bsr, scale, 48, real_start)
+        d, e = cheb_c.recurrence_dots(bsr, scale, 48, real_start, real=True)
+        assert np.abs(d - d_ref).max() < 1e-11 and np.abs(e - e_ref).max() < 1e-11
