@@ -432,6 +432,8 @@ int ensure_blocks(bdg_system* sys, const ModeInfo& mode, const void** out) {
 
 // Matrix-side kernel arguments for `plan` (block data or dictionary, sizes).  Every launch of
 // a step kernel goes through here so that no pointer the chosen kernel reads is left unset.
+constexpr size_t kStreamVectorBytes = (size_t)256 << 20;
+
 int matrix_args(bdg_system* sys, const StepPlan& plan, bdg::StepArgs* args) {
     *args = bdg::StepArgs{};
     args->indptr = sys->indptr.ptr;
@@ -635,6 +637,7 @@ struct Batch {
     StepPlan plan;
     bdg::StepArgs args{};
     bool real = false;
+    bool alternate = false;  // dictionary kernel: sweep direction flips every launch
     ModeInfo mode{};
     int rl = 0, rv = 0, n_active = 0, n_steps = 0, chunk = 1, strip_rows = 0;
     size_t width = 0, per_step = 0, vec_count = 0;
@@ -671,6 +674,14 @@ struct Batch {
         if (int rc = matrix_args(sys, plan, &args)) return rc;
 
         vec_count = (size_t)4 * sys->ncols * rl;  // 16-byte lane payloads
+        // t_n and t_{n-1} together beyond the 256 MB Infinity Cache: the write of t_{n+1} and the
+        // read of t_{n-1} are hinted non-temporal (+6 % at 10^6 sites x 8 vectors); smaller buffers
+        // stay resident from one launch to the next and are faster with plain accesses
+        // (profiles/r01_stream_probe.log)
+        args.stream_vectors = 2 * vec_count * sizeof(double2) > kStreamVectorBytes ? 3 : 0;
+        if (const char* env = std::getenv("BODGE_AMD_STREAM_VECTORS")) args.stream_vectors = std::atoi(env);
+        alternate = true;
+        if (const char* env = std::getenv("BODGE_AMD_ALTERNATE")) alternate = std::atoi(env) != 0;
         if (int rc = sys->vec_a.reserve(vec_count)) return rc;
         if (int rc = sys->vec_b.reserve(vec_count)) return rc;
         width = (size_t)2 * rv;
@@ -910,6 +921,7 @@ struct Batch {
         args.prev = prev;
         args.coef = (n == 0 ? 1.0 : 2.0) / scale;
         args.partial = sys->partial.ptr + (size_t)in_chunk * per_step;
+        args.reverse = alternate ? (n & 1) : 0;
         plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
         std::swap(cur, prev);
         if (in_chunk == chunk - 1 || n == n_steps - 1) {

@@ -40,6 +40,13 @@ __device__ inline double2 load_stream(const double2* p) {
     return make_double2(v.x, v.y);
 }
 
+__device__ inline void store_stream(double2* p, double2 v) {
+    v2d w;
+    w.x = v.x;
+    w.y = v.y;
+    __builtin_nontemporal_store(w, reinterpret_cast<v2d*>(p));
+}
+
 // Flat slot of (component alpha, block row `site`, lane payload r) in a vector buffer
 // with rv payloads per (site, component).  Planar: one plane per component.
 #ifndef BDG_LAYOUT_INTERLEAVED
@@ -198,6 +205,13 @@ struct StepArgs {
     int ncols;    // block rows of the vector buffers (owned + halo); == nb without slabs
     int n_tiles;  // workgroup tiles of 4 * (64/RL) block rows
     int max_row_blocks;
+    // dictionary kernel: 1 = t_{n-1} loads and t_{n+1} stores carry the non-temporal hint (vector
+    // buffers larger than the Infinity Cache), 0 = plain (buffers that stay cache resident)
+    int stream_vectors;
+    // dictionary kernel: 1 = sweep the tiles of each XCD range back to front.  Alternating the
+    // direction from one launch to the next re-reads first what the previous launch touched last,
+    // i.e. what the Infinity Cache still holds.
+    int reverse;
 };
 
 // Arithmetic modes.  A lane's 16-byte payload is either one complex number of
@@ -683,7 +697,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
     const int t_hi = (int)(((int64_t)a.n_tiles * (xcd + 1)) >> 3);
     auto first_row = [&](int t) {
         if (t >= t_hi) return a.nb;
-        const int tile = a.tile_order ? a.tile_order[t] : t;
+        const int tt = a.reverse ? t_lo + t_hi - 1 - t : t;
+        const int tile = a.tile_order ? a.tile_order[tt] : tt;
         return (tile * kWavesPerBlock + wave) * RW;
     };
     // one word per stored block: column in the low 24 bits, table index in the high 8
@@ -744,7 +759,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
             for (int al = 0; al < 4; ++al) acc[al] = make_double2(0.0, 0.0);
             if (meta.len > 0 && source(meta.word[0]) == kWave) {
 #pragma unroll
-                for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, col_of(meta.word[0]), r, a.ncols, RL)];
+                for (int be = 0; be < 4; ++be)
+                    xn[be] = a.cur[vslot(be, col_of(meta.word[0]), r, a.ncols, RL)];
             }
 #pragma unroll
             for (int q = 0; q < MAXB; ++q) {
@@ -769,15 +785,28 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
             // Chebyshev instantiations compile to the plain coef * acc - prev
             const LaneScalars ls = COLS ? lane_scalars<Mode::kVec>(a.coef, a.col_coef, a.col_pscale, r)
                                         : lane_scalars<Mode::kVec>(a.coef, nullptr, nullptr, r);
+            double2 p[4];
+            if (a.stream_vectors & 1) {
+#pragma unroll
+                for (int al = 0; al < 4; ++al) p[al] = load_stream(a.prev + vslot(al, (size_t)i, r, a.ncols, RL));
+            } else {
+#pragma unroll
+                for (int al = 0; al < 4; ++al) p[al] = a.prev[vslot(al, (size_t)i, r, a.ncols, RL)];
+            }
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
-                const size_t slot_own = vslot(al, (size_t)i, r, a.ncols, RL);
-                const double2 p = a.prev[slot_own];
                 double2 nx;
-                nx.x = fma(ls.c.x, acc[al].x, -(ls.s.x * p.x));
-                nx.y = fma(ls.c.y, acc[al].y, -(ls.s.y * p.y));
-                a.prev[slot_own] = nx;
+                nx.x = fma(ls.c.x, acc[al].x, -(ls.s.x * p[al].x));
+                nx.y = fma(ls.c.y, acc[al].y, -(ls.s.y * p[al].y));
+                p[al] = nx;
                 Mode::dots(dot, share[lane * 4 + al], nx);
+            }
+            if (a.stream_vectors & 2) {
+#pragma unroll
+                for (int al = 0; al < 4; ++al) store_stream(a.prev + vslot(al, (size_t)i, r, a.ncols, RL), p[al]);
+            } else {
+#pragma unroll
+                for (int al = 0; al < 4; ++al) a.prev[vslot(al, (size_t)i, r, a.ncols, RL)] = p[al];
             }
         }
         // the next tile overwrites `share`; same-wave LDS ops are ordered
