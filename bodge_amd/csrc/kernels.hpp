@@ -410,7 +410,8 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
     double dot[4] = {0.0, 0.0, 0.0, 0.0};
 
     for (int t = t_lo + slot; t < t_hi; t += slots) {
-        const int tile = a.tile_order ? a.tile_order[t] : t;
+        const int tt = a.reverse ? t_lo + t_hi - 1 - t : t;
+        const int tile = a.tile_order ? a.tile_order[tt] : tt;
         const int row0 = (tile * kWavesPerBlock + wave) * RW;
         if (row0 >= a.nb) continue;
         const int row_end = min(row0 + RW, a.nb);
@@ -469,12 +470,13 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
                 const size_t own = vslot(al, (size_t)i, r, a.ncols, RL);
-                const double2 p = a.prev[own];
+                const double2 p = (a.stream_vectors & 1) ? load_stream(a.prev + own) : a.prev[own];
                 const double2 c = a.cur[own];
                 double2 nx;
                 nx.x = fma(ls.c.x, acc[al].x, -(ls.s.x * p.x));
                 nx.y = fma(ls.c.y, acc[al].y, -(ls.s.y * p.y));
-                a.prev[own] = nx;
+                if (a.stream_vectors & 2) store_stream(a.prev + own, nx);
+                else a.prev[own] = nx;
                 Mode::dots(dot, c, nx);
             }
         }
@@ -528,7 +530,8 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
     // tile -> first block row of this wave (>= nb means "no work")
     auto first_row = [&](int t) {
         if (t >= t_hi) return a.nb;
-        const int tile = a.tile_order ? a.tile_order[t] : t;
+        const int tt = a.reverse ? t_lo + t_hi - 1 - t : t;
+        const int tile = a.tile_order ? a.tile_order[tt] : tt;
         return (tile * kWavesPerBlock + wave) * RW;
     };
 
@@ -629,12 +632,13 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
                 const size_t own = vslot(al, (size_t)i, r, a.ncols, RL);
-                const double2 p = a.prev[own];
+                const double2 p = (a.stream_vectors & 1) ? load_stream(a.prev + own) : a.prev[own];
                 const double2 c = a.cur[own];
                 double2 nx;
                 nx.x = fma(ls.c.x, acc[al].x, -(ls.s.x * p.x));
                 nx.y = fma(ls.c.y, acc[al].y, -(ls.s.y * p.y));
-                a.prev[own] = nx;
+                if (a.stream_vectors & 2) store_stream(a.prev + own, nx);
+                else a.prev[own] = nx;
                 Mode::dots(dot, c, nx);
             }
         }

@@ -1,5 +1,5 @@
 #!/bin/bash
-for lat in 1000,1000,1 1400,1400,1; do
-  echo "== $lat"
-  timeout -k 10 200 python3 scratch/kbench.py "s0=BODGE_AMD_STREAM_VECTORS=0" "s1_prev=BODGE_AMD_STREAM_VECTORS=1" "s2_store=BODGE_AMD_STREAM_VECTORS=2" "s3_both=BODGE_AMD_STREAM_VECTORS=3" --lattice $lat || exit 1
-done
+V="old=BODGE_AMD_STREAM_VECTORS=0,BODGE_AMD_ALTERNATE=0 alt=BODGE_AMD_STREAM_VECTORS=0,BODGE_AMD_ALTERNATE=1 stream_alt=BODGE_AMD_STREAM_VECTORS=3,BODGE_AMD_ALTERNATE=1 stream=BODGE_AMD_STREAM_VECTORS=3,BODGE_AMD_ALTERNATE=0"
+echo "== streamed real PH"; BODGE_AMD_DICT=0 timeout -k 10 200 python3 scratch/kbench.py $V || exit 1
+echo "== streamed complex PH"; BODGE_AMD_DICT=0 BODGE_AMD_REAL=0 timeout -k 10 200 python3 scratch/kbench.py $V || exit 1
+echo "== dict complex"; BODGE_AMD_REAL=0 timeout -k 10 200 python3 scratch/kbench.py $V || exit 1
