@@ -343,7 +343,8 @@ class Communicator:
                 time.sleep(0.05)
             with open(path, "rb") as fh:
                 uid = fh.read()
-        comm = cls(rank, world, local, uid)
+        # one process per GPU; more ranks than GPUs wrap around and RCCL reports the duplicate
+        comm = cls(rank, world, local % max(1, backend.device_count()), uid)
         comm.barrier()
         if rank == 0:
             try:
