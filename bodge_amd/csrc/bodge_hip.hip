@@ -528,6 +528,8 @@ struct SolverApi {
     decltype(&rocsolver_zheevd) zheevd = nullptr;
     decltype(&rocsolver_zheev) zheev = nullptr;
     decltype(&rocsolver_zheevj) zheevj = nullptr;
+    decltype(&rocsolver_dsyevd) dsyevd = nullptr;
+    decltype(&rocsolver_dsyevj) dsyevj = nullptr;
 };
 
 int load_solver(SolverApi** out) {
@@ -549,8 +551,10 @@ int load_solver(SolverApi** out) {
             api.zheevd = reinterpret_cast<decltype(api.zheevd)>(dlsym(api.solver, "rocsolver_zheevd"));
             api.zheev = reinterpret_cast<decltype(api.zheev)>(dlsym(api.solver, "rocsolver_zheev"));
             api.zheevj = reinterpret_cast<decltype(api.zheevj)>(dlsym(api.solver, "rocsolver_zheevj"));
+            api.dsyevd = reinterpret_cast<decltype(api.dsyevd)>(dlsym(api.solver, "rocsolver_dsyevd"));
+            api.dsyevj = reinterpret_cast<decltype(api.dsyevj)>(dlsym(api.solver, "rocsolver_dsyevj"));
             ok = api.create_handle && api.destroy_handle && api.set_stream && api.zheevd && api.zheev &&
-                 api.zheevj;
+                 api.zheevj && api.dsyevd && api.dsyevj;
         }
     }
     if (!ok) return fail(BDG_ELIBRARY, "rocSOLVER/rocBLAS could not be loaded: %s", dlerror());
@@ -1744,39 +1748,75 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     if (int rc = load_solver(&api)) return rc;
     if (n > 46000) return fail(BDG_EINVAL, "dense path limited to 4*nb <= 46000 (32-bit LAPACK sizes)");
     DeviceBuffer<double2> dense;
+    DeviceBuffer<double> dense_real;
     DeviceBuffer<double> eig, offdiag;
     DeviceBuffer<int> info;
     rocblas_handle handle = nullptr;
     const rocblas_evect evect = z_out ? rocblas_evect_original : rocblas_evect_none;
+    // imag(H) = 0 everywhere (checked at upload): real symmetric drivers, half the memory and a
+    // quarter of the arithmetic of the Hermitian ones (BASELINE config 5 names dsyevd).
+    bool real_route = sys->is_real;
+    if (const char* env = getenv("BODGE_AMD_EIGH_REAL")) real_route = real_route && atoi(env) != 0;
 
     // One attempt with the named rocSOLVER driver: "evd" divide & conquer, "evj" Jacobi, "ev" QL/QR.
     auto attempt = [&](const std::string& algo) -> int {
-        HIP_TRY(hipMemsetAsync(dense.ptr, 0, sizeof(double2) * n * n, sys->stream));
-        bdg::scatter_dense<<<(unsigned)sys->nb, 128, 0, sys->stream>>>(
-            sys->indptr.ptr, sys->indices.ptr, sys->blocks.ptr, dense.ptr, (int)sys->nb);
-        HIP_TRY(hipGetLastError());
-        auto* a_ptr = reinterpret_cast<rocblas_double_complex*>(dense.ptr);
         rocblas_status st;
-        if (algo == "ev") {
-            st = api->zheev(handle, evect, rocblas_fill_lower, (rocblas_int)n, a_ptr, (rocblas_int)n,
-                            eig.ptr, offdiag.ptr, info.ptr);
-        } else if (algo == "evj") {
-            // offdiag doubles as {residual, n_sweeps} scratch
-            st = api->zheevj(handle, rocblas_esort_ascending, evect, rocblas_fill_lower, (rocblas_int)n,
-                             a_ptr, (rocblas_int)n, 0.0, offdiag.ptr, 100,
-                             reinterpret_cast<rocblas_int*>(offdiag.ptr + 1), eig.ptr, info.ptr);
+        if (real_route) {
+            HIP_TRY(hipMemsetAsync(dense_real.ptr, 0, sizeof(double) * n * n, sys->stream));
+            bdg::scatter_dense_real<<<(unsigned)sys->nb, 128, 0, sys->stream>>>(
+                sys->indptr.ptr, sys->indices.ptr, sys->blocks.ptr, dense_real.ptr, (int)sys->nb);
+            HIP_TRY(hipGetLastError());
+            if (algo == "evj") {
+                st = api->dsyevj(handle, rocblas_esort_ascending, evect, rocblas_fill_lower, (rocblas_int)n,
+                                 dense_real.ptr, (rocblas_int)n, 0.0, offdiag.ptr, 100,
+                                 reinterpret_cast<rocblas_int*>(offdiag.ptr + 1), eig.ptr, info.ptr);
+            } else if (algo == "evd") {
+                st = api->dsyevd(handle, evect, rocblas_fill_lower, (rocblas_int)n, dense_real.ptr,
+                                 (rocblas_int)n, eig.ptr, offdiag.ptr, info.ptr);
+            } else {
+                return fail(BDG_EINVAL, "real symmetric route has drivers evd and evj, not '%s'", algo.c_str());
+            }
         } else {
-            st = api->zheevd(handle, evect, rocblas_fill_lower, (rocblas_int)n, a_ptr, (rocblas_int)n,
-                             eig.ptr, offdiag.ptr, info.ptr);
+            HIP_TRY(hipMemsetAsync(dense.ptr, 0, sizeof(double2) * n * n, sys->stream));
+            bdg::scatter_dense<<<(unsigned)sys->nb, 128, 0, sys->stream>>>(
+                sys->indptr.ptr, sys->indices.ptr, sys->blocks.ptr, dense.ptr, (int)sys->nb);
+            HIP_TRY(hipGetLastError());
+            auto* a_ptr = reinterpret_cast<rocblas_double_complex*>(dense.ptr);
+            if (algo == "ev") {
+                st = api->zheev(handle, evect, rocblas_fill_lower, (rocblas_int)n, a_ptr, (rocblas_int)n,
+                                eig.ptr, offdiag.ptr, info.ptr);
+            } else if (algo == "evj") {
+                // offdiag doubles as {residual, n_sweeps} scratch
+                st = api->zheevj(handle, rocblas_esort_ascending, evect, rocblas_fill_lower, (rocblas_int)n,
+                                 a_ptr, (rocblas_int)n, 0.0, offdiag.ptr, 100,
+                                 reinterpret_cast<rocblas_int*>(offdiag.ptr + 1), eig.ptr, info.ptr);
+            } else {
+                st = api->zheevd(handle, evect, rocblas_fill_lower, (rocblas_int)n, a_ptr, (rocblas_int)n,
+                                 eig.ptr, offdiag.ptr, info.ptr);
+            }
         }
         if (st != rocblas_status_success)
             return fail(BDG_ELIBRARY, "rocsolver eigensolver (%s) returned %d", algo.c_str(), (int)st);
         int host_info = 0;
         HIP_TRY(hipMemcpyAsync(&host_info, info.ptr, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
         HIP_TRY(hipMemcpyAsync(w_out, eig.ptr, sizeof(double) * n, hipMemcpyDeviceToHost, sys->stream));
-        if (z_out)
-            HIP_TRY(hipMemcpyAsync(z_out, dense.ptr, sizeof(double2) * n * n, hipMemcpyDeviceToHost,
-                                   sys->stream));
+        if (z_out) {
+            if (real_route) {
+                // real eigenvectors land in the back half of z_out and are widened in place
+                double* tmp = z_out + (size_t)n * n;
+                HIP_TRY(hipMemcpyAsync(tmp, dense_real.ptr, sizeof(double) * n * n, hipMemcpyDeviceToHost,
+                                       sys->stream));
+                HIP_TRY(hipStreamSynchronize(sys->stream));
+                for (size_t i = 0, total = (size_t)n * n; i < total; ++i) {
+                    const double v = tmp[i];
+                    z_out[2 * i] = v;
+                    z_out[2 * i + 1] = 0.0;
+                }
+            } else {
+                HIP_TRY(hipMemcpyAsync(z_out, dense.ptr, sizeof(double2) * n * n, hipMemcpyDeviceToHost,
+                                       sys->stream));
+            }
+        }
         HIP_TRY(hipStreamSynchronize(sys->stream));
         if (host_info != 0)
             return fail(BDG_ELIBRARY, "eigensolver (%s) did not converge (info=%d)", algo.c_str(), host_info);
@@ -1791,7 +1831,11 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
         return true;
     };
     auto body = [&]() -> int {
-        if (int rc = dense.reserve((size_t)n * n)) return rc;
+        if (real_route) {
+            if (int rc = dense_real.reserve((size_t)n * n)) return rc;
+        } else if (int rc = dense.reserve((size_t)n * n)) {
+            return rc;
+        }
         if (int rc = eig.reserve((size_t)std::max<int64_t>(n, 2))) return rc;
         if (int rc = offdiag.reserve((size_t)std::max<int64_t>(n, 2))) return rc;
         if (int rc = info.reserve(1)) return rc;
@@ -1813,6 +1857,7 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     int rc = body();
     if (handle) api->destroy_handle(handle);
     dense.release();
+    dense_real.release();
     eig.release();
     offdiag.release();
     info.release();

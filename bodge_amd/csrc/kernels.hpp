@@ -990,6 +990,19 @@ __global__ __launch_bounds__(256) void reduce_partials(const double* __restrict_
 }
 
 // ------------------------------------------------------------------------ K5
+// real parts only, for matrices with imag(H) = 0 (real symmetric eigensolver)
+__global__ void scatter_dense_real(const int* __restrict__ indptr, const int* __restrict__ indices,
+                                   const double2* __restrict__ blocks, double* __restrict__ dense, int nb) {
+    const int64_t n = 4 * (int64_t)nb;
+    const int i = blockIdx.x;
+    for (int k = indptr[i] + (threadIdx.x >> 4); k < indptr[i + 1]; k += blockDim.x >> 4) {
+        const int el = threadIdx.x & 15;
+        const int64_t row = 4 * (int64_t)i + (el >> 2);
+        const int64_t col = 4 * (int64_t)indices[k] + (el & 3);
+        dense[col * n + row] = blocks[(size_t)k * 16 + el].x;
+    }
+}
+
 // dense (column-major, n = 4 nb) gets every stored block; caller zero-fills first.
 __global__ void scatter_dense(const int* __restrict__ indptr, const int* __restrict__ indices,
                               const double2* __restrict__ blocks, double2* __restrict__ dense,

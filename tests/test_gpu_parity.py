@@ -345,22 +345,25 @@ def test_diagonalize_matches_reference(api, golden, name):
                            "BODGE_AMD_TEST_ROCSOLVER=1 to run; profiles/r01_eigh_probe.log has a recorded run")
 @pytest.mark.parametrize("name", ["complex235", "barrier"])
 def test_rocsolver_route_used_above_4096(api, golden, monkeypatch, name):
-    """The library route taken for 4N > 4096, forced here on small systems: zheevd, and its
-    NaN-eigenvector defect on degenerate spectra (barrier) caught and repaired with zheevj."""
+    """The library route taken for 4N > 4096, forced here on small systems: dsyevd when imag(H) = 0
+    (barrier), zheevd otherwise (complex235), and zheevd's NaN-eigenvector defect on degenerate
+    spectra caught and repaired with zheevj."""
     monkeypatch.setenv("BODGE_AMD_EIGH", "evd")
     system = _build(api, name)
+    dense = np.asarray(system.matrix("dense"))
     vals, vecs = system.diagonalize(format="raw")
     assert np.allclose(vals, golden.eigenvalues(name), rtol=0, atol=1e-10)
-    if name == "complex235":
-        dense = np.asarray(system.matrix("dense"))
-        assert np.allclose(dense @ vecs, vecs * vals, atol=1e-9)
-    else:
-        assert np.isnan(vecs).any()  # forced evd shows the defect; the default route checks and falls back
-    monkeypatch.delenv("BODGE_AMD_EIGH")
-    monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")
-    vals2, vecs2 = system.diagonalize(format="raw")
-    dense = np.asarray(system.matrix("dense"))
-    assert np.isfinite(vecs2).all() and np.allclose(dense @ vecs2, vecs2 * vals2, atol=1e-9)
+    assert np.isfinite(vecs).all() and np.allclose(dense @ vecs, vecs * vals, atol=1e-9)
+    if name == "barrier":
+        # the same real matrix through the Hermitian drivers: forced evd shows the defect,
+        # the default route ("rocsolver") checks for it and falls back to zheevj
+        monkeypatch.setenv("BODGE_AMD_EIGH_REAL", "0")
+        vals1, vecs1 = system.diagonalize(format="raw")
+        assert np.allclose(vals1, golden.eigenvalues(name), rtol=0, atol=1e-10)
+        assert np.isnan(vecs1).any()
+        monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")
+        vals2, vecs2 = system.diagonalize(format="raw")
+        assert np.isfinite(vecs2).all() and np.allclose(dense @ vecs2, vecs2 * vals2, atol=1e-9)
 
 
 def test_diagonalize_counts_2n_states(api):
