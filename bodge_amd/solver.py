@@ -345,7 +345,8 @@ class Communicator:
             with open(path, "rb") as fh:
                 uid = fh.read()
         # one process per GPU; more ranks than GPUs wrap around and RCCL reports the duplicate
-        comm = cls(rank, world, local % max(1, backend.device_count()), uid)
+        count = backend.device_count()
+        comm = cls(rank, world, local % count if count > 0 else local, uid)
         comm.barrier()
         if rank == 0:
             try:
