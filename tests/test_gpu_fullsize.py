@@ -127,3 +127,64 @@ def test_diagonal_hamiltonian_has_closed_form_free_energy(api, hip_library):
 
     estimate = system.free_energy(temperature, method="chebyshev", trace="stochastic", vectors=8, moments=256)
     assert np.isclose(estimate, exact, rtol=5e-3)
+
+
+def test_config2_200x200_256_moments_against_cpu_on_the_same_vectors(api, hip_library):
+    """configs[1] as SURVEY §8d C2 states it: (200,200,1) s-wave, M = 256, 64 Rademacher vectors,
+    seed 0.  The CPU restatement runs the same vectors: every moment within 1e-12 (relative to
+    mu_0 = 4N per vector), F within 1e-10 relative."""
+    from bodge_amd import chebyshev
+    from oracle import cheb_c
+
+    lattice = api.CubicLattice((200, 200, 1))
+    system = api.Hamiltonian(lattice)
+    with system as (H, Δ):
+        H.set_sites(3.0 * api.σ0)
+        Δ.set_sites(-0.1 * api.jσ2)
+        H.set_bonds(-1.0 * api.σ0)
+    bsr = system.matrix("bsr")
+    assert bsr.indices.size == 199_200
+    n, moments, vectors, temperature = bsr.shape[0], 256, 64, 0.5
+    scale = cheb_ref.spectral_bound(bsr)
+    start = cheb_ref.random_block(n, 0, range(vectors))
+    # numpy/scipy oracle on the first 8 vectors pins the C restatement, which then covers all 64
+    d8, e8 = cheb_ref.recurrence_dots(bsr, scale, moments, start[:, :8])
+    d_ref, e_ref = cheb_c.recurrence_dots(bsr, scale, moments, start, real=True)
+    assert np.allclose(d_ref[:, :8], d8, rtol=0, atol=1e-12 * n) and np.allclose(e_ref[:, :8], e8, rtol=0, atol=1e-12 * n)
+    d, e = system._solver().dots_random(scale, moments // 2, vectors, seed=0)  # cached solver, reused below
+    assert np.abs(d - d_ref).max() <= 1e-12 * n and np.abs(e - e_ref).max() <= 1e-12 * n
+    f_ref = chebyshev.free_energy_series(chebyshev.dots_to_moments(d_ref, e_ref).mean(axis=1), scale, temperature)
+    f_gpu = system.free_energy(temperature, method="chebyshev", moments=moments, vectors=vectors, seed=0,
+                               trace="stochastic")
+    assert abs(f_gpu - f_ref) <= 1e-10 * abs(f_ref)
+
+
+def test_config4_100cubed_dwave_slabs_match_the_whole_matrix(api, hip_library):
+    """configs[3]: (100,100,100) d-wave on all bonds, 8 row slabs of 12/13 x-planes with a halo
+    exchange per step (same-process transport on one GPU) against the undivided matrix, and the
+    first steps against the CPU oracle."""
+    from bodge_amd.solver import DeviceSolver, SlabGroup
+
+    lattice = api.CubicLattice((100, 100, 100))
+    system = api.Hamiltonian(lattice)
+    pairs = lattice.bond_array(coords=True)
+    with system as (H, Δ):
+        H.set_sites(3.0 * api.σ0)
+        H.set_bonds(-1.0 * api.σ0)
+        Δ.set_bonds(-0.1 * api.dwave()(pairs[:, 0], pairs[:, 1]))  # z bonds give 0 (ref tests/test_hamiltonian.py:249-251)
+    indptr, indices, data = system.bsr_arrays()
+    assert indices.size == 6_940_000  # 7 L^3 - 6 L^2 (SURVEY §8a)
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    steps, vectors = 12, 4
+    with DeviceSolver.from_hamiltonian(system) as whole:
+        mono = whole.dots_random(scale, steps, vectors, seed=4)
+    with SlabGroup.from_hamiltonian(system, 8) as group:
+        sizes = sorted(p.n_own // 10_000 for p in group.plans)
+        assert sizes == [12, 12, 12, 12, 13, 13, 13, 13]
+        assert all(p.halo_rows in (10_000, 20_000) for p in group.plans)
+        split = group.dots_random(scale, steps, vectors, seed=4)
+    n = bsr.shape[0]
+    assert np.allclose(split[0], mono[0], rtol=0, atol=1e-12 * n) and np.allclose(split[1], mono[1], rtol=0, atol=1e-12 * n)
+    ref = cheb_ref.recurrence_dots(bsr, scale, 4, cheb_ref.random_block(n, 4, range(vectors)))
+    assert np.allclose(mono[0][:2], ref[0], rtol=0, atol=1e-12 * n) and np.allclose(mono[1][:2], ref[1], rtol=0, atol=1e-12 * n)
