@@ -22,10 +22,17 @@ def spectral_bound(indptr: np.ndarray, data: np.ndarray, pad: float = 1.01) -> f
     n_sites = len(indptr) - 1
     if len(data) == 0:
         return 1.0
-    per_block = np.abs(data).sum(axis=2)  # (nnzb, 4)
-    owner = np.repeat(np.arange(n_sites), np.diff(indptr))
-    radius = np.zeros((n_sites, 4))
-    np.add.at(radius, owner, per_block)
+    if np.iscomplexobj(data) and not data.imag.any():
+        per_block = np.abs(data.real).sum(axis=2)  # same numbers as |z|, without the hypot pass
+    else:
+        per_block = np.abs(data).sum(axis=2)  # (nnzb, 4)
+    lengths = np.diff(indptr)
+    if lengths.min(initial=1) > 0:
+        radius = np.add.reduceat(per_block, indptr[:-1].astype(np.intp), axis=0)
+    else:  # empty rows break reduceat's segment convention
+        owner = np.repeat(np.arange(n_sites), lengths)
+        radius = np.zeros((n_sites, 4))
+        np.add.at(radius, owner, per_block)
     bound = float(radius.max())
     return pad * bound if bound > 0 else 1.0
 

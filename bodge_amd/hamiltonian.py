@@ -102,6 +102,8 @@ class Hamiltonian:
         self._revision = 0
         self._device = None
         self._device_revision = -1
+        self._memo: dict = {}
+        self._memo_revision = -1
 
     def _skeleton_pairs(self) -> tuple[np.ndarray, np.ndarray]:
         lattice = self.lattice
@@ -180,10 +182,13 @@ class Hamiltonian:
         off-diagonal part holds when the pairing obeys fermionic antisymmetry Δ_ij = -Δ_ji^T
         (singlet on-site terms, odd-parity triplet bond terms).  The Chebyshev free energy
         relies on it; the dense path and the LDOS do not."""
-        data = self._data
-        a = np.abs(data[:, 2:4, 2:4] + data[:, 0:2, 0:2].conj()).max(initial=0.0)
-        b = np.abs(data[:, 2:4, 0:2] + data[:, 0:2, 2:4].conj()).max(initial=0.0)
-        return bool(max(a, b) <= tol)
+        def defect() -> float:
+            data = self._data
+            a = np.abs(data[:, 2:4, 2:4] + data[:, 0:2, 0:2].conj()).max(initial=0.0)
+            b = np.abs(data[:, 2:4, 0:2] + data[:, 0:2, 2:4].conj()).max(initial=0.0)
+            return float(max(a, b))
+
+        return bool(self._memoized("ph_defect", defect) <= tol)
 
     # ------------------------------------------------------------------ export
     def matrix(self, format: str = "dense"):
@@ -224,6 +229,15 @@ class Hamiltonian:
         new_ptr = np.zeros(n + 1, dtype=np.int32)
         np.cumsum(np.bincount(block_rows, minlength=n), out=new_ptr[1:])
         return new_ptr, indices[keep].copy(), np.ascontiguousarray(data[keep])
+
+    def _memoized(self, name: str, compute):
+        """Value of `compute()` cached until the next `with` block rewrites the matrix."""
+        if self._memo_revision != self._revision:
+            self._memo = {}
+            self._memo_revision = self._revision
+        if name not in self._memo:
+            self._memo[name] = compute()
+        return self._memo[name]
 
     # ------------------------------------------------------------- observables
     def _solver(self):

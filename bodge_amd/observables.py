@@ -28,8 +28,11 @@ EXACT_TRACE_LIMIT = 16384  # largest 4N for which "auto" uses every unit vector
 
 
 def _scale_of(system, pad: float = 1.01) -> float:
-    indptr, _, data = system.bsr_arrays()
-    return cheb.spectral_bound(indptr, data, pad)
+    # zero blocks add nothing to the row sums: the skeleton arrays give the same bound as the
+    # trimmed ones, without the copy; cached until the next `with` block
+    bound = system._memoized(
+        "gershgorin", lambda: cheb.spectral_bound(system._matrix.indptr, system._data, pad=1.0))
+    return pad * bound if bound > 0 else 1.0
 
 
 # --------------------------------------------------------------------------- F
