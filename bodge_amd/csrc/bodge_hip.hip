@@ -995,6 +995,24 @@ StartSpec batch_start(const StartSpec& start, int col) {
     return batch;
 }
 
+// Vectors advanced together.  Wide batches amortise launch latency and the matrix stream, narrow
+// ones keep t_n and t_{n-1} close to the caches: measured optimum (wall time per vector-step of
+// 64 vectors, profiles/r01_batch_width.log) is ~2.5 M site-vectors per launch, i.e. 64 vectors up
+// to 200x200 sites, 32 at 300x300, 16 at 400x400, 8 from 64^3 on (10^6 sites: 18.0 us per
+// vector-step at 8 per batch, 21.3 us at 64).  Rule: the largest power of two that keeps one
+// vector buffer within 96 MB, at least one full lane group (8 real / 4 complex), at most 64.
+int batch_width(const bdg_system* sys, const StartSpec& start, int n_vectors) {
+    if (const char* env = getenv("BODGE_AMD_BATCH")) return std::clamp(atoi(env), 1, 64);
+    const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
+    const bool real = sys->is_real && start_is_real;
+    const double per_vector = (double)sys->ncols * 4 * (real ? 8.0 : 16.0);
+    const int granule = real ? 8 : 4;
+    constexpr double kBufferTarget = 96.0 * 1024 * 1024;
+    int width = 64;
+    while (width > granule && width * per_vector > kBufferTarget) width >>= 1;
+    return std::min(width, std::max(n_vectors, 1));
+}
+
 // Single handle (whole matrix, or one slab of a multi-process run with RCCL halos).
 int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, StartSpec start,
                    double* d_out, double* e_out) {
@@ -1002,10 +1020,11 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
     const bool trace = getenv("BODGE_AMD_TRACE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    for (int col = 0; col < n_vectors; col += 64) {
+    const int width = batch_width(sys, start, n_vectors);
+    for (int col = 0; col < n_vectors; col += width) {
         Batch batch;
         const auto t0 = now();
-        if (int rc = batch.begin(sys, scale, n_steps, std::min(64, n_vectors - col),
+        if (int rc = batch.begin(sys, scale, n_steps, std::min(width, n_vectors - col),
                                  batch_start(start, col), -1))
             return rc;
         const auto t1 = now();
