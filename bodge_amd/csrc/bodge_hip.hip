@@ -319,6 +319,7 @@ struct StepPlan {
     size_t lds_footprint = 0;  // what one workgroup occupies (reported)
     bool pipelined = false;
     bool dictionary = false;
+    int stage_blocks = 1;      // generic form: blocks per wave staging region
     ModeInfo mode{};
     StepKernel kernel = nullptr;
 };
@@ -357,14 +358,14 @@ int make_plan(bdg_system* sys, int rl, const ModeInfo& mode, StepPlan* plan, boo
     } else {
         plan->kernel = col_scalars ? step_cols_kernel(mode, rl) : step_kernel(mode, rl);
         if (!plan->kernel) return fail(BDG_EINVAL, "unsupported lanes-per-row %d", rl);
-        const size_t stage = (size_t)bdg::kWavesPerBlock * rows_per_wave * sys->max_row_blocks *
-                             block_stride * sizeof(double2);
+        // a wave stages its tile's blocks in LDS; tiles that do not fit a quarter of the 160 KB
+        // (long rows of general matrices) pass through in chunks
+        const int tile_blocks = rows_per_wave * std::max(1, sys->max_row_blocks);
+        const int cap = (int)((160 * 1024 / bdg::kWavesPerBlock) / (block_stride * sizeof(double2)));
+        plan->stage_blocks = std::max(1, std::min(tile_blocks, cap));
+        const size_t stage = (size_t)bdg::kWavesPerBlock * plan->stage_blocks * block_stride * sizeof(double2);
         const size_t reduce = (size_t)bdg::kWavesPerBlock * rl * lane_doubles * sizeof(double);
         plan->lds_bytes = plan->lds_footprint = std::max(stage, reduce);
-        if (plan->lds_bytes > 160 * 1024)
-            return fail(BDG_EINVAL,
-                        "a block row with %d blocks needs %zu bytes of LDS per workgroup (limit 160 KiB)",
-                        sys->max_row_blocks, plan->lds_bytes);
         if (plan->lds_bytes > 64 * 1024)
             HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan->kernel),
                                         hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -449,6 +450,7 @@ int matrix_args(bdg_system* sys, const StepPlan& plan, bdg::StepArgs* args) {
     args->ncols = (int)sys->ncols;
     args->n_tiles = plan.n_tiles;
     args->max_row_blocks = sys->max_row_blocks;
+    args->stage_blocks = std::max(1, plan.stage_blocks);
     return BDG_OK;
 }
 

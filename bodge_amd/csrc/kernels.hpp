@@ -205,6 +205,8 @@ struct StepArgs {
     int ncols;    // block rows of the vector buffers (owned + halo); == nb without slabs
     int n_tiles;  // workgroup tiles of 4 * (64/RL) block rows
     int max_row_blocks;
+    // generic kernel: blocks a wave's LDS staging region holds; a tile with more is staged in chunks
+    int stage_blocks;
     // dictionary kernel: 1 = t_{n-1} loads and t_{n+1} stores carry the non-temporal hint (vector
     // buffers larger than the Infinity Cache), 0 = plain (buffers that stay cache resident)
     int stream_vectors;
@@ -395,7 +397,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
     const int wave = threadIdx.x / kWave;
     const int s = lane / RL;
     const int r = lane % RL;
-    const int region = RW * a.max_row_blocks * STRIDE;
+    const int region = a.stage_blocks * STRIDE;
     double2* stage = lds + wave * region;
     const double2* all_blocks = static_cast<const double2*>(a.blocks);
 
@@ -418,51 +420,65 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
         const int kb0 = a.indptr[row0];
         const int kb1 = a.indptr[row_end];
 
-        // -- stage this wave's blocks: slot e of the run goes to (e / SPB) * STRIDE + e % SPB
-        const int n_el = (kb1 - kb0) * SPB;
-        const double2* src = all_blocks + (size_t)kb0 * SPB;
-        for (int e0 = 0; e0 < n_el; e0 += 4 * kWave) {
-            double2 v[4];
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * kWave + lane;
-                if (e < n_el) v[u] = load_stream(src + e);
-            }
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int e = e0 + u * kWave + lane;
-                if (e < n_el) stage[(e / SPB) * STRIDE + (e % SPB)] = v[u];
-            }
-        }
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-
         const int i = row0 + s;
-        if (i < a.nb) {
-            const int kbeg = a.indptr[i];
-            const int kend = a.indptr[i + 1];
-            double2 acc[4];
+        const bool valid = i < a.nb;
+        int kbeg = 0, kend = 0;
+        if (valid) {
+            kbeg = a.indptr[i];
+            kend = a.indptr[i + 1];
+        }
+        double2 acc[4];
 #pragma unroll
-            for (int al = 0; al < 4; ++al) acc[al] = make_double2(0.0, 0.0);
+        for (int al = 0; al < 4; ++al) acc[al] = make_double2(0.0, 0.0);
 
+        // The tile's blocks [kb0, kb1) pass through the staging region in chunks of at most
+        // a.stage_blocks (one chunk for lattice matrices; long rows of general matrices take more).
+        for (int c0 = kb0; c0 < kb1; c0 += a.stage_blocks) {
+            const int c1 = min(c0 + a.stage_blocks, kb1);
+            // -- stage: slot e of the run goes to (e / SPB) * STRIDE + e % SPB
+            const int n_el = (c1 - c0) * SPB;
+            const double2* src = all_blocks + (size_t)c0 * SPB;
+            for (int e0 = 0; e0 < n_el; e0 += 4 * kWave) {
+                double2 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * kWave + lane;
+                    if (e < n_el) v[u] = load_stream(src + e);
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + u * kWave + lane;
+                    if (e < n_el) stage[(e / SPB) * STRIDE + (e % SPB)] = v[u];
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+            const int k0 = max(kbeg, c0), k1 = min(kend, c1);  // this lane's blocks in the chunk
             double2 x[4], xn[4];
-            if (kbeg < kend) {
-                const size_t j = (size_t)a.indices[kbeg];
+            if (k0 < k1) {
+                const size_t j = (size_t)a.indices[k0];
 #pragma unroll
                 for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, j, r, a.ncols, RL)];
             }
-            for (int k = kbeg; k < kend; ++k) {
+            for (int k = k0; k < k1; ++k) {
 #pragma unroll
                 for (int be = 0; be < 4; ++be) x[be] = xn[be];
-                if (k + 1 < kend) {
+                if (k + 1 < k1) {
                     const size_t j = (size_t)a.indices[k + 1];
 #pragma unroll
                     for (int be = 0; be < 4; ++be) xn[be] = a.cur[vslot(be, j, r, a.ncols, RL)];
                 }
-                Mode::mac_row(acc, stage + (k - kb0) * STRIDE, x);
+                Mode::mac_row(acc, stage + (k - c0) * STRIDE, x);
             }
+            // the next chunk (or tile) overwrites `stage`; same-wave LDS ops are ordered, the
+            // fence only stops the compiler from hoisting the next stores.
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+        }
 
+        if (valid) {
             // COLS instantiations (Lanczos) fetch per-column scalars here, once per tile; the
             // Chebyshev instantiations compile to the plain coef * acc - prev
             const LaneScalars ls = COLS ? lane_scalars<Mode::kVec>(a.coef, a.col_coef, a.col_pscale, r)
@@ -480,10 +496,6 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
                 Mode::dots(dot, c, nx);
             }
         }
-        // the next tile overwrites `stage`; same-wave LDS ops are ordered, the
-        // fence only stops the compiler from hoisting the next stores.
-        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-        __builtin_amdgcn_wave_barrier();
     }
 
     __syncthreads();  // every wave is done with its staging region

@@ -246,6 +246,39 @@ def test_matrix_without_particle_hole_form_uses_full_storage(api, solver_cls):
     assert np.allclose(got[0], ref[0], atol=1e-12) and np.allclose(got[1], ref[1], atol=1e-12)
 
 
+@pytest.mark.parametrize("n_vectors,kind,real", [
+    (3, cheb_ref.VEC_Z4, False),         # complex, 4 lanes per row: 16 rows x ~60 blocks per wave tile
+    (8, cheb_ref.VEC_RADEMACHER, True),  # real matrix, real arithmetic
+    (40, cheb_ref.VEC_Z4, False),        # wide batch, 64 lanes per row
+])
+def test_general_matrix_with_long_rows_is_staged_in_chunks(solver_cls, n_vectors, kind, real):
+    """A non-lattice Hermitian BSR matrix whose block rows hold 40-80 distinct blocks: more than
+    a wave's LDS staging region takes at once, so the generic kernel passes them through in chunks."""
+    import scipy.sparse as sp
+
+    rng = np.random.default_rng(11)
+    nb = 150
+    mask = rng.random((nb, nb)) < 0.22
+    mask |= mask.T
+    np.fill_diagonal(mask, True)
+    dense = rng.standard_normal((4 * nb, 4 * nb)) + (0 if real else 1j) * rng.standard_normal((4 * nb, 4 * nb))
+    dense = (dense + dense.conj().T) * np.kron(mask, np.ones((4, 4)))
+    mat = sp.bsr_matrix(dense.astype(np.complex128), blocksize=(4, 4))
+    mat.sort_indices()
+    assert np.diff(mat.indptr).max() > 40
+    scale = 1.01 * np.abs(dense).sum(axis=1).max()
+    start = cheb_ref.random_block(4 * nb, 2, range(n_vectors), kind)
+    ref = cheb_ref.recurrence_dots(mat, scale, 16, start)
+    x = rng.standard_normal(4 * nb) + 1j * rng.standard_normal(4 * nb)
+    with solver_cls(mat.indptr, mat.indices, mat.data) as dev:
+        assert np.allclose(dev.spmv(x), dense @ x, rtol=1e-12, atol=1e-12 * np.abs(dense @ x).max())
+        got = dev.dots_random(scale, 8, n_vectors, seed=2, kind=kind)
+        perf = dev.perf()
+        assert perf["dict_blocks"] == 0 and perf["pipelined"] == 0 and perf["real_arithmetic"] == int(real)
+    assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * 4 * nb)
+    assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * 4 * nb)
+
+
 @pytest.mark.parametrize("name,kind,lane_options", [
     ("dwave8", cheb_ref.VEC_RADEMACHER, (4, 8, 16, 32)),  # real arithmetic: two vectors per lane
     ("random357", cheb_ref.VEC_Z4, (4, 8, 16, 32, 64)),   # complex arithmetic
