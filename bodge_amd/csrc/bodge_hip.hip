@@ -869,6 +869,7 @@ struct Batch {
         part.tile_order = sys->tiles_interior.ptr;
         part.n_tiles = sys->n_interior;
         part.partial = slot;
+        part.reverse = alternate ? (n & 1) : 0;  // same cache-aware sweep as the plain step
         plan.kernel<<<grid_interior, bdg::kBlockThreads, plan.lds_bytes, st>>>(part);
         HIP_TRY(hipStreamWaitEvent(st, sys->ev_halo_ready, 0));
         part.tile_order = sys->tiles_boundary.ptr;
