@@ -61,6 +61,85 @@ def build_system(shape, model="swave", zeeman=0.05, gap=0.1, mu=3.0):
     return system
 
 
+
+class GlooReductions:
+    """Stand-in for the RCCL communicator in the bench's three reductions (sum of the moment
+    vector, max of the elapsed time, barrier), over torch.distributed's gloo backend.  Used only
+    if the RCCL communicator cannot be created; the JSON line then says so in config.collective."""
+
+    def __init__(self):
+        import torch
+        import torch.distributed as dist
+
+        self._torch, self._dist = torch, dist
+        if not dist.is_initialized():
+            from bodge_amd.solver import _StdoutToStderr
+
+            with _StdoutToStderr():  # gloo announces its peers on stdout; stdout carries the JSON line only
+                dist.init_process_group("gloo", init_method="env://")
+                dist.barrier()
+
+    def _reduce(self, values, op):
+        t = self._torch.from_numpy(np.array(values, dtype=np.float64))
+        self._dist.all_reduce(t, op=op)
+        return t.numpy()
+
+    def allreduce_sum(self, values):
+        return self._reduce(values, self._dist.ReduceOp.SUM)
+
+    def allreduce_max(self, values):
+        return self._reduce(values, self._dist.ReduceOp.MAX)
+
+    def barrier(self):
+        self._dist.barrier()
+
+    def finish(self):
+        """torch brings its own ROCm runtime next to the one libbodge_hip.so loaded; their exit-time
+        destructors collide (double free at interpreter shutdown), so leave without running them."""
+        self._dist.barrier()
+        self._dist.destroy_process_group()
+        sys.stdout.flush()
+        sys.stderr.flush()
+        os._exit(0)
+
+
+def make_communicator(communicator_cls, world: int, rank: int, mode: str):
+    """(communicator or None, description).  RCCL through the library; if that raises on this rank
+    the ranks agree through status files (a rank cannot fall back alone) and use gloo instead."""
+    if world <= 1:
+        return communicator_cls.from_environment(), "none (single process)"
+    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
+    base = os.path.join(os.environ.get("BODGE_AMD_RDZV_DIR", "/tmp"), f"bodge_amd_bench_{tag}")
+    comm, error = None, ""
+    try:
+        comm = communicator_cls.from_environment()
+    except Exception as exc:  # noqa: BLE001 - any failure means "no RCCL on this rank"
+        error = f"{type(exc).__name__}: {exc}"
+    import atexit
+
+    own = f"{base}_rank{rank}.status"
+    with open(f"{own}.tmp", "w") as fh:
+        fh.write("ok" if comm is not None else error or "failed")
+    os.replace(f"{own}.tmp", own)
+    atexit.register(lambda: os.path.exists(own) and os.unlink(own))
+    deadline = time.time() + 300
+    states = []
+    for r in range(world):
+        path = f"{base}_rank{r}.status"
+        while not (os.path.exists(path) and os.path.getsize(path) > 0):
+            if time.time() > deadline:
+                sys.exit(f"rank {rank}: no communicator status from rank {r}")
+            time.sleep(0.05)
+        with open(path) as fh:
+            states.append(fh.read())
+    if all(state == "ok" for state in states):
+        return comm, "rccl (ncclAllReduce of the moments inside bdg_cheb_moments)"
+    if mode == "slab":
+        sys.exit(f"rank {rank}: slab mode needs RCCL send/recv; communicator states: {states}")
+    reason = next(state for state in states if state != "ok")
+    return GlooReductions(), f"gloo fallback on the host (RCCL communicator failed: {reason[:200]})"
+
+
 def measured_traffic(kernel: str, shape, vectors: int):
     """HBM bytes per launch from the committed rocprofv3 PMC passes (tools/pmc_traffic.py), or None.
 
@@ -108,7 +187,7 @@ def main():
         build.build_library()
     backend.load()
     backend.require_device()
-    comm = Communicator.from_environment()
+    comm, collective = make_communicator(Communicator, world, rank, args.mode)
 
     shape = [int(v) for v in args.lattice.split(",")]
     t0 = time.perf_counter()
@@ -125,7 +204,7 @@ def main():
 
         bounds = slab.partition_rows(system.lattice.size, world, slab.lattice_granule(system.lattice))
         plan = slab.build_plan(indptr, indices, data, bounds, rank)
-        solver = DeviceSolver.from_slab_plan(plan, comm=comm, device=device)
+        solver = DeviceSolver.from_slab_plan(plan, comm=comm, device=device)  # (slab mode needs RCCL)
         first = 0
     else:
         solver = DeviceSolver(indptr, indices, data, device=device)
@@ -135,6 +214,9 @@ def main():
         solver.set_lanes_per_row(args.lanes)
 
     def run(steps):
+        if isinstance(comm, GlooReductions):  # RCCL unavailable: local moments, summed on the host
+            return comm.allreduce_sum(
+                solver.moments_random(scale, 2 * steps, r_local, seed=0, first_id=first, kind=kind, comm=None))
         return solver.moments_random(scale, 2 * steps, r_local, seed=0, first_id=first, kind=kind, comm=comm)
 
     if args.warmup > 0:
@@ -177,6 +259,8 @@ def main():
     complex_pass = alternative({"BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"}) if perf["real_arithmetic"] else None
 
     if rank != 0:
+        if isinstance(comm, GlooReductions):
+            comm.finish()
         return
 
     total_vectors = r_local * (1 if args.mode == "slab" else args.gpus)
@@ -213,6 +297,7 @@ def main():
             "vector_kind": args.vector_kind,
             "spectral_scale": scale,
             "parallelism": f"{args.mode} x{args.gpus}",
+            "collective": collective,
         },
         "roofline": {
             "bound": "hbm",
@@ -276,6 +361,8 @@ def main():
     else:
         record["cpu_baseline"] = None
     print(json.dumps(record), flush=True)
+    if isinstance(comm, GlooReductions):
+        comm.finish()
 
 
 if __name__ == "__main__":

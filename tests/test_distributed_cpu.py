@@ -111,3 +111,21 @@ def test_rccl_rendezvous_under_torchrun(tmp_path):
     assert len({r["uid"] for r in ranks}) == 1, "ranks disagree on the unique id"
     assert len({r["ppid"] for r in ranks}) == 1  # the rendezvous file name relies on a common parent
     assert not [f for f in os.listdir(tmp_path) if f.endswith(".id")], "rendezvous file was not cleaned up"
+
+
+@pytest.mark.timeout(600)
+def test_bench_falls_back_to_gloo_when_rccl_is_unavailable(tmp_path):
+    """bench.py's safety net: if the RCCL communicator cannot be built, the ranks agree on it and
+    do the moment sum / timing max over gloo instead of dying (the JSON line then says so)."""
+    cmd = [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+        os.path.join(ROOT, "tests", "_fallback_worker.py"), str(tmp_path),
+    ]
+    env = dict(os.environ, BODGE_AMD_RDZV_DIR=str(tmp_path))
+    proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    for r in range(2):
+        rec = json.loads((tmp_path / f"rank{r}.json").read_text())
+        assert rec["sum"] == [1.0, 3.0, 5.0, 7.0] and rec["max"] == [1.0]
+        assert rec["description"].startswith("gloo fallback") and "simulated" in rec["description"]
