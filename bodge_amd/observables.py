@@ -10,9 +10,10 @@ Routing (all device-side; there is no CPU path):
            recurrence kernel advances R start vectors together; exact trace
            (every unit vector) for small systems, stochastic trace otherwise.
 
-`method="auto"` picks dense while the matrix is small enough for it to be
-both exact and quick (4N <= DENSE_AUTO_LIMIT, served by the library-free Jacobi
-kernels; up to DENSE_AUTO_LIMIT_T0 at T = 0), Chebyshev beyond that.
+`method="auto"` picks, by estimated run time, between the dense eigensolver
+(4N <= DENSE_AUTO_LIMIT: the library-free Jacobi kernels; rocSOLVER up to
+DENSE_AUTO_LIMIT_T0; always dense at T = 0 within that limit) and the Chebyshev
+expansion (`_auto_method`).
 """
 
 from __future__ import annotations
@@ -22,8 +23,8 @@ import numpy as np
 from . import chebyshev as cheb
 from .backend import VEC_RADEMACHER, VEC_Z4
 
-DENSE_AUTO_LIMIT = 4096  # largest 4N routed to the dense eigensolver by method="auto" (own Jacobi kernels)
-DENSE_AUTO_LIMIT_T0 = 16384  # at T = 0 the Chebyshev series converges only algebraically: stay dense longer
+DENSE_AUTO_LIMIT = 4096  # largest 4N served by the own Jacobi kernels
+DENSE_AUTO_LIMIT_T0 = 16384  # largest 4N method="auto" ever sends to a dense eigensolver
 EXACT_TRACE_LIMIT = 16384  # largest 4N for which "auto" uses every unit vector
 
 
@@ -33,6 +34,32 @@ def _scale_of(system, pad: float = 1.01) -> float:
     bound = system._memoized(
         "gershgorin", lambda: cheb.spectral_bound(system._matrix.indptr, system._data, pad=1.0))
     return pad * bound if bound > 0 else 1.0
+
+
+def _auto_method(system, temperature: float, moments, scale) -> str:
+    """Dense or Chebyshev for `free_energy(method="auto")`, by estimated run time.
+
+    T = 0 stays dense as long as possible (|ε| is not analytic: the series converges only
+    algebraically).  Matrices without the particle-hole form must go dense.  Otherwise the two
+    routes are priced with measured constants (profiles/r01_wall_table.log): the Jacobi kernels
+    cost ≈ 8e-11·(4N)³ s (0.35 s at 4N = 1600, 4.6 s at 4096), rocSOLVER ≈ 2e-12·(4N)³ s plus its
+    load time; an exact-trace Chebyshev run costs M/2 launches per batch of 64 unit vectors, each
+    ≥ 7 µs or its HBM time.  Both routes meet the 1e-10 relative accuracy the tests ask for.
+    """
+    dim = system.shape[0]
+    if temperature == 0:
+        return "dense" if dim <= DENSE_AUTO_LIMIT_T0 else "chebyshev"
+    if dim > DENSE_AUTO_LIMIT_T0:
+        return "chebyshev"
+    if not system.has_symmetric_spectrum(1e-12):
+        return "dense"
+    a = _scale_of(system) if scale is None else float(scale)
+    m = cheb.moments_for_free_energy(a, temperature) if moments is None else int(moments)
+    batches = -(-dim // 64) if dim <= EXACT_TRACE_LIMIT else 1
+    launch = max(7e-6, (dim // 4) * 64 * 192 / 5e12)
+    chebyshev_seconds = 0.5 * m * batches * launch
+    dense_seconds = 8e-11 * dim**3 if dim <= DENSE_AUTO_LIMIT else 2.0 + 2e-12 * dim**3
+    return "dense" if dense_seconds <= chebyshev_seconds else "chebyshev"
 
 
 # --------------------------------------------------------------------------- F
@@ -69,8 +96,7 @@ def free_energy(
         raise ValueError("Expected non-negative temperature!")
     dim = system.shape[0]
     if method == "auto":
-        limit = DENSE_AUTO_LIMIT_T0 if temperature == 0 else DENSE_AUTO_LIMIT
-        method = "dense" if dim <= limit else "chebyshev"
+        method = _auto_method(system, temperature, moments, scale)
     if method == "chebyshev" and not system.has_symmetric_spectrum(1e-12):
         # Σ_{ε>0} g(ε) equals a trace of a smooth function only for a ±-symmetric spectrum
         raise RuntimeError(
