@@ -36,6 +36,17 @@ def _scale_of(system, pad: float = 1.01) -> float:
     return pad * bound if bound > 0 else 1.0
 
 
+def _electron_rows(dim: int) -> np.ndarray:
+    """Scalar rows of the electron components (e↑, e↓) of every site.
+
+    The Chebyshev route requires H = -τx H* τx (checked by the caller).  Then T_m(H) = ±τx T_m(H)* τx
+    and only even m enter an even f, so the diagonal entry of f(H) on a hole row equals the one on
+    the electron row of the same site and spin: the exact trace is twice the sum over these rows.
+    """
+    rows = np.arange(dim, dtype=np.int64)
+    return rows[(rows & 3) < 2]
+
+
 def _auto_method(system, temperature: float, moments, scale) -> str:
     """Dense or Chebyshev for `free_energy(method="auto")`, by estimated run time.
 
@@ -55,7 +66,7 @@ def _auto_method(system, temperature: float, moments, scale) -> str:
         return "dense"
     a = _scale_of(system) if scale is None else float(scale)
     m = cheb.moments_for_free_energy(a, temperature) if moments is None else int(moments)
-    batches = -(-dim // 64) if dim <= EXACT_TRACE_LIMIT else 1
+    batches = -(-(dim // 2) // 64) if dim <= EXACT_TRACE_LIMIT else 1  # electron rows only
     launch = max(7e-6, (dim // 4) * 64 * 192 / 5e12)
     chebyshev_seconds = 0.5 * m * batches * launch
     dense_seconds = 8e-11 * dim**3 if dim <= DENSE_AUTO_LIMIT else 2.0 + 2e-12 * dim**3
@@ -127,8 +138,8 @@ def free_energy(
         solver = _slab_solver(system, comm)
         steps = moments // 2
         if trace == "exact":
-            d, e = solver.dots_unit(scale, steps, np.arange(dim, dtype=np.int64))
-            total = 1
+            d, e = solver.dots_unit(scale, steps, _electron_rows(dim))
+            total = 0.5  # the hole rows contribute the same again (see _electron_rows)
         elif trace == "stochastic":
             kind = {"rademacher": VEC_RADEMACHER, "z4": VEC_Z4}[vector_kind]
             total = 64 if vectors is None else int(vectors)
@@ -141,10 +152,10 @@ def free_energy(
     solver = system._solver()
 
     if trace == "exact":
-        rows = np.arange(dim, dtype=np.int64)
+        rows = _electron_rows(dim)
         if comm is not None:
             rows = rows[comm.rank :: comm.n_ranks]
-        mu = solver.moments_unit(scale, moments, rows).sum(axis=1)
+        mu = 2.0 * solver.moments_unit(scale, moments, rows).sum(axis=1)
         if comm is not None:
             mu = comm.allreduce_sum(mu)
     elif trace == "stochastic":
