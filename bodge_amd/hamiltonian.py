@@ -100,7 +100,7 @@ class Hamiltonian:
 
         # Device-side state (created lazily; invalidated whenever terms change).
         self._revision = 0
-        self._device = None
+        self._devices: dict = {}
         self._device_revision = -1
         self._memo: dict = {}
         self._memo_revision = -1
@@ -240,16 +240,22 @@ class Hamiltonian:
         return self._memo[name]
 
     # ------------------------------------------------------------- observables
-    def _solver(self):
-        """Device mirror of the current matrix (re-uploaded after every `with`)."""
+    def _solver(self, lane: int = 0):
+        """Device mirror of the current matrix (re-uploaded after every `with`).
+
+        `lane` > 0 gives further independent mirrors (own stream and buffers): mid-size exact
+        traces drive two of them from two host threads to overlap their launch latencies.
+        """
         from .solver import DeviceSolver
 
-        if self._device is None or self._device_revision != self._revision:
-            if self._device is not None:
-                self._device.close()
-            self._device = DeviceSolver.from_hamiltonian(self)
+        if self._device_revision != self._revision:
+            for device in self._devices.values():
+                device.close()
+            self._devices = {}
             self._device_revision = self._revision
-        return self._device
+        if lane not in self._devices:
+            self._devices[lane] = DeviceSolver.from_hamiltonian(self)
+        return self._devices[lane]
 
     def diagonalize(self, cuda: bool = False, format: str = "reshape"):
         """Positive-energy eigenpairs (E, v[n, site, α]) or raw (E, X[:, n]).
