@@ -1249,7 +1249,7 @@ int lanczos_advance(bdg_system* sys, int n_iter, double* alpha_out, double* beta
 // ------------------------------------------------------------- dense eigensolver
 // One-sided Jacobi on the GPU for matrices up to kJacobiLimit (no external library: the first
 // use of rocSOLVER on a fresh machine pages in ~1 GB and was measured at 1.5-7.5 minutes).
-constexpr int64_t kJacobiLimit = 4096;
+constexpr int64_t kJacobiLimit = 2048;  // 0.9 s with vectors; 4096 would take 8 s, rocSOLVER 0.5 s
 
 int eigh_jacobi(bdg_system* sys, double* w_out, double* z_out) {
     const int64_t n = 4 * sys->nb;

@@ -3,7 +3,7 @@
 Routing (all device-side; there is no CPU path):
 
 * dense    BSR -> dense scatter kernel + Hermitian eigensolver on the GPU (own
-           one-sided Jacobi kernels up to 4N = 4096, rocSOLVER `zheevd` above).
+           one-sided Jacobi kernels up to 4N = 2048, rocSOLVER `dsyevd` / `zheevd` above).
            Exact, O((4N)^3); what the reference's `cuda=True` branch does with
            CuPy (ref hamiltonian.py:206-221, :287-295).
 * chebyshev  kernel-polynomial expansion on the BSR matrix, O(N·M): the
@@ -23,7 +23,7 @@ import numpy as np
 from . import chebyshev as cheb
 from .backend import VEC_RADEMACHER, VEC_Z4
 
-DENSE_AUTO_LIMIT = 4096  # largest 4N served by the own Jacobi kernels
+DENSE_AUTO_LIMIT = 2048  # largest 4N served by the own Jacobi kernels (kJacobiLimit in the library)
 DENSE_AUTO_LIMIT_T0 = 16384  # largest 4N method="auto" ever sends to a dense eigensolver
 EXACT_TRACE_LIMIT = 16384  # largest 4N for which "auto" uses every unit vector
 
@@ -76,7 +76,7 @@ def _auto_method(system, temperature: float, moments, scale) -> str:
     T = 0 stays dense as long as possible (|ε| is not analytic: the series converges only
     algebraically).  Matrices without the particle-hole form must go dense.  Otherwise the two
     routes are priced with measured constants (profiles/r01_wall_table.log): the Jacobi kernels
-    cost ≈ 8e-11·(4N)³ s (0.35 s at 4N = 1600, 4.6 s at 4096), rocSOLVER ≈ 2e-12·(4N)³ s plus its
+    cost ≈ 8e-11·(4N)³ s (0.35 s at 4N = 1600), rocSOLVER ≈ 2e-12·(4N)³ s plus its
     load time; an exact-trace Chebyshev run costs M/2 launches per batch of 64 unit vectors, each
     ≥ 7 µs or its HBM time.  Both routes meet the 1e-10 relative accuracy the tests ask for.
     """

@@ -186,7 +186,7 @@ class DeviceSolver:
         return alpha, beta
 
     def eigh(self, vectors: bool = True):
-        """All eigenvalues ascending (and eigenvectors as columns): own Jacobi kernels up to 4N = 4096,
+        """All eigenvalues ascending (and eigenvectors as columns): own Jacobi kernels up to 4N = 2048,
         rocSOLVER above (dsyevd when imag(H) = 0, else zheevd)."""
         w = np.empty(self.dim)
         if not vectors:

@@ -165,7 +165,7 @@ int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t v
  * eigenvalues ascending in w_out; if z_out is non-null it receives the
  * eigenvectors in column-major (Fortran) order: eigenvector n occupies the
  * 4nb complex entries starting at z_out[2*n*4nb].
- * Drivers: own one-sided Jacobi kernels for 4*nb <= 4096; above, rocSOLVER dsyevd when
+ * Drivers: own one-sided Jacobi kernels for 4*nb <= 2048; above, rocSOLVER dsyevd when
  * imag(H) = 0 (real eigenvectors, widened to complex in z_out) and zheevd otherwise;
  * limit 4*nb <= 46000.
  */

@@ -377,8 +377,8 @@ def test_diagonalize_matches_reference(api, golden, name):
                     reason="first rocSOLVER use pages in ~1 GB (1.5-7.5 min on a fresh box); set "
                            "BODGE_AMD_TEST_ROCSOLVER=1 to run; profiles/r01_eigh_probe.log has a recorded run")
 @pytest.mark.parametrize("name", ["complex235", "barrier"])
-def test_rocsolver_route_used_above_4096(api, golden, monkeypatch, name):
-    """The library route taken for 4N > 4096, forced here on small systems: dsyevd when imag(H) = 0
+def test_rocsolver_route_used_above_the_jacobi_limit(api, golden, monkeypatch, name):
+    """The library route taken for 4N > 2048, forced here on small systems: dsyevd when imag(H) = 0
     (barrier), zheevd otherwise (complex235), and zheevd's NaN-eigenvector defect on degenerate
     spectra caught and repaired with zheevj."""
     monkeypatch.setenv("BODGE_AMD_EIGH", "evd")
