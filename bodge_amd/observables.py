@@ -50,8 +50,8 @@ def _electron_rows(dim: int) -> np.ndarray:
 CONCURRENT_TRACE_MAX_SITES = 200_000  # below this a launch leaves the GPU part idle: run two at a time
 
 
-def _unit_moment_sum(system, scale: float, moments: int, rows: np.ndarray) -> np.ndarray:
-    """Σ over `rows` of the unit-vector moments <e_r|T_m(H/scale)|e_r>, shape (moments,).
+def _unit_moments(system, scale: float, moments: int, rows: np.ndarray) -> np.ndarray:
+    """Unit-vector moments <e_r|T_m(H/scale)|e_r> for every r in `rows`, shape (moments, len(rows)).
 
     Small lattices are launch-latency bound (one launch ≈ 7-10 µs whatever it holds), so two
     device mirrors, each with its own stream and buffers, are driven from two host threads (the
@@ -59,15 +59,20 @@ def _unit_moment_sum(system, scale: float, moments: int, rows: np.ndarray) -> np
     """
     lanes = 2 if (len(rows) >= 512 and system.lattice.size <= CONCURRENT_TRACE_MAX_SITES) else 1
     if lanes == 1:
-        return system._solver().moments_unit(scale, moments, rows).sum(axis=1)
+        return system._solver().moments_unit(scale, moments, rows)
     from concurrent.futures import ThreadPoolExecutor
 
     solvers = [system._solver(lane) for lane in range(lanes)]  # created here, on one thread
     half = (len(rows) // (64 * lanes)) * 64 or len(rows) // lanes
     parts = [rows[:half], rows[half:]]
     with ThreadPoolExecutor(lanes) as pool:
-        sums = pool.map(lambda job: job[0].moments_unit(scale, moments, job[1]).sum(axis=1), zip(solvers, parts))
-        return sum(sums)
+        blocks = pool.map(lambda job: job[0].moments_unit(scale, moments, job[1]), zip(solvers, parts))
+        return np.concatenate(list(blocks), axis=1)
+
+
+def _unit_moment_sum(system, scale: float, moments: int, rows: np.ndarray) -> np.ndarray:
+    """Σ over `rows` of the unit-vector moments, shape (moments,)."""
+    return _unit_moments(system, scale, moments, rows).sum(axis=1)
 
 
 def _auto_method(system, temperature: float, moments, scale) -> str:
@@ -320,7 +325,7 @@ def ldos(system, site, energies, *, moments: int | None = None, scale: float | N
 
     index = np.array([system.lattice[s] for s in sites], dtype=np.int64)
     rows = (4 * index[:, None] + np.arange(4)[None, :]).reshape(-1)
-    mu = system._solver().moments_unit(scale, moments, rows)  # (M, 4 * n_sites)
+    mu = _unit_moments(system, scale, moments, rows)  # (M, 4 * n_sites)
 
     out = np.empty((len(sites), energies.size))
     for n in range(len(sites)):

@@ -425,6 +425,22 @@ def test_ldos_of_many_sites_in_one_call(api, golden):
     assert np.allclose(table[9], system.ldos((7, 5, 0), energies), rtol=1e-12)
 
 
+def test_ldos_map_of_a_whole_lattice_uses_two_device_mirrors(api, golden):
+    """All 256 sites in one call (1024 unit vectors): the rows are split over two device mirrors
+    driven by two host threads; every row must still equal the single-site call."""
+    system = _build(api, "ldos16")
+    sites = [(x, y, 0) for x in range(16) for y in range(16)]
+    energies = list(np.linspace(-0.3, 0.3, 7))
+    table = system.ldos(sites, energies)
+    assert table.shape == (256, 7) and len(system._devices) == 2
+    assert np.allclose(table[sites.index((8, 8, 0))], golden.ldos("ldos16", 0), rtol=1e-9, atol=1e-12)
+    for site in [(0, 0, 0), (7, 15, 0), (15, 15, 0)]:
+        assert np.allclose(table[sites.index(site)], system.ldos(site, energies), rtol=1e-12)
+    # the model is uniform: the map has the lattice's mirror symmetry
+    grid = table.reshape(16, 16, 7)
+    assert np.allclose(grid, grid[::-1], rtol=1e-9) and np.allclose(grid, grid.transpose(1, 0, 2), rtol=1e-9)
+
+
 def test_ldos_is_positive_everywhere(api):
     """ref tests/test_hamiltonian.py:467-500 on a seeded random periodic metal."""
     system = systems.random_periodic(api, shape=(5, 5, 2), seed=21)
