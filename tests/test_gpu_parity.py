@@ -399,6 +399,33 @@ def test_rocsolver_route_used_above_the_jacobi_limit(api, golden, monkeypatch, n
         assert np.isfinite(vecs2).all() and np.allclose(dense @ vecs2, vecs2 * vals2, atol=1e-9)
 
 
+def test_single_site_and_single_line_systems(api):
+    """Smallest inputs: a 1x1x1 lattice (one 4x4 block; every axis degenerate, so the self-"edges"
+    merge into the diagonal block, ref lattice.py:190-195) and a 1x1xL chain, through every observable."""
+    for shape in [(1, 1, 1), (1, 1, 5)]:
+        lattice = api.CubicLattice(shape)
+        system = api.Hamiltonian(lattice)
+        with system as (H, Δ):
+            for i in lattice.sites():
+                H[i, i] = 0.7 * api.σ0 + 0.2 * api.σ3
+                Δ[i, i] = -0.3 * api.jσ2
+            for i, j in lattice.bonds():
+                H[i, j] = -1.0 * api.σ0
+        dense = np.asarray(system.matrix("dense"))
+        vals, vecs = system.diagonalize(format="raw")
+        ref_vals, _ = dense_ref.diagonalize(dense, format="raw")
+        assert np.allclose(vals, ref_vals, atol=1e-12) and np.allclose(dense @ vecs, vecs * vals, atol=1e-12)
+        for temperature in (0.0, 0.3):
+            for method in ("dense", "auto") + (("chebyshev",) if temperature > 0 else ()):
+                assert np.isclose(system.free_energy(temperature, method=method),
+                                  dense_ref.free_energy(dense, temperature), rtol=1e-10)
+        site = tuple(s - 1 for s in shape)
+        energies = [0.0, 0.5, 1.0]
+        assert np.allclose(system.ldos(site, energies),
+                           dense_ref.ldos(system.matrix("csc"), lattice[site], energies), rtol=1e-9, atol=1e-12)
+        assert np.allclose(system.lowest_eigenvalues(1), ref_vals.min(), atol=1e-6)
+
+
 def test_diagonalize_counts_2n_states(api):
     system = _build(api, "barrier")  # ref tests/test_hamiltonian.py:353
     vals, _ = system.diagonalize()
