@@ -75,24 +75,37 @@ def _unit_moment_sum(system, scale: float, moments: int, rows: np.ndarray) -> np
     return _unit_moments(system, scale, moments, rows).sum(axis=1)
 
 
+def _gap_estimate(system) -> float:
+    """Smallest positive eigenvalue from a short Lanczos run (an upper bound, good to ~1e-3);
+    cached until the matrix changes."""
+    return system._memoized("gap_estimate", lambda: float(lowest_eigenvalues(system, 1, tol=1e-3)[0]))
+
+
 def _auto_method(system, temperature: float, moments, scale) -> str:
     """Dense or Chebyshev for `free_energy(method="auto")`, by estimated run time.
 
-    T = 0 stays dense as long as possible (|ε| is not analytic: the series converges only
-    algebraically).  Matrices without the particle-hole form must go dense.  Otherwise the two
+    T = 0: dense within reach of the own Jacobi kernels; above, the Chebyshev expansion at the
+    surrogate temperature gap/30 (see `free_energy`) when the spectrum is gapped enough, else the
+    dense library.  Matrices without the particle-hole form must go dense.  Otherwise the two
     routes are priced with measured constants (profiles/r01_wall_table.log): the Jacobi kernels
     cost ≈ 8e-11·(4N)³ s (0.35 s at 4N = 1600), rocSOLVER ≈ 2e-12·(4N)³ s plus its
     load time; an exact-trace Chebyshev run costs M/2 launches per batch of 64 unit vectors, each
     ≥ 7 µs or its HBM time.  Both routes meet the 1e-10 relative accuracy the tests ask for.
     """
     dim = system.shape[0]
-    if temperature == 0:
-        return "dense" if dim <= DENSE_AUTO_LIMIT_T0 else "chebyshev"
     if dim > DENSE_AUTO_LIMIT_T0:
         return "chebyshev"
     if not system.has_symmetric_spectrum(1e-12):
         return "dense"
     a = _scale_of(system) if scale is None else float(scale)
+    if temperature == 0:
+        # beyond the own Jacobi kernels: Chebyshev at T = gap/30 if the spectrum is gapped enough
+        # for that expansion to converge within the moment cap, the dense library otherwise
+        if dim <= DENSE_AUTO_LIMIT or moments is not None:
+            return "dense"
+        gap = _gap_estimate(system)
+        gapped = gap > 0 and cheb.moments_for_free_energy(a, gap / 30.0) < (1 << 17)
+        return "chebyshev" if gapped else "dense"
     m = cheb.moments_for_free_energy(a, temperature) if moments is None else int(moments)
     batches = -(-(dim // 2) // 64) if dim <= EXACT_TRACE_LIMIT else 1  # electron rows only
     launch = max(7e-6, (dim // 4) * 64 * 192 / 5e12)
@@ -113,6 +126,7 @@ def free_energy(
     vector_kind: str = "rademacher",
     trace: str = "auto",
     scale: float | None = None,
+    gap_surrogate: bool = True,
     damping: bool = False,
     comm=None,
     decomposition: str = "vectors",
@@ -123,6 +137,9 @@ def free_energy(
     moments  Chebyshev order M (even); default from the analyticity strip of f at T
     trace    "exact" (all 4N unit vectors), "stochastic", or "auto"
     vectors  number of random vectors for the stochastic trace (default 64)
+    gap_surrogate  at T = 0 with the Chebyshev method and no explicit `moments`: expand f at
+             T = gap/30 instead (gap from `lowest_eigenvalues`), which differs from f_0 by ~1e-13 on a
+             gapped spectrum but converges geometrically; False keeps the plain T = 0 coefficients
     comm     optional `Communicator` (one process per GPU)
     decomposition  how the ranks of `comm` share the work:
              "vectors" - H replicated, each rank owns a contiguous share of the start
@@ -156,8 +173,19 @@ def free_energy(
     if decomposition not in ("vectors", "slab"):
         raise RuntimeError(f"Decomposition '{decomposition}' is not supported")
     scale = _scale_of(system) if scale is None else float(scale)
+    series_temperature = temperature
+    if temperature == 0 and moments is None and gap_surrogate and decomposition != "slab":
+        # f_0(ε) = -|ε|/4 has a kink at ε = 0, but a gapped spectrum never samples it: for T ≪ gap
+        # f_T - f_0 = -(T/2) log1p(e^{-|ε|/T}) ≤ (T/2) e^{-gap/T} on the spectrum, and f_T is analytic.
+        # With T = gap/30 the difference is ~1e-13 and the series converges geometrically
+        # (20x20 README model: 8e-15 of the dense value with 16384 moments, against 3e-9 for the
+        # T = 0 coefficients).  The Lanczos estimate of the gap approaches it from above; the
+        # factor 30 leaves room for that.  A gapless spectrum keeps the plain T = 0 series.
+        gap = _gap_estimate(system)
+        if gap > 1e-9 * scale:
+            series_temperature = gap / 30.0
     if moments is None:
-        moments = cheb.moments_for_free_energy(scale, temperature)
+        moments = cheb.moments_for_free_energy(scale, series_temperature)
     moments += moments & 1
     if trace == "auto":
         trace = "exact" if dim <= EXACT_TRACE_LIMIT else "stochastic"
@@ -175,7 +203,7 @@ def free_energy(
         else:
             raise RuntimeError(f"Trace mode '{trace}' is not supported")
         mu = comm.allreduce_sum(cheb.dots_to_moments(d, e).sum(axis=1)) / total
-        return cheb.free_energy_series(mu, scale, temperature, damping=damping)
+        return cheb.free_energy_series(mu, scale, series_temperature, damping=damping)
 
     solver = system._solver()
 
@@ -194,7 +222,7 @@ def free_energy(
         mu = mu / total
     else:
         raise RuntimeError(f"Trace mode '{trace}' is not supported")
-    return cheb.free_energy_series(mu, scale, temperature, damping=damping)
+    return cheb.free_energy_series(mu, scale, series_temperature, damping=damping)
 
 
 def _slab_solver(system, comm):

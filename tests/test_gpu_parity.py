@@ -328,6 +328,19 @@ def test_free_energy_default_moment_rule_reaches_1e10(api, golden):
         assert np.isclose(value, golden.free_energy("snf", temperature), rtol=1e-10, atol=0)
 
 
+@pytest.mark.parametrize("name", ["swave20_zeeman", "snf"])
+def test_zero_temperature_chebyshev_on_a_gapped_spectrum(api, golden, name):
+    """T = 0 beyond dense reach: |ε| is not analytic, but on a gapped spectrum the expansion of f at
+    T = gap/30 (gap from Lanczos) reproduces the dense T = 0 value; the plain T = 0 coefficients
+    with the same number of moments do not."""
+    system = _build(api, name)
+    exact = golden.free_energy(name, 0.0)
+    value = system.free_energy(0.0, method="chebyshev")
+    assert np.isclose(value, exact, rtol=1e-10, atol=0)
+    plain = system.free_energy(0.0, method="chebyshev", gap_surrogate=False)
+    assert abs(plain - exact) > abs(value - exact) and np.isclose(plain, exact, rtol=1e-6)
+
+
 def test_free_energy_stochastic_matches_oracle_on_same_vectors(api):
     system = systems.swave_square(api, L=40)
     bsr = system.matrix("bsr")
