@@ -8,12 +8,13 @@ Routing (all device-side; there is no CPU path):
            CuPy (ref hamiltonian.py:206-221, :287-295).
 * chebyshev  kernel-polynomial expansion on the BSR matrix, O(N·M): the
            recurrence kernel advances R start vectors together; exact trace
-           (every unit vector) for small systems, stochastic trace otherwise.
+           (unit vectors of the electron rows, x2 by particle-hole symmetry) up to
+           4N = EXACT_TRACE_LIMIT, stochastic trace beyond.  T = 0 is expanded at the
+           surrogate temperature gap/30 when the spectrum is gapped.
 
 `method="auto"` picks, by estimated run time, between the dense eigensolver
 (4N <= DENSE_AUTO_LIMIT: the library-free Jacobi kernels; rocSOLVER up to
-DENSE_AUTO_LIMIT_T0; always dense at T = 0 within that limit) and the Chebyshev
-expansion (`_auto_method`).
+DENSE_AUTO_LIMIT_T0) and the Chebyshev expansion (`_auto_method`).
 """
 
 from __future__ import annotations
