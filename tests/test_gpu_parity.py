@@ -72,6 +72,34 @@ def test_spmv_keeps_explicit_zero_blocks_and_empty_rows(api, solver_cls):
         assert np.allclose(dev.spmv(x), mat @ x, rtol=1e-13)
 
 
+@pytest.mark.parametrize("seed", range(8))
+def test_random_periodic_lattices_of_random_shape(api, solver_cls, seed):
+    """Seeded random shapes (1..6 per axis, so degenerate axes and their self-edges occur) with dense
+    complex on-site, bond and periodic-edge terms: SpMV, recurrence dots, spectrum and the dense
+    free energy against the oracle.  (These matrices are Hermitian but not particle-hole
+    symmetric, so they run the full-block complex kernels and the dense route.)"""
+    rng = np.random.default_rng(500 + seed)
+    shape = tuple(int(v) for v in rng.integers(1, 7, size=3))
+    system = systems.random_periodic(api, shape=shape, seed=900 + seed)
+    bsr = system.matrix("bsr")
+    n = bsr.shape[0]
+    x = rng.standard_normal(n) + 1j * rng.standard_normal(n)
+    scale = cheb_ref.spectral_bound(bsr)
+    n_vectors = int(rng.integers(1, 20))
+    ref = cheb_ref.recurrence_dots(bsr, scale, 24, cheb_ref.random_block(n, seed, range(n_vectors), cheb_ref.VEC_Z4))
+    with solver_cls.from_hamiltonian(system) as dev:
+        y = dev.spmv(x)
+        got = dev.dots_random(scale, 12, n_vectors, seed=seed, kind=cheb_ref.VEC_Z4)
+    assert np.allclose(y, bsr @ x, rtol=1e-12, atol=1e-12 * np.abs(bsr @ x).max())
+    assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * n) and np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * n)
+    dense = np.asarray(system.matrix("dense"))
+    vals, vecs = system.diagonalize(format="raw")
+    ref_vals, _ = dense_ref.diagonalize(dense, format="raw")
+    assert np.allclose(vals, ref_vals, rtol=0, atol=1e-10) and np.allclose(dense @ vecs, vecs * vals, atol=1e-9)
+    for temperature in (0.0, 0.3):
+        assert np.isclose(system.free_energy(temperature), dense_ref.free_energy(dense, temperature), rtol=1e-10)
+
+
 def test_device_start_vectors_equal_oracle(api, solver_cls):
     system = _build(api, "barrier")
     with solver_cls.from_hamiltonian(system) as dev:
