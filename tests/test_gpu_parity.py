@@ -517,6 +517,41 @@ def test_ldos_is_positive_everywhere(api):
         assert np.all(system.ldos(site, energies) >= 0)
 
 
+def test_handles_release_their_device_memory(api, solver_cls):
+    """Create / use / destroy in a loop (recurrence, unit moments, Lanczos, dense eigensolver, slab
+    group): free device memory must return to where it started."""
+    import ctypes
+
+    from bodge_amd.solver import SlabGroup
+
+    hip = ctypes.CDLL("libamdhip64.so")
+
+    def free_bytes():
+        free, total = ctypes.c_size_t(), ctypes.c_size_t()
+        assert hip.hipMemGetInfo(ctypes.byref(free), ctypes.byref(total)) == 0
+        return free.value
+
+    system = _build(api, "swave20")
+    scale = cheb_ref.spectral_bound(system.matrix("bsr"))
+
+    def cycle():
+        with solver_cls.from_hamiltonian(system) as dev:
+            dev.dots_random(scale, 8, 24)
+            dev.moments_unit(scale, 16, np.arange(40, dtype=np.int64))
+            dev.lanczos_begin(4, seed=1, max_iter=64)
+            dev.lanczos_advance(16)
+            dev.eigh(vectors=True)
+        with SlabGroup.from_hamiltonian(system, 3) as group:
+            group.dots_random(scale, 4, 8)
+
+    cycle()  # first use loads code objects and creates the runtime's own pools
+    before = free_bytes()
+    for _ in range(10):
+        cycle()
+    after = free_bytes()
+    assert before - after < 8 << 20, f"{(before - after) >> 20} MiB of device memory not returned"
+
+
 # ----------------------------------------------------- revision / re-upload
 def test_device_copy_follows_with_block_updates(api):
     system = systems.swave_square(api, L=6, gap=0.0)
