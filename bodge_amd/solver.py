@@ -180,6 +180,8 @@ class DeviceSolver:
     def lanczos_advance(self, n_iter: int):
         """Run n_iter more iterations; returns (alpha, beta) of shape (n_iter, n_vectors): diagonal and
         off-diagonal (beta_{j+1}) of the tridiagonal representation of H^2."""
+        if not getattr(self, "_lanczos_vectors", 0):
+            raise ValueError("bodge_hip: lanczos_begin has not been called on this handle")
         alpha = np.empty((n_iter, self._lanczos_vectors))
         beta = np.empty((n_iter, self._lanczos_vectors))
         backend.check(self._lib.bdg_lanczos_advance(self._handle, n_iter, backend.as_f64p(alpha), backend.as_f64p(beta)))

@@ -517,6 +517,38 @@ def test_ldos_is_positive_everywhere(api):
         assert np.all(system.ldos(site, energies) >= 0)
 
 
+def test_c_abi_rejects_malformed_input(api, solver_cls, hip_library):
+    """Error behaviour at the boundary: every malformed matrix or argument is refused with a
+    message (ValueError for caller mistakes), nothing reaches a kernel."""
+    rng = np.random.default_rng(0)
+    good_ptr = np.array([0, 2, 4], dtype=np.int32)
+    good_idx = np.array([0, 1, 0, 1], dtype=np.int32)
+    data = rng.standard_normal((4, 4, 4)) + 0j
+    cases = {
+        "indptr does not span": (np.array([0, 2, 3], dtype=np.int32), good_idx),
+        "not monotone": (np.array([0, 3, 2, 4], dtype=np.int32)[:3], good_idx),
+        "out of range": (good_ptr, np.array([0, 1, 0, 2], dtype=np.int32)),
+        "duplicate": (good_ptr, np.array([0, 0, 0, 1], dtype=np.int32)),
+        "not sorted": (good_ptr, np.array([1, 0, 0, 1], dtype=np.int32)),
+    }
+    for fragment, (ptr, idx) in cases.items():
+        with pytest.raises(ValueError) as err:
+            solver_cls(ptr, idx, data)
+        assert "bodge_hip" in str(err.value), fragment
+    with solver_cls(good_ptr, good_idx, data) as dev:
+        with pytest.raises(ValueError):
+            dev.dots_random(-1.0, 4, 2)          # scale must be positive
+        with pytest.raises(ValueError):
+            dev.dots_random(1.0, 0, 2)           # at least one step
+        with pytest.raises(ValueError):
+            dev.dots_random(1.0, 4, 0)           # at least one vector
+        with pytest.raises(ValueError):
+            dev.moments_unit(1.0, 8, np.array([99], dtype=np.int64))  # row outside the matrix
+        with pytest.raises(ValueError):
+            dev.lanczos_advance(4)               # begin was not called
+        assert np.isfinite(dev.dots_random(10.0, 4, 2)[0]).all()  # the handle is still usable
+
+
 def test_handles_release_their_device_memory(api, solver_cls):
     """Create / use / destroy in a loop (recurrence, unit moments, Lanczos, dense eigensolver, slab
     group): free device memory must return to where it started."""
