@@ -112,6 +112,7 @@ struct bdg_system {
     int split_rows_per_tile = 0, n_interior = 0, n_boundary = 0;
     void* lanczos = nullptr;  // LanczosState of a run in progress (defined with the driver)
     int max_row_blocks = 0;
+    int64_t bandwidth = 0;  // max |column - row| over the stored blocks (square matrices)
     int num_cus = 0;
     int lanes_override = 0;
     DeviceBuffer<int> indptr, indices;
@@ -644,6 +645,9 @@ struct Batch {
     bdg::StepArgs args{};
     bool real = false;
     bool alternate = false;  // dictionary kernel: sweep direction flips every launch
+    // unit start vectors: block rows that can be non-zero after n steps are within
+    // (n + 1) * bandwidth of [band_lo, band_hi]; -1 = no band (random vectors, slabs, strip order)
+    int64_t band_lo = -1, band_hi = -1;
     ModeInfo mode{};
     int rl = 0, rv = 0, n_active = 0, n_steps = 0, chunk = 1, strip_rows = 0;
     size_t width = 0, per_step = 0, vec_count = 0;
@@ -727,6 +731,14 @@ struct Batch {
             if (int rc = sys->rows.reserve(64)) return rc;
             HIP_TRY(hipMemcpyAsync(sys->rows.ptr, start.rows, sizeof(int64_t) * n_active,
                                    hipMemcpyHostToDevice, st));
+            if (sys->ncols == sys->nb && !getenv("BODGE_AMD_NO_BAND")) {
+                band_lo = sys->nb;
+                band_hi = 0;
+                for (int r = 0; r < n_active; ++r) {
+                    band_lo = std::min<int64_t>(band_lo, start.rows[r] >> 2);
+                    band_hi = std::max<int64_t>(band_hi, start.rows[r] >> 2);
+                }
+            }
             bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, (int64_t)vec_count);
             if (real)
                 bdg::set_unit_real<<<1, 64, 0, st>>>(reinterpret_cast<double*>(sys->vec_a.ptr), sys->nb,
@@ -743,6 +755,7 @@ struct Batch {
         if (int rc = prepare_tile_order(sys, plan.rows_per_tile, plan.n_tiles,
                                         (real ? 32.0 : 64.0) * rv, &args.tile_order, &strip_rows))
             return rc;
+        if (args.tile_order) band_lo = band_hi = -1;  // the band is a range of naturally ordered tiles
         cur = sys->vec_a.ptr;
         prev = sys->vec_b.ptr;
         kernel_ms = 0.f;
@@ -929,6 +942,18 @@ struct Batch {
         args.coef = (n == 0 ? 1.0 : 2.0) / scale;
         args.partial = sys->partial.ptr + (size_t)in_chunk * per_step;
         args.reverse = alternate ? (n & 1) : 0;
+        args.tile_base = 0;
+        args.n_tiles = plan.n_tiles;
+        if (band_lo >= 0) {
+            // t_{n+1} can be non-zero only where t_n or a neighbour within the bandwidth was
+            const int64_t reach = (int64_t)(n + 1) * sys->bandwidth;
+            const int64_t lo = std::max<int64_t>(0, band_lo - reach);
+            const int64_t hi = std::min<int64_t>(sys->nb, band_hi + reach + 1);
+            const int first = (int)(lo / plan.rows_per_tile);
+            const int last = (int)((hi + plan.rows_per_tile - 1) / plan.rows_per_tile);
+            args.tile_base = first;
+            args.n_tiles = std::min(plan.n_tiles, last) - first;
+        }
         plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
         std::swap(cur, prev);
         if (in_chunk == chunk - 1 || n == n_steps - 1) {
@@ -1344,6 +1369,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
         return fail(BDG_EINVAL, "matrix too large for 32-bit block indexing");
     if (indptr[0] != 0 || indptr[nb] != nnzb) return fail(BDG_EINVAL, "indptr does not span the blocks");
     int max_row = 0;
+    int64_t bandwidth = 0;
     for (int64_t i = 0; i < nb; ++i)
         if (indptr[i + 1] < indptr[i] || indptr[i + 1] > nnzb)
             return fail(BDG_EINVAL, "indptr is not monotone within [0, nnzb] at row %lld", (long long)i);
@@ -1358,6 +1384,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
                 return fail(BDG_EINVAL, "row %lld has a duplicate column", (long long)i);
             if (ncols == nb && k > indptr[i] && indices[k] < indices[k - 1])
                 return fail(BDG_EINVAL, "row %lld is not sorted", (long long)i);
+            bandwidth = std::max<int64_t>(bandwidth, std::llabs((long long)indices[k] - (long long)i));
         }
     }
     bool is_real = true;
@@ -1423,6 +1450,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     sys->row_offset = row_offset;
     sys->nnzb = nnzb;
     sys->max_row_blocks = std::max(1, max_row);
+    sys->bandwidth = bandwidth;
     if (ncols > nb) {
         sys->row_needs_halo.assign((size_t)nb, 0);
         for (int64_t i = 0; i < nb; ++i)

@@ -214,6 +214,9 @@ struct StepArgs {
     // direction from one launch to the next re-reads first what the previous launch touched last,
     // i.e. what the Infinity Cache still holds.
     int reverse;
+    // first tile of the launch when only a band of block rows is swept (natural order only):
+    // unit start vectors spread by at most the matrix bandwidth per step, the rest is still zero
+    int tile_base;
 };
 
 // Arithmetic modes.  A lane's 16-byte payload is either one complex number of
@@ -413,7 +416,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
 
     for (int t = t_lo + slot; t < t_hi; t += slots) {
         const int tt = a.reverse ? t_lo + t_hi - 1 - t : t;
-        const int tile = a.tile_order ? a.tile_order[tt] : tt;
+        const int tile = a.tile_order ? a.tile_order[tt] : tt + a.tile_base;
         const int row0 = (tile * kWavesPerBlock + wave) * RW;
         if (row0 >= a.nb) continue;
         const int row_end = min(row0 + RW, a.nb);
@@ -543,7 +546,7 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
     auto first_row = [&](int t) {
         if (t >= t_hi) return a.nb;
         const int tt = a.reverse ? t_lo + t_hi - 1 - t : t;
-        const int tile = a.tile_order ? a.tile_order[tt] : tt;
+        const int tile = a.tile_order ? a.tile_order[tt] : tt + a.tile_base;
         return (tile * kWavesPerBlock + wave) * RW;
     };
 
@@ -714,7 +717,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
     auto first_row = [&](int t) {
         if (t >= t_hi) return a.nb;
         const int tt = a.reverse ? t_lo + t_hi - 1 - t : t;
-        const int tile = a.tile_order ? a.tile_order[tt] : tt;
+        const int tile = a.tile_order ? a.tile_order[tt] : tt + a.tile_base;
         return (tile * kWavesPerBlock + wave) * RW;
     };
     // one word per stored block: column in the low 24 bits, table index in the high 8
