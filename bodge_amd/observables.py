@@ -10,7 +10,7 @@ Routing (all device-side; there is no CPU path):
            recurrence kernel advances R start vectors together; exact trace
            (unit vectors of the electron rows, x2 by particle-hole symmetry) up to
            4N = EXACT_TRACE_LIMIT, stochastic trace beyond.  T = 0 is expanded at the
-           surrogate temperature gap/30 when the spectrum is gapped.
+           surrogate temperature gap/20 when the spectrum is gapped.
 
 `method="auto"` picks, by estimated run time, between the dense eigensolver
 (4N <= DENSE_AUTO_LIMIT: the library-free Jacobi kernels; rocSOLVER up to
@@ -26,6 +26,7 @@ from .backend import VEC_RADEMACHER, VEC_Z4
 
 DENSE_AUTO_LIMIT = 2048  # largest 4N served by the own Jacobi kernels (kJacobiLimit in the library)
 DENSE_AUTO_LIMIT_T0 = 16384  # largest 4N method="auto" ever sends to a dense eigensolver
+GAP_SURROGATE_RATIO = 20.0  # T = 0 is expanded at T = gap / this (see free_energy)
 EXACT_TRACE_LIMIT = 65536  # largest 4N for which trace="auto" is exact (128x128 sites: ~2 s at T = 0.1)
 
 
@@ -86,7 +87,7 @@ def _auto_method(system, temperature: float, moments, scale) -> str:
     """Dense or Chebyshev for `free_energy(method="auto")`, by estimated run time.
 
     T = 0: dense within reach of the own Jacobi kernels; above, the Chebyshev expansion at the
-    surrogate temperature gap/30 (see `free_energy`) when the spectrum is gapped enough, else the
+    surrogate temperature gap/20 (see `free_energy`) when the spectrum is gapped enough, else the
     dense library.  Matrices without the particle-hole form must go dense.  Otherwise the two
     routes are priced with measured constants (profiles/r01_wall_table.log): the Jacobi kernels
     cost ≈ 8e-11·(4N)³ s (0.35 s at 4N = 1600), rocSOLVER ≈ 2e-12·(4N)³ s plus its
@@ -100,12 +101,12 @@ def _auto_method(system, temperature: float, moments, scale) -> str:
         return "dense"
     a = _scale_of(system) if scale is None else float(scale)
     if temperature == 0:
-        # beyond the own Jacobi kernels: Chebyshev at T = gap/30 if the spectrum is gapped enough
+        # beyond the own Jacobi kernels: Chebyshev at T = gap/20 if the spectrum is gapped enough
         # for that expansion to converge within the moment cap, the dense library otherwise
         if dim <= DENSE_AUTO_LIMIT or moments is not None:
             return "dense"
         gap = _gap_estimate(system)
-        gapped = gap > 0 and cheb.moments_for_free_energy(a, gap / 30.0) < (1 << 17)
+        gapped = gap > 0 and cheb.moments_for_free_energy(a, gap / GAP_SURROGATE_RATIO) < (1 << 17)
         return "chebyshev" if gapped else "dense"
     m = cheb.moments_for_free_energy(a, temperature) if moments is None else int(moments)
     batches = -(-(dim // 2) // 64) if dim <= EXACT_TRACE_LIMIT else 1  # electron rows only
@@ -139,7 +140,7 @@ def free_energy(
     trace    "exact" (all 4N unit vectors), "stochastic", or "auto"
     vectors  number of random vectors for the stochastic trace (default 64)
     gap_surrogate  at T = 0 with the Chebyshev method and no explicit `moments`: expand f at
-             T = gap/30 instead (gap from `lowest_eigenvalues`), which differs from f_0 by ~1e-13 on a
+             T = gap/20 instead (gap from `lowest_eigenvalues`), which differs from f_0 by ~1e-14 on a
              gapped spectrum but converges geometrically; False keeps the plain T = 0 coefficients
     comm     optional `Communicator` (one process per GPU)
     decomposition  how the ranks of `comm` share the work:
@@ -178,13 +179,13 @@ def free_energy(
     if temperature == 0 and moments is None and gap_surrogate and decomposition != "slab":
         # f_0(ε) = -|ε|/4 has a kink at ε = 0, but a gapped spectrum never samples it: for T ≪ gap
         # f_T - f_0 = -(T/2) log1p(e^{-|ε|/T}) ≤ (T/2) e^{-gap/T} on the spectrum, and f_T is analytic.
-        # With T = gap/30 the difference is ~1e-13 and the series converges geometrically
-        # (20x20 README model: 8e-15 of the dense value with 16384 moments, against 3e-9 for the
-        # T = 0 coefficients).  The Lanczos estimate of the gap approaches it from above; the
-        # factor 30 leaves room for that.  A gapless spectrum keeps the plain T = 0 series.
+        # With T = gap/20 the difference is ~1e-14 relative (20x20 README model: 8e-15 of the dense
+        # value with 16384 moments, against 3e-9 for the T = 0 coefficients; gap/10 would leave
+        # 5e-10) and the series converges geometrically.  The Lanczos estimate approaches the gap
+        # from above, to 1e-3.  A gapless spectrum keeps the plain T = 0 series.
         gap = _gap_estimate(system)
         if gap > 1e-9 * scale:
-            series_temperature = gap / 30.0
+            series_temperature = gap / GAP_SURROGATE_RATIO
     if moments is None:
         moments = cheb.moments_for_free_energy(scale, series_temperature)
     moments += moments & 1

@@ -359,7 +359,7 @@ def test_free_energy_default_moment_rule_reaches_1e10(api, golden):
 @pytest.mark.parametrize("name", ["swave20_zeeman", "snf"])
 def test_zero_temperature_chebyshev_on_a_gapped_spectrum(api, golden, name):
     """T = 0 beyond dense reach: |ε| is not analytic, but on a gapped spectrum the expansion of f at
-    T = gap/30 (gap from Lanczos) reproduces the dense T = 0 value; the plain T = 0 coefficients
+    T = gap/20 (gap from Lanczos) reproduces the dense T = 0 value; the plain T = 0 coefficients
     with the same number of moments do not."""
     system = _build(api, name)
     exact = golden.free_energy(name, 0.0)
