@@ -1052,21 +1052,59 @@ __device__ inline void jacobi_pair(int n, int round, int k, int& p, int& q) {
     }
 }
 
-__global__ __launch_bounds__(256) void jacobi_round(double2* __restrict__ G, double2* __restrict__ V, int n,
-                                                    int round, double tol, int* __restrict__ rotations) {
+// Scalar helpers so that one kernel text serves complex (double2) and real (double) matrices; the
+// real form is used when imag(H) = 0 (rotations then have no phase): half the bytes.
+__device__ inline double jnorm2(double2 x) { return fma(x.x, x.x, x.y * x.y); }
+__device__ inline double jnorm2(double x) { return x * x; }
+__device__ inline double2 jdot(double2 x, double2 y) {  // conj(x) y
+    return make_double2(fma(x.x, y.x, x.y * y.y), fma(x.x, y.y, -x.y * y.x));
+}
+__device__ inline double2 jdot(double x, double y) { return make_double2(x * y, 0.0); }
+// (nx, ny) = (cs x - sn e^{-iφ} y,  sn e^{iφ} x + cs y),  e^{iφ} = er + i ei
+__device__ inline void jrotate(double2& x, double2& y, double cs, double sn, double er, double ei) {
+    const double s1r = sn * er, s1i = -sn * ei, s2r = sn * er, s2i = sn * ei;
+    double2 nx, ny;
+    nx.x = cs * x.x - (s1r * y.x - s1i * y.y);
+    nx.y = cs * x.y - (s1r * y.y + s1i * y.x);
+    ny.x = (s2r * x.x - s2i * x.y) + cs * y.x;
+    ny.y = (s2r * x.y + s2i * x.x) + cs * y.y;
+    x = nx;
+    y = ny;
+}
+__device__ inline void jrotate(double& x, double& y, double cs, double sn, double er, double) {
+    const double s = sn * er;  // er = ±1
+    const double nx = cs * x - s * y, ny = s * x + cs * y;
+    x = nx;
+    y = ny;
+}
+
+// One round.  The two columns of G stay in registers between the dot products and the rotation
+// (n <= 256 * kJacobiElems), so G is read once and written once per round; V is read and written.
+constexpr int kJacobiElems = 8;
+
+template <typename T>
+__global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ G, T* __restrict__ V, int n, int round,
+                                                    double tol, int* __restrict__ rotations) {
     __shared__ double red[4][256];
     __shared__ double rot[4];  // cs, sn, cos φ, sin φ  (sn = 0: skip)
     int p, q;
     jacobi_pair(n, round, blockIdx.x, p, q);
-    double2* gp = G + (size_t)p * n;
-    double2* gq = G + (size_t)q * n;
+    T* gp = G + (size_t)p * n;
+    T* gq = G + (size_t)q * n;
+    T x[kJacobiElems], y[kJacobiElems];
     double a = 0.0, b = 0.0, cr = 0.0, ci = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) {
-        const double2 x = gp[i], y = gq[i];
-        a = fma(x.x, x.x, fma(x.y, x.y, a));
-        b = fma(y.x, y.x, fma(y.y, y.y, b));
-        cr = fma(x.x, y.x, fma(x.y, y.y, cr));   // Re conj(x) y
-        ci = fma(x.x, y.y, fma(-x.y, y.x, ci));  // Im conj(x) y
+#pragma unroll
+    for (int u = 0; u < kJacobiElems; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < n) {
+            x[u] = gp[i];
+            y[u] = gq[i];
+            a += jnorm2(x[u]);
+            b += jnorm2(y[u]);
+            const double2 c = jdot(x[u], y[u]);
+            cr += c.x;
+            ci += c.y;
+        }
     }
     red[0][threadIdx.x] = a;
     red[1][threadIdx.x] = b;
@@ -1099,43 +1137,52 @@ __global__ __launch_bounds__(256) void jacobi_round(double2* __restrict__ G, dou
     const double sn = rot[1];
     if (sn == 0.0) return;
     const double cs = rot[0], er = rot[2], ei = rot[3];
-    // s1 = sn e^{-iφ} (multiplies column q into p), s2 = sn e^{iφ} (multiplies column p into q)
-    const double s1r = sn * er, s1i = -sn * ei, s2r = sn * er, s2i = sn * ei;
-    for (int pass = 0; pass < 2; ++pass) {
-        double2* xp = pass == 0 ? gp : (V ? V + (size_t)p * n : nullptr);
-        double2* xq = pass == 0 ? gq : (V ? V + (size_t)q * n : nullptr);
-        if (!xp) break;
+#pragma unroll
+    for (int u = 0; u < kJacobiElems; ++u) {
+        const int i = threadIdx.x + 256 * u;
+        if (i < n) {
+            jrotate(x[u], y[u], cs, sn, er, ei);
+            gp[i] = x[u];
+            gq[i] = y[u];
+        }
+    }
+    if (V) {
+        T* vp = V + (size_t)p * n;
+        T* vq = V + (size_t)q * n;
         for (int i = threadIdx.x; i < n; i += 256) {
-            const double2 x = xp[i], y = xq[i];
-            double2 nx, ny;
-            nx.x = cs * x.x - (s1r * y.x - s1i * y.y);
-            nx.y = cs * x.y - (s1r * y.y + s1i * y.x);
-            ny.x = (s2r * x.x - s2i * x.y) + cs * y.x;
-            ny.y = (s2r * x.y + s2i * x.x) + cs * y.y;
-            xp[i] = nx;
-            xq[i] = ny;
+            T vx = vp[i], vy = vq[i];
+            jrotate(vx, vy, cs, sn, er, ei);
+            vp[i] = vx;
+            vq[i] = vy;
         }
     }
 }
 
 // G += shift * I;  V = I (if given)
-__global__ void jacobi_setup(double2* __restrict__ G, double2* __restrict__ V, int n, double shift) {
+__device__ inline void jadd_real(double2& g, double v) { g.x += v; }
+__device__ inline void jadd_real(double& g, double v) { g += v; }
+__device__ inline void jset_real(double2& g, double v) { g = make_double2(v, 0.0); }
+__device__ inline void jset_real(double& g, double v) { g = v; }
+
+template <typename T>
+__global__ void jacobi_setup(T* __restrict__ G, T* __restrict__ V, int n, double shift) {
     const int64_t total = (int64_t)n * n;
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
         const bool diag = (idx / n) == (idx % n);
-        if (diag) G[idx].x += shift;
-        if (V) V[idx] = make_double2(diag ? 1.0 : 0.0, 0.0);
+        if (diag) jadd_real(G[idx], shift);
+        if (V) jset_real(V[idx], diag ? 1.0 : 0.0);
     }
 }
 
 // eig[p] = |g_p| - shift, one block per column
-__global__ __launch_bounds__(256) void jacobi_eigenvalues(const double2* __restrict__ G, int n, double shift,
+template <typename T>
+__global__ __launch_bounds__(256) void jacobi_eigenvalues(const T* __restrict__ G, int n, double shift,
                                                           double* __restrict__ eig) {
     __shared__ double red[256];
-    const double2* g = G + (size_t)blockIdx.x * n;
+    const T* g = G + (size_t)blockIdx.x * n;
     double a = 0.0;
-    for (int i = threadIdx.x; i < n; i += 256) a = fma(g[i].x, g[i].x, fma(g[i].y, g[i].y, a));
+    for (int i = threadIdx.x; i < n; i += 256) a += jnorm2(g[i]);
     red[threadIdx.x] = a;
     __syncthreads();
     for (int stride = 128; stride > 0; stride >>= 1) {

@@ -1,7 +1,7 @@
 import sys, time
 sys.path.insert(0, "."); sys.path.insert(0, "tests")
 import numpy as np, bodge_amd as ba, systems, bench
-for L in (3, 8, 13, 20, 30):
+for L in (3, 8, 13, 20, 22):  # 4N <= 2048: the own kernels (larger sizes would load rocSOLVER)
     s = bench.build_system([L, L, 1]) if L != 13 else systems.random_periodic(ba)
     n = s.shape[0]
     dense = np.asarray(s.matrix("dense"))
