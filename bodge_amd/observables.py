@@ -90,7 +90,7 @@ def _auto_method(system, temperature: float, moments, scale) -> str:
     surrogate temperature gap/20 (see `free_energy`) when the spectrum is gapped enough, else the
     dense library.  Matrices without the particle-hole form must go dense.  Otherwise the two
     routes are priced with measured constants (profiles/r01_wall_table.log): the Jacobi kernels
-    cost ≈ 8e-11·(4N)³ s (0.35 s at 4N = 1600), rocSOLVER ≈ 2e-12·(4N)³ s plus its
+    cost ≈ 6e-11·(4N)³ s (0.25 s at 4N = 1600), rocSOLVER ≈ 2e-12·(4N)³ s plus its
     load time; an exact-trace Chebyshev run costs M/2 launches per batch of 64 unit vectors, each
     ≥ 7 µs or its HBM time.  Both routes meet the 1e-10 relative accuracy the tests ask for.
     """
@@ -112,7 +112,7 @@ def _auto_method(system, temperature: float, moments, scale) -> str:
     batches = -(-(dim // 2) // 64) if dim <= EXACT_TRACE_LIMIT else 1  # electron rows only
     launch = max(7e-6, (dim // 4) * 64 * 192 / 5e12)
     chebyshev_seconds = 0.5 * m * batches * launch
-    dense_seconds = 8e-11 * dim**3 if dim <= DENSE_AUTO_LIMIT else 2.0 + 2e-12 * dim**3
+    dense_seconds = 6e-11 * dim**3 if dim <= DENSE_AUTO_LIMIT else 2.0 + 2e-12 * dim**3
     return "dense" if dense_seconds <= chebyshev_seconds else "chebyshev"
 
 
