@@ -1416,26 +1416,9 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
             bandwidth = std::max<int64_t>(bandwidth, std::llabs((long long)indices[k] - (long long)i));
         }
     }
-    bool is_real = true;
-    for (int64_t q = 0; q < nnzb * 16 && is_real; ++q) is_real = data[2 * q + 1] == 0.0;
-    double gershgorin = 0.0;
-    for (int64_t i = 0; i < nb; ++i) {
-        double row_sum[4] = {0.0, 0.0, 0.0, 0.0};
-        for (int k = indptr[i]; k < indptr[i + 1]; ++k)
-            for (int e = 0; e < 16; ++e)
-                row_sum[e >> 2] += std::hypot(data[2 * ((int64_t)k * 16 + e)], data[2 * ((int64_t)k * 16 + e) + 1]);
-        for (double v : row_sum) gershgorin = std::max(gershgorin, v);
-    }
-    // particle-hole form: lower-right 2x2 == -conj(upper-left 2x2), exactly, in every block
-    bool is_ph = true;
-    for (int64_t k = 0; k < nnzb && is_ph; ++k)
-        for (int i = 0; i < 2 && is_ph; ++i)
-            for (int j = 0; j < 2; ++j) {
-                const double* a = data + 2 * (k * 16 + i * 4 + j);
-                const double* d = data + 2 * (k * 16 + (i + 2) * 4 + (j + 2));
-                if (d[0] != -a[0] || d[1] != a[1]) is_ph = false;
-            }
     // Distinct blocks (exact, bitwise).  Gives up as soon as there are too many to be useful.
+    // A lattice matrix repeats a handful of blocks, mostly in runs: the four most recent ones are
+    // compared directly before the hash map is asked.
     constexpr int kMaxDistinct = 256;  // table index shares a 32-bit word with the 24-bit column
     std::vector<int> ids;
     std::vector<double> distinct;  // n_unique x 32 doubles
@@ -1444,24 +1427,93 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
         bool wanted = !(env && env[0] == '0') && nnzb > 0 && ncols <= (1 << 24);
         if (wanted) {
             std::unordered_map<std::string_view, int> seen;
+            const double* recent_key[4] = {nullptr, nullptr, nullptr, nullptr};
+            int recent_id[4] = {0, 0, 0, 0};
+            int recent_next = 0;
             ids.resize((size_t)nnzb);
             for (int64_t k = 0; k < nnzb; ++k) {
-                std::string_view key(reinterpret_cast<const char*>(data + 32 * k), 256);
-                auto it = seen.find(key);
-                if (it == seen.end()) {
-                    if ((int)seen.size() == kMaxDistinct) {
-                        wanted = false;
-                        break;
+                const double* block = data + 32 * k;
+                int id = -1;
+                for (int m = 0; m < 4 && id < 0; ++m)
+                    if (recent_key[m] && memcmp(recent_key[m], block, 256) == 0) id = recent_id[m];
+                if (id < 0) {
+                    std::string_view key(reinterpret_cast<const char*>(block), 256);
+                    auto it = seen.find(key);
+                    if (it == seen.end()) {
+                        if ((int)seen.size() == kMaxDistinct) {
+                            wanted = false;
+                            break;
+                        }
+                        it = seen.emplace(key, (int)seen.size()).first;
+                        distinct.insert(distinct.end(), block, block + 32);
                     }
-                    it = seen.emplace(key, (int)seen.size()).first;
-                    distinct.insert(distinct.end(), data + 32 * k, data + 32 * (k + 1));
+                    id = it->second;
+                    recent_key[recent_next] = block;
+                    recent_id[recent_next] = id;
+                    recent_next = (recent_next + 1) & 3;
                 }
-                ids[(size_t)k] = (int)((unsigned)indices[k] | ((unsigned)it->second << 24));
+                ids[(size_t)k] = (int)((unsigned)indices[k] | ((unsigned)id << 24));
             }
         }
         if (!wanted) {
             ids.clear();
             distinct.clear();
+        }
+    }
+    // Properties of the matrix: imag(H) == 0, particle-hole form of every block (lower-right 2x2 ==
+    // -conj(upper-left 2x2), exactly), Gershgorin bound.  With a block dictionary they follow from
+    // the distinct blocks and the ids; otherwise every stored block is scanned.
+    auto block_is_real = [](const double* blk) {
+        for (int e = 0; e < 16; ++e)
+            if (blk[2 * e + 1] != 0.0) return false;
+        return true;
+    };
+    auto block_is_ph = [](const double* blk) {
+        for (int i = 0; i < 2; ++i)
+            for (int j = 0; j < 2; ++j) {
+                const double* a = blk + 2 * (i * 4 + j);
+                const double* d = blk + 2 * ((i + 2) * 4 + (j + 2));
+                if (d[0] != -a[0] || d[1] != a[1]) return false;
+            }
+        return true;
+    };
+    auto block_row_sums = [](const double* blk, double out[4]) {
+        for (int r = 0; r < 4; ++r) {
+            out[r] = 0.0;
+            for (int c = 0; c < 4; ++c) out[r] += std::hypot(blk[2 * (4 * r + c)], blk[2 * (4 * r + c) + 1]);
+        }
+    };
+    bool is_real = true, is_ph = true;
+    double gershgorin = 0.0;
+    if (!ids.empty()) {
+        const size_t n_distinct = distinct.size() / 32;
+        std::vector<double> sums(4 * n_distinct);
+        for (size_t d = 0; d < n_distinct; ++d) {
+            is_real = is_real && block_is_real(distinct.data() + 32 * d);
+            is_ph = is_ph && block_is_ph(distinct.data() + 32 * d);
+            block_row_sums(distinct.data() + 32 * d, sums.data() + 4 * d);
+        }
+        for (int64_t i = 0; i < nb; ++i) {
+            double row_sum[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
+                const double* sum = sums.data() + 4 * ((unsigned)ids[(size_t)k] >> 24);
+                for (int r = 0; r < 4; ++r) row_sum[r] += sum[r];
+            }
+            for (double v : row_sum) gershgorin = std::max(gershgorin, v);
+        }
+    } else {
+        for (int64_t k = 0; k < nnzb && (is_real || is_ph); ++k) {
+            is_real = is_real && block_is_real(data + 32 * k);
+            is_ph = is_ph && block_is_ph(data + 32 * k);
+        }
+        for (int64_t i = 0; i < nb; ++i) {
+            double row_sum[4] = {0.0, 0.0, 0.0, 0.0};
+            for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
+                double sum[4];
+                block_row_sums(data + 32 * (int64_t)k, sum);
+                for (int r = 0; r < 4; ++r) row_sum[r] += sum[r];
+            }
+            for (double v : row_sum) gershgorin = std::max(gershgorin, v);
         }
     }
     int n_dev = 0;
