@@ -103,6 +103,7 @@ class Hamiltonian:
         self._devices: dict = {}
         self._device_revision = -1
         self._memo: dict = {}
+        self._recheck_all = False  # set when a Hermiticity check failed: the next one covers everything
         self._memo_revision = -1
 
     def _skeleton_pairs(self) -> tuple[np.ndarray, np.ndarray]:
@@ -142,6 +143,7 @@ class Hamiltonian:
 
     def __exit__(self, exc_type, exc_val, exc_tb):
         data = self._data
+        touched = np.zeros(len(data), dtype=bool)
         for table, is_pairing in ((self._hopp, False), (self._pair, True)):
             batches = list(table._bulk)
             keyed = self._dict_to_arrays(table)
@@ -149,6 +151,7 @@ class Hamiltonian:
                 batches.append(keyed)
             for rows, cols, vals in batches:
                 k = self._block_ids(rows, cols)
+                touched[k] = True
                 if is_pairing:
                     data[k, 0:2, 2:4] = vals
                     data[self._mirror[k], 2:4, 0:2] = vals.conj().transpose(0, 2, 1)
@@ -159,21 +162,33 @@ class Hamiltonian:
         del self._pair
         self._revision += 1
 
-        if self._hermiticity_defect() > 1e-6:
+        # Blocks this `with` did not write were checked when they were written (and start out zero),
+        # unless that earlier check failed and left the matrix in a non-Hermitian state.
+        everything = self._recheck_all or bool(touched.all())
+        defect = self._hermiticity_defect(None if everything else np.flatnonzero(touched))
+        self._recheck_all = defect > 1e-6
+        if self._recheck_all:
             raise RuntimeError("The constructed Hamiltonian is not Hermitian!")
 
-    def _hermiticity_defect(self, chunk: int = 8192) -> float:
-        """max |H - H^†| over stored entries, block (i,j) against block (j,i)^†.
+    def _hermiticity_defect(self, blocks: np.ndarray | None = None, chunk: int = 8192) -> float:
+        """max |H - H^†| over stored entries, block (i,j) against block (j,i)^†, for the given block
+        ids (default: all).
 
         Same criterion as the reference's sparse `M - M.getH()` (ref :121-122),
         evaluated in cache-sized chunks so a 10^6-site matrix takes seconds.
         """
         data, mirror, worst = self._data, self._mirror, 0.0
-        for lo in range(0, len(data), chunk):
-            part = data[lo : lo + chunk]
-            twin = data[mirror[lo : lo + chunk]]
-            diff = part - twin.conj().transpose(0, 2, 1)
-            worst = max(worst, float(np.abs(diff).max()))
+        if blocks is None:
+            for lo in range(0, len(data), chunk):
+                part = data[lo : lo + chunk]
+                twin = data[mirror[lo : lo + chunk]]
+                diff = part - twin.conj().transpose(0, 2, 1)
+                worst = max(worst, float(np.abs(diff).max()))
+            return worst
+        for lo in range(0, len(blocks), chunk):
+            ids = blocks[lo : lo + chunk]
+            diff = data[ids] - data[mirror[ids]].conj().transpose(0, 2, 1)
+            worst = max(worst, float(np.abs(diff).max(initial=0.0)))
         return worst
 
     def has_symmetric_spectrum(self, tol: float = 0.0) -> bool:

@@ -276,3 +276,28 @@ def test_random_lattices_assemble_like_the_reference_restatement(api, seed):
     assert np.array_equal(np.asarray(trimmed.todense()), np.asarray(ref.todense()))
     ptr, idx, dat = system.bsr_arrays()
     assert np.array_equal(idx, trimmed.indices) and np.array_equal(ptr, trimmed.indptr) and np.array_equal(dat, trimmed.data)
+
+
+def test_partial_updates_are_checked_and_a_failed_check_is_not_forgotten(api):
+    """Re-entering `with` checks Hermiticity of the blocks it wrote; after a failed check the next
+    one covers the whole matrix again (the bad block must not slip through)."""
+    lattice = api.CubicLattice((4, 3, 1))
+    system = api.Hamiltonian(lattice)
+    with system as (H, Δ):
+        for i in lattice.sites():
+            H[i, i] = 1.0 * api.σ0
+        for i, j in lattice.bonds():
+            H[i, j] = -1.0 * api.σ0
+    with pytest.raises(RuntimeError):
+        with system as (H, Δ):
+            H[(0, 0, 0), (1, 0, 0)] = 2.0 * api.σ0  # its partner (1,0,0)->(0,0,0) still holds -1
+    with pytest.raises(RuntimeError):
+        with system as (H, Δ):
+            H[(2, 2, 0), (2, 2, 0)] = 0.5 * api.σ3  # fine by itself: the earlier damage must still be seen
+    with system as (H, Δ):
+        H[(1, 0, 0), (0, 0, 0)] = 2.0 * api.σ0      # repaired
+    assert system._hermiticity_defect() == 0.0
+    with system as (H, Δ):
+        H[(3, 1, 0), (3, 1, 0)] = 0.25 * api.σ1      # partial update on a healthy matrix
+    dense = np.asarray(system.matrix("dense"))
+    assert np.array_equal(dense, dense.conj().T)
