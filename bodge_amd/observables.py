@@ -59,7 +59,7 @@ def _unit_moments(system, scale: float, moments: int, rows: np.ndarray) -> np.nd
     device mirrors, each with its own stream and buffers, are driven from two host threads (the
     library is thread safe per handle, ctypes releases the GIL): 1.5-1.9x at 32x32 … 100x100.
     """
-    lanes = 2 if (len(rows) >= 512 and system.lattice.size <= CONCURRENT_TRACE_MAX_SITES) else 1
+    lanes = 2 if (len(rows) >= 128 and system.lattice.size <= CONCURRENT_TRACE_MAX_SITES) else 1
     if lanes == 1:
         return system._solver().moments_unit(scale, moments, rows)
     from concurrent.futures import ThreadPoolExecutor
@@ -73,8 +73,13 @@ def _unit_moments(system, scale: float, moments: int, rows: np.ndarray) -> np.nd
 
 
 def _unit_moment_sum(system, scale: float, moments: int, rows: np.ndarray) -> np.ndarray:
-    """Σ over `rows` of the unit-vector moments, shape (moments,)."""
-    return _unit_moments(system, scale, moments, rows).sum(axis=1)
+    """Σ over `rows` of the unit-vector moments, shape (moments,).  Rows are fed in slices so that
+    the (moments x rows) table never exceeds ~128 MB on the host (low temperatures: 10^4-10^5 moments)."""
+    step = max(64, ((1 << 24) // max(1, moments)) // 64 * 64)
+    total = np.zeros(moments)
+    for lo in range(0, len(rows), 2 * step):  # two device mirrors take `step` rows each
+        total += _unit_moments(system, scale, moments, rows[lo : lo + 2 * step]).sum(axis=1)
+    return total
 
 
 def _gap_estimate(system) -> float:
