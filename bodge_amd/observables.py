@@ -232,6 +232,32 @@ def free_energy(
     return cheb.free_energy_series(mu, scale, series_temperature, damping=damping)
 
 
+def free_energy_stochastic(system, temperature: float, *, moments: int | None = None, vectors: int = 64,
+                           seed: int = 0, vector_kind: str = "rademacher", scale: float | None = None):
+    """(F, σ): stochastic-trace free energy and its standard error, from the spread of the
+    per-vector estimates F_r = Σ_m c_m μ_m^{(r)} (F is their mean; σ = std(F_r)/√R).
+
+    For lattices beyond the exact trace this tells how many vectors a wanted accuracy needs;
+    differences between configurations computed with the same `seed` are far more accurate than σ
+    suggests, because the same vectors are used and most of the noise cancels.
+    """
+    if temperature <= 0:
+        raise ValueError("Expected positive temperature (T = 0 goes through free_energy)")
+    if not system.has_symmetric_spectrum(1e-12):
+        raise RuntimeError("The Chebyshev free energy needs a particle-hole symmetric Hamiltonian")
+    scale = _scale_of(system) if scale is None else float(scale)
+    if moments is None:
+        moments = cheb.moments_for_free_energy(scale, temperature)
+    moments += moments & 1
+    kind = {"rademacher": VEC_RADEMACHER, "z4": VEC_Z4}[vector_kind]
+    d, e = system._solver().dots_random(scale, moments // 2, int(vectors), seed=seed, kind=kind)
+    mu = cheb.dots_to_moments(d, e)  # (M, R)
+    coeff = cheb.chebyshev_coefficients(lambda x: cheb._f_density(scale * x, temperature), moments)
+    per_vector = coeff @ mu
+    sigma = float(np.std(per_vector, ddof=1) / np.sqrt(len(per_vector))) if len(per_vector) > 1 else float("nan")
+    return float(np.mean(per_vector)), sigma
+
+
 def _slab_solver(system, comm):
     """This rank's slab of `system` on its GPU (rebuilt after every `with` block)."""
     from . import slab

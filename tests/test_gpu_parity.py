@@ -380,6 +380,22 @@ def test_free_energy_stochastic_matches_oracle_on_same_vectors(api):
         assert np.isclose(value, ref, rtol=1e-10, atol=0)
 
 
+def test_stochastic_free_energy_reports_a_meaningful_error(api, golden):
+    """F from 64 random vectors with its standard error: the exact value lies within a few σ, the
+    mean equals what `free_energy(trace="stochastic")` returns for the same seed, and more
+    vectors shrink σ like 1/√R."""
+    from bodge_amd.observables import free_energy_stochastic
+
+    system = _build(api, "swave20_zeeman")
+    exact = golden.free_energy("swave20_zeeman", 0.5)
+    value, sigma = free_energy_stochastic(system, 0.5, vectors=64, seed=3)
+    assert sigma > 0 and abs(value - exact) < 5 * sigma and sigma < 5e-3 * abs(exact)
+    same = system.free_energy(0.5, method="chebyshev", trace="stochastic", vectors=64, seed=3)
+    assert np.isclose(value, same, rtol=1e-12)
+    _, sigma_few = free_energy_stochastic(system, 0.5, vectors=16, seed=3)
+    assert 1.2 < sigma_few / sigma < 3.5  # ~2 = sqrt(64/16), up to the noise of the noise
+
+
 def test_free_energy_like_reference_test(api):
     """ref tests/test_hamiltonian.py:428-464: F against the closed form over ±ε, T = 0, T < 0."""
     system = _build(api, "snf")
