@@ -47,6 +47,18 @@ __device__ inline void store_stream(double2* p, double2 v) {
     __builtin_nontemporal_store(w, reinterpret_cast<v2d*>(p));
 }
 
+// Wave-private LDS slot of (lane, component) in the dictionary kernel.  Component-major: the 64
+// lanes of one 16-byte access touch consecutive slots (no bank conflicts); lane-major (stride of
+// four slots) costs 4-way conflicts (SQ_LDS_BANK_CONFLICT 1.75e7 vs 3.7e6 cycles per launch).
+#ifndef BDG_SHARE_LANE_MAJOR
+#define BDG_SHARE_LANE_MAJOR 0
+#endif
+#if BDG_SHARE_LANE_MAJOR
+#define SHARE_SLOT(l, c) ((l) * 4 + (c))
+#else
+#define SHARE_SLOT(l, c) ((c) * kWave + (l))
+#endif
+
 // Flat slot of (component alpha, block row `site`, lane payload r) in a vector buffer
 // with rv payloads per (site, component).  Planar: one plane per component.
 #ifndef BDG_LAYOUT_INTERLEAVED
@@ -759,7 +771,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
             for (int be = 0; be < 4; ++be)
                 own[be] = valid ? a.cur[vslot(be, (size_t)i, r, a.ncols, RL)] : make_double2(0.0, 0.0);
 #pragma unroll
-            for (int be = 0; be < 4; ++be) share[lane * 4 + be] = own[be];
+            for (int be = 0; be < 4; ++be) share[SHARE_SLOT(lane, be)] = own[be];
         }
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
@@ -790,7 +802,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
                         for (int be = 0; be < 4; ++be) x[be] = xn[be];
                     } else {
 #pragma unroll
-                        for (int be = 0; be < 4; ++be) x[be] = share[(lane + src * RL) * 4 + be];
+                        for (int be = 0; be < 4; ++be) x[be] = share[SHARE_SLOT(lane + src * RL, be)];
                     }
                     if (q + 1 < MAXB && q + 1 < meta.len && source(meta.word[q + 1 < MAXB ? q + 1 : 0]) == kWave) {
 #pragma unroll
@@ -818,7 +830,7 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
                 nx.x = fma(ls.c.x, acc[al].x, -(ls.s.x * p[al].x));
                 nx.y = fma(ls.c.y, acc[al].y, -(ls.s.y * p[al].y));
                 p[al] = nx;
-                Mode::dots(dot, share[lane * 4 + al], nx);
+                Mode::dots(dot, share[SHARE_SLOT(lane, al)], nx);
             }
             if (a.stream_vectors & 2) {
 #pragma unroll
