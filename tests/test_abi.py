@@ -84,3 +84,24 @@ def test_package_does_not_import_the_oracle():
             if name.endswith(".py"):
                 with open(os.path.join(dirpath, name)) as fh:
                     assert not re.search(r"^\s*(from|import)\s+oracle\b", fh.read(), flags=re.M), name
+
+
+def test_c_program_links_against_the_header_and_library(tmp_path, hip_library):
+    """The boundary from C: tests/c/abi_smoke.c is compiled with gcc (C99, -Wall -Werror) against
+    include/bodge_hip.h, linked with the built library and run (no GPU needed for what it calls)."""
+    import shutil
+    import subprocess
+
+    gcc = shutil.which("gcc")
+    if gcc is None:
+        pytest.skip("gcc not available")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    from bodge_amd import build
+
+    lib_dir = os.path.dirname(build.LIBRARY)
+    exe = tmp_path / "abi_smoke"
+    subprocess.run([gcc, "-std=c99", "-Wall", "-Werror", f"-I{root}/include", os.path.join(root, "tests", "c", "abi_smoke.c"),
+                    f"-L{lib_dir}", "-lbodge_hip", f"-Wl,-rpath,{lib_dir}", "-o", str(exe)], check=True)
+    out = subprocess.run([str(exe)], capture_output=True, text=True, timeout=120)
+    assert out.returncode == 0, out.stdout + out.stderr
+    assert "bodge_hip" in out.stdout and "indptr" in out.stdout
