@@ -17,6 +17,9 @@ from __future__ import annotations
 import numpy as np
 
 
+MAX_MOMENTS = 1 << 17  # default cap of the expansion order (low temperatures)
+
+
 def spectral_bound(indptr: np.ndarray, data: np.ndarray, pad: float = 1.01) -> float:
     """max over scalar rows of Σ|H_rc|, times `pad` (> 1 keeps the spectrum strictly inside)."""
     n_sites = len(indptr) - 1
@@ -95,7 +98,14 @@ def moments_for_free_energy(scale: float, temperature: float, digits: float = 11
         return 4096
     rate = np.log1p(np.pi * temperature / scale)
     m = int(np.ceil(digits * np.log(10.0) / rate))
-    m = int(np.clip(m, 32, 1 << 17))
+    if m > MAX_MOMENTS:
+        import warnings
+
+        warnings.warn(
+            f"T/scale = {temperature / scale:.1e} asks for {m} Chebyshev moments; capped at {MAX_MOMENTS}, "
+            f"expect a truncation error of about 1e-{digits * MAX_MOMENTS / m:.0f} instead of 1e-{digits:.0f} "
+            "(pass moments=... to override)", RuntimeWarning, stacklevel=3)
+    m = int(np.clip(m, 32, MAX_MOMENTS))
     return m + (m & 1)
 
 

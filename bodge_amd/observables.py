@@ -111,7 +111,7 @@ def _auto_method(system, temperature: float, moments, scale) -> str:
         if dim <= DENSE_AUTO_LIMIT or moments is not None:
             return "dense"
         gap = _gap_estimate(system)
-        gapped = gap > 0 and cheb.moments_for_free_energy(a, gap / GAP_SURROGATE_RATIO) < (1 << 17)
+        gapped = gap > 0 and np.pi * (gap / GAP_SURROGATE_RATIO) / a > 11 * np.log(10.0) / cheb.MAX_MOMENTS
         return "chebyshev" if gapped else "dense"
     m = cheb.moments_for_free_energy(a, temperature) if moments is None else int(moments)
     batches = -(-(dim // 2) // 64) if dim <= EXACT_TRACE_LIMIT else 1  # electron rows only
