@@ -21,7 +21,9 @@ single-core scipy.sparse restatement beside it.
 
 For N > 1 the driver starts one process per GPU with torch.distributed.run;
 only its environment variables are used (RANK, LOCAL_RANK, WORLD_SIZE,
-MASTER_PORT) - the collective is RCCL through the C ABI, not torch.
+MASTER_PORT) - the collective is RCCL through the C ABI, not torch.  Only if the RCCL
+communicator cannot be created do the ranks fall back to torch.distributed (gloo) for the three
+scalar reductions of this script; config.collective says which one ran.
 """
 
 from __future__ import annotations
