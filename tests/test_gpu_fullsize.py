@@ -188,3 +188,38 @@ def test_config4_100cubed_dwave_slabs_match_the_whole_matrix(api, hip_library):
     assert np.allclose(split[0], mono[0], rtol=0, atol=1e-12 * n) and np.allclose(split[1], mono[1], rtol=0, atol=1e-12 * n)
     ref = cheb_ref.recurrence_dots(bsr, scale, 4, cheb_ref.random_block(n, 4, range(vectors)))
     assert np.allclose(mono[0][:2], ref[0], rtol=0, atol=1e-12 * n) and np.allclose(mono[1][:2], ref[1], rtol=0, atol=1e-12 * n)
+
+
+def test_complex_hamiltonian_at_full_size(api, hip_library):
+    """A genuinely complex matrix at 10^6 sites (Peierls phase on the x bonds: uniform flux-free
+    gauge field, H_ij = -e^{±iφ} σ0): the complex dictionary kernel against the CPU oracle on the
+    first steps, its streamed form against it bit-compatibly to round-off, and norm conservation
+    of the start vectors."""
+    from bodge_amd import chebyshev
+    from bodge_amd.solver import DeviceSolver
+
+    lattice = api.CubicLattice((1000, 1000, 1))
+    system = api.Hamiltonian(lattice)
+    pairs = lattice.bond_array(axis=0, coords=True)          # directed x bonds, both directions
+    forward = pairs[:, 1, 0] > pairs[:, 0, 0]
+    phase = np.where(forward, np.exp(0.3j), np.exp(-0.3j))
+    with system as (H, Δ):
+        H.set_sites(3.0 * api.σ0 - 0.05 * api.σ3)
+        Δ.set_sites(-0.1 * api.jσ2)
+        H.set_bonds(-phase[:, None, None] * api.σ0, axis=0)
+        H.set_bonds(-1.0 * api.σ0, axis=1)
+    indptr, indices, data = system.bsr_arrays()
+    assert np.abs(data.imag).max() > 0.2 and indices.size == 4_996_000
+    scale = chebyshev.spectral_bound(indptr, data)
+    bsr = system.matrix("bsr")
+    n, steps, vectors = bsr.shape[0], 3, 2
+    ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 7, range(vectors), cheb_ref.VEC_Z4))
+    with DeviceSolver(indptr, indices, data) as solver:
+        solver.set_lattice_shape(lattice.shape)
+        got, perf = _with_env(solver, {}, scale, steps, vectors, seed=7, kind=cheb_ref.VEC_Z4)
+        assert perf["real_arithmetic"] == 0 and perf["dict_blocks"] > 0
+        streamed, perf_s = _with_env(solver, {"BODGE_AMD_DICT": "0"}, scale, steps, vectors, seed=7, kind=cheb_ref.VEC_Z4)
+        assert perf_s["dict_blocks"] == 0
+    for out in (got, streamed):
+        assert np.allclose(out[0], ref[0], rtol=0, atol=1e-12 * n) and np.allclose(out[1], ref[1], rtol=0, atol=1e-12 * n)
+    assert np.allclose(got[0][0], n, rtol=1e-15)  # |v|^2 = 4N exactly for Z4 vectors
