@@ -535,11 +535,32 @@ struct SolverApi {
     decltype(&rocsolver_dsyevj) dsyevj = nullptr;
 };
 
+// Sequential read of a shared object before dlopen.  librocsolver.so is 931 MB; on a machine whose
+// page cache does not hold it yet, dlopen + first use fault it in 4 KB at a time in link order
+// (measured 1.5-7.5 minutes on fresh boxes, profiles/r01_eigh_probe.log), while a streaming read
+// with read-ahead brings the same bytes in at disk speed.  Pure I/O: no symbol is used from it.
+void warm_page_cache(const char* path) {
+    FILE* fh = fopen(path, "rb");
+    if (!fh) return;
+    std::vector<char> chunk((size_t)8 << 20);
+    while (fread(chunk.data(), 1, chunk.size(), fh) == chunk.size()) {
+    }
+    fclose(fh);
+}
+
 int load_solver(SolverApi** out) {
     static SolverApi api;
     static bool tried = false, ok = false;
     if (!tried) {
         tried = true;
+        if (!getenv("BODGE_AMD_NO_PREFETCH")) {
+            const auto t0 = std::chrono::steady_clock::now();
+            warm_page_cache("/opt/rocm/lib/librocblas.so");
+            warm_page_cache("/opt/rocm/lib/librocsolver.so");
+            if (getenv("BODGE_AMD_TRACE"))
+                fprintf(stderr, "[bdg] rocBLAS/rocSOLVER files read in %.1f s\n",
+                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
+        }
         api.blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
         if (!api.blas) api.blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
         api.solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
@@ -1890,7 +1911,8 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     if (const char* env = getenv("BODGE_AMD_EIGH_REAL")) real_route = real_route && atoi(env) != 0;
 
     // One attempt with the named rocSOLVER driver: "evd" divide & conquer, "evj" Jacobi, "ev" QL/QR.
-    auto attempt = [&](const std::string& algo) -> int {
+    // `copy_bad`: copy the results out even if they contain non-finite values
+    auto attempt = [&](const std::string& algo, bool copy_bad, bool* nonfinite) -> int {
         rocblas_status st;
         if (real_route) {
             HIP_TRY(hipMemsetAsync(dense_real.ptr, 0, sizeof(double) * n * n, sys->stream));
@@ -1928,8 +1950,22 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
         }
         if (st != rocblas_status_success)
             return fail(BDG_ELIBRARY, "rocsolver eigensolver (%s) returned %d", algo.c_str(), (int)st);
-        int host_info = 0;
-        HIP_TRY(hipMemcpyAsync(&host_info, info.ptr, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
+        // convergence flag and a finite-ness scan of the results, both on the device: nothing is
+        // copied to the host before the result is known to be usable
+        const double* vec_ptr = real_route ? dense_real.ptr : reinterpret_cast<const double*>(dense.ptr);
+        const int64_t vec_doubles = z_out ? (real_route ? n * n : 2 * n * n) : 0;
+        HIP_TRY(hipMemsetAsync(info.ptr + 1, 0, sizeof(int), sys->stream));
+        bdg::count_nonfinite<<<64, 256, 0, sys->stream>>>(eig.ptr, n, info.ptr + 1);
+        if (vec_doubles > 0)
+            bdg::count_nonfinite<<<4096, 256, 0, sys->stream>>>(vec_ptr, vec_doubles, info.ptr + 1);
+        HIP_TRY(hipGetLastError());
+        int host_info[2] = {0, 0};
+        HIP_TRY(hipMemcpyAsync(host_info, info.ptr, 2 * sizeof(int), hipMemcpyDeviceToHost, sys->stream));
+        HIP_TRY(hipStreamSynchronize(sys->stream));
+        if (host_info[0] != 0)
+            return fail(BDG_ELIBRARY, "eigensolver (%s) did not converge (info=%d)", algo.c_str(), host_info[0]);
+        *nonfinite = host_info[1] != 0;
+        if (*nonfinite && !copy_bad) return BDG_OK;
         HIP_TRY(hipMemcpyAsync(w_out, eig.ptr, sizeof(double) * n, hipMemcpyDeviceToHost, sys->stream));
         if (z_out) {
             if (real_route) {
@@ -1949,17 +1985,7 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
             }
         }
         HIP_TRY(hipStreamSynchronize(sys->stream));
-        if (host_info != 0)
-            return fail(BDG_ELIBRARY, "eigensolver (%s) did not converge (info=%d)", algo.c_str(), host_info);
         return BDG_OK;
-    };
-    auto all_finite = [&]() {
-        for (int64_t i = 0; i < n; ++i)
-            if (!std::isfinite(w_out[i])) return false;
-        if (z_out)
-            for (int64_t i = 0; i < 2 * n * n; ++i)
-                if (!std::isfinite(z_out[i])) return false;
-        return true;
     };
     auto body = [&]() -> int {
         if (real_route) {
@@ -1969,20 +1995,24 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
         }
         if (int rc = eig.reserve((size_t)std::max<int64_t>(n, 2))) return rc;
         if (int rc = offdiag.reserve((size_t)std::max<int64_t>(n, 2))) return rc;
-        if (int rc = info.reserve(1)) return rc;
+        if (int rc = info.reserve(2)) return rc;
         if (api->create_handle(&handle) != rocblas_status_success)
             return fail(BDG_ELIBRARY, "rocblas_create_handle failed");
         if (api->set_stream(handle, sys->stream) != rocblas_status_success)
             return fail(BDG_ELIBRARY, "rocblas_set_stream failed");
         const char* forced = getenv("BODGE_AMD_EIGH");
-        if (forced && *forced && std::string(forced) != "rocsolver") return attempt(forced);
-        // zheevd is the fast driver, but on ROCm 7.2 / gfx950 its eigenvectors come back
-        // NaN for spectra with exact degeneracies (measured: profiles/r01_eigh_probe.log);
-        // eigenvalues are unaffected.  Verify, and redo with the Jacobi driver if needed.
-        if (int rc = attempt("evd")) return rc;
-        if (all_finite()) return BDG_OK;
-        if (int rc = attempt("evj")) return rc;
-        if (!all_finite()) return fail(BDG_ELIBRARY, "eigensolver returned non-finite values");
+        bool nonfinite = false;
+        // a forced driver returns whatever it produced (tests look at the defect itself)
+        if (forced && *forced && std::string(forced) != "rocsolver") return attempt(forced, true, &nonfinite);
+        // Divide & conquer is the fast driver.  On ROCm 7.2 / gfx950 zheevd was seen to return NaN
+        // eigenvectors when it is handed a matrix with imag(H) = 0 and a degenerate spectrum
+        // (profiles/r01_eigh_probe.log; eigenvalues unaffected) - a case the real route above never
+        // sends it.  The device-side scan catches any such result before it is copied; only then is
+        // the Jacobi driver run, as a safety net and at its own O(n^3) cost.
+        if (int rc = attempt("evd", false, &nonfinite)) return rc;
+        if (!nonfinite) return BDG_OK;
+        if (int rc = attempt("evj", false, &nonfinite)) return rc;
+        if (nonfinite) return fail(BDG_ELIBRARY, "eigensolver returned non-finite values");
         return BDG_OK;
     };
     int rc = body();

@@ -1204,6 +1204,18 @@ __global__ __launch_bounds__(256) void jacobi_eigenvalues(const T* __restrict__ 
     if (threadIdx.x == 0) eig[blockIdx.x] = sqrt(red[0]) - shift;
 }
 
+// count of non-finite doubles in x[0..n) (eigensolver results are checked on the device, before
+// any copy to the host): one atomicAdd per workgroup that saw one
+__global__ void count_nonfinite(const double* __restrict__ x, int64_t n, int* __restrict__ count) {
+    int bad = 0;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < n;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const double v = x[idx];
+        bad |= !(fabs(v) <= 1.79769313486231570815e308);
+    }
+    if (__syncthreads_or(bad) && threadIdx.x == 0) atomicAdd(count, 1);
+}
+
 // planar [4][nb][rv] column r  <->  site-major [nb][4]
 __global__ void planar_from_sitemajor(const double2* __restrict__ x, double2* __restrict__ planar,
                                       int64_t nb, int rv, int r) {

@@ -158,6 +158,35 @@ def field_chain(ns, theta=0.7, phi=2.1, L=128):
     return system
 
 
+def peierls_square(ns, L=30, phase=0.3):
+    """Genuinely complex matrix for the Hermitian (zheevd) dense route: the README model with a
+    Peierls phase e^{±iφ} on the x bonds (BASELINE config 5 ladder rung n = 3600)."""
+    lattice = ns.CubicLattice((L, L, 1))
+    system = ns.Hamiltonian(lattice)
+    with system as (H, Δ):
+        for i in lattice.sites():
+            H[i, i] = 3.0 * ns.σ0 - 0.05 * ns.σ3
+            Δ[i, i] = -0.1 * ns.jσ2
+        for i, j in lattice.bonds():
+            step = j[0] - i[0]
+            H[i, j] = -np.exp(1j * phase * step) * ns.σ0
+    return system
+
+
+def swave_chain(ns, L=300, zeeman=0.05, gap=0.1, mu=1.0):
+    """(L,1,1) s-wave chain with Zeeman splitting: the literal "300" of BASELINE config 5 at a
+    size the dense path can hold."""
+    lattice = ns.CubicLattice((L, 1, 1))
+    system = ns.Hamiltonian(lattice)
+    with system as (H, Δ):
+        for i in lattice.sites():
+            H[i, i] = mu * ns.σ0 - zeeman * ns.σ3
+            Δ[i, i] = -gap * ns.jσ2
+        for i, j in lattice.bonds():
+            H[i, j] = -1.0 * ns.σ0
+    return system
+
+
 # name -> (builder, kwargs, what to record)
 CATALOG = {
     "swave20": dict(build=swave_square, kwargs={}, temps=[0.0, 0.01, 0.1, 0.5, 1.0], spectrum=True),
@@ -192,6 +221,10 @@ CATALOG = {
         spectrum=False,
         ldos=[((15, 15, 0), [0.0, 0.025]), ((0, 15, 0), [0.0, 0.025])],
     ),
+    # dense-route ladder of BASELINE config 5: n = 3600 real, n = 3600 complex, n = 1200
+    "swave30_zeeman": dict(build=swave_square, kwargs=dict(L=30, zeeman=0.05), temps=[0.0, 0.1, 0.5], spectrum=True),
+    "peierls30": dict(build=peierls_square, kwargs={}, temps=[0.0, 0.1, 0.5], spectrum=True),
+    "chain300": dict(build=swave_chain, kwargs={}, temps=[0.0, 0.1, 0.5], spectrum=True),
     "chain128": dict(
         build=field_chain,
         kwargs={},

@@ -88,6 +88,39 @@ def test_size_independent_properties(big):
         assert np.allclose(ex, e, rtol=1e-12, atol=1e-6), env
 
 
+def test_config3_1000x1000_512_moments_full_length_against_cpu_on_the_same_vectors(big):
+    """configs[2] at full size AND full length (north_star: "free_energy matching SciPy to 1e-10"):
+    (1000,1000,1) s-wave+Zeeman, M = 512 (256 launches), the 8 vectors of rank 0 (seed 0, ids 0..7).
+    The C/OpenMP restatement runs the same vectors; it is pinned here to the numpy/scipy.sparse
+    restatement on 2 vectors x 8 steps.  Every d_n, e_n within 1e-12 * 4N, F within 1e-10 relative
+    (F defined by ref hamiltonian.py:305-321, evaluated as the trace of f(H))."""
+    from bodge_amd import chebyshev
+    from oracle import cheb_c
+
+    system, solver, scale = big
+    bsr = system.matrix("bsr")
+    n, moments, vectors, temperature = bsr.shape[0], 512, 8, 0.5
+    start = cheb_ref.random_block(n, 0, range(vectors))
+    d2, e2 = cheb_ref.recurrence_dots(bsr, scale, 16, start[:, :2])
+    cheb_c.set_threads(min(16, os.cpu_count() or 1))
+    d_ref, e_ref = cheb_c.recurrence_dots(bsr, scale, moments, start, real=True)
+    assert np.allclose(d_ref[:8, :2], d2, rtol=0, atol=1e-12 * n) and np.allclose(e_ref[:8, :2], e2, rtol=0, atol=1e-12 * n)
+    (d, e), perf = _with_env(solver, {}, scale, moments // 2, vectors, seed=0)
+    assert perf["launches"] == moments // 2
+    assert np.abs(d - d_ref).max() <= 1e-12 * n and np.abs(e - e_ref).max() <= 1e-12 * n
+    f_ref = chebyshev.free_energy_series(chebyshev.dots_to_moments(d_ref, e_ref).mean(axis=1), scale, temperature)
+    f_gpu = chebyshev.free_energy_series(solver.moments_random(scale, moments, vectors, seed=0) / vectors, scale, temperature)
+    assert abs(f_gpu - f_ref) <= 1e-10 * abs(f_ref)
+    # the same call through the reference-shaped API (own device mirror of the same matrix)
+    f_api = system.free_energy(temperature, method="chebyshev", moments=moments, vectors=vectors, seed=0,
+                               trace="stochastic", scale=scale)
+    assert abs(f_api - f_ref) <= 1e-10 * abs(f_ref)
+    # streamed (non-dictionary) complex128 kernels, the reference's own dtype: same vectors, 64 launches
+    (dc, ec), perf_c = _with_env(solver, {"BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"}, scale, 64, vectors, seed=0)
+    assert perf_c["real_arithmetic"] == 0 and perf_c["dict_blocks"] == 0
+    assert np.abs(dc - d_ref[:64]).max() <= 1e-12 * n and np.abs(ec - e_ref[:64]).max() <= 1e-12 * n
+
+
 def test_stochastic_free_energy_is_stable_and_in_range(big, api):
     """512-moment stochastic-trace F of configs[2]: two disjoint sets of vectors must agree to the
     stochastic error, and F/N must sit near the 20x20 reference value per site."""
@@ -188,6 +221,41 @@ def test_config4_100cubed_dwave_slabs_match_the_whole_matrix(api, hip_library):
     assert np.allclose(split[0], mono[0], rtol=0, atol=1e-12 * n) and np.allclose(split[1], mono[1], rtol=0, atol=1e-12 * n)
     ref = cheb_ref.recurrence_dots(bsr, scale, 4, cheb_ref.random_block(n, 4, range(vectors)))
     assert np.allclose(mono[0][:2], ref[0], rtol=0, atol=1e-12 * n) and np.allclose(mono[1][:2], ref[1], rtol=0, atol=1e-12 * n)
+
+
+def test_config4_100cubed_dwave_256_moments_full_length_whole_and_slabs_against_cpu(api, hip_library):
+    """configs[3] at full length: (100,100,100) d-wave, M = 256 (128 launches), 4 vectors (seed 4),
+    the undivided matrix AND the 8-slab group with a halo exchange per step, both against the
+    C/OpenMP restatement on the same vectors (pinned to the numpy/scipy restatement on the first 4
+    steps): every d_n, e_n within 1e-12 * 4N, F within 1e-10 relative."""
+    from bodge_amd import chebyshev
+    from bodge_amd.solver import DeviceSolver, SlabGroup
+    from oracle import cheb_c
+
+    lattice = api.CubicLattice((100, 100, 100))
+    system = api.Hamiltonian(lattice)
+    pairs = lattice.bond_array(coords=True)
+    with system as (H, Δ):
+        H.set_sites(3.0 * api.σ0)
+        H.set_bonds(-1.0 * api.σ0)
+        Δ.set_bonds(-0.1 * api.dwave()(pairs[:, 0], pairs[:, 1]))
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    n, moments, vectors, temperature = bsr.shape[0], 256, 4, 0.5
+    start = cheb_ref.random_block(n, 4, range(vectors))
+    d4, e4 = cheb_ref.recurrence_dots(bsr, scale, 8, start[:, :2])
+    cheb_c.set_threads(min(16, os.cpu_count() or 1))
+    d_ref, e_ref = cheb_c.recurrence_dots(bsr, scale, moments, start, real=True)
+    assert np.allclose(d_ref[:4, :2], d4, rtol=0, atol=1e-12 * n) and np.allclose(e_ref[:4, :2], e4, rtol=0, atol=1e-12 * n)
+    f_ref = chebyshev.free_energy_series(chebyshev.dots_to_moments(d_ref, e_ref).mean(axis=1), scale, temperature)
+    with DeviceSolver.from_hamiltonian(system) as whole:
+        mono = whole.dots_random(scale, moments // 2, vectors, seed=4)
+    with SlabGroup.from_hamiltonian(system, 8) as group:
+        split = group.dots_random(scale, moments // 2, vectors, seed=4)
+    for d, e in (mono, split):
+        assert np.abs(d - d_ref).max() <= 1e-12 * n and np.abs(e - e_ref).max() <= 1e-12 * n
+        f = chebyshev.free_energy_series(chebyshev.dots_to_moments(d, e).mean(axis=1), scale, temperature)
+        assert abs(f - f_ref) <= 1e-10 * abs(f_ref)
 
 
 def test_complex_hamiltonian_at_full_size(api, hip_library):

@@ -1,0 +1,50 @@
+"""Dense route above the own Jacobi kernels' limit (4N > 2048): rocSOLVER dsyevd / zheevd.
+
+Kept in a file of its own that sorts last: the first use of rocSOLVER on a fresh machine has to
+bring a 931 MB shared object in (the library streams the file through the page cache first,
+`warm_page_cache` in bodge_hip.hip), so everything else has already been reported by then.
+"""
+
+import numpy as np
+import pytest
+
+import systems
+
+pytestmark = pytest.mark.gpu
+
+
+def _build(api, name):
+    spec = systems.CATALOG[name]
+    return spec["build"](api, **spec["kwargs"])
+
+
+# BASELINE config 5's feasible ladder: goldens are the reference's own
+# diagonalize() / free_energy() on these systems (tests/golden/make_golden.py)
+@pytest.mark.parametrize("name,driver", [("swave30_zeeman", "dsyevd"), ("peierls30", "zheevd"), ("chain300", "dsyevd")])
+def test_dense_ladder_above_the_jacobi_limit_matches_reference(api, golden, monkeypatch, name, driver):
+    """n = 3600 real (dsyevd, the driver BASELINE config 5 names), n = 3600 complex (zheevd), and the
+    literal "300" chain (n = 1200, sent to rocSOLVER here as well): eigenvalues within 1e-10 of the
+    reference's, eigen-equation residual <= 1e-9, orthonormal finite vectors, reference shapes,
+    and F(T) from the same spectrum within 1e-10 relative."""
+    if name == "chain300":
+        monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")  # 4N = 1200 would use the own Jacobi kernels
+    system = _build(api, name)
+    dim = system.shape[0]
+    data = system._data
+    assert (np.abs(data.imag).max() > 0) == (driver == "zheevd")
+    vals, vecs = system.diagonalize(format="raw")
+    ref = golden.eigenvalues(name)
+    assert vals.shape == ref.shape == (dim // 2,) and vecs.shape == (dim, dim // 2)
+    assert np.all(np.diff(vals) >= 0) and np.abs(vals - ref).max() <= 1e-10
+    assert np.isfinite(vecs).all()
+    bsr = system.matrix("bsr")
+    assert np.abs(bsr @ vecs - vecs * vals).max() <= 1e-9
+    idx = np.arange(0, vals.size, max(1, vals.size // 64))  # a sample of columns against all of them
+    gram = vecs[:, idx].conj().T @ vecs
+    gram[np.arange(idx.size), idx] -= 1.0
+    assert np.abs(gram).max() <= 1e-9
+    _, shaped = system.diagonalize()
+    assert shaped.shape == (dim // 2, dim // 4, 4) and np.array_equal(shaped[3, 7, :], vecs[28:32, 3])
+    for temperature in (0.0, 0.1, 0.5):
+        value = system.free_energy(temperature, method="dense")
+        assert abs(value - golden.free_energy(name, temperature)) <= 1e-10 * abs(value)
