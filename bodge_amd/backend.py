@@ -80,6 +80,8 @@ SIGNATURES = {
     "bdg_lanczos_advance": (C.c_int, [_handle, C.c_int32, _f64p, _f64p]),
     "bdg_random_vector": (C.c_int, [_handle, C.c_uint64, C.c_uint64, C.c_int32, _f64p]),
     "bdg_eigh_dense": (C.c_int, [_handle, _f64p, _f64p]),
+    "bdg_dense_prefetch": (C.c_int, []),
+    "bdg_dense_prefetch_wait": (C.c_int, [C.c_double, C.POINTER(C.c_int32)]),
     "bdg_perf_query": (C.c_int, [_handle, C.POINTER(Perf)]),
     "bdg_set_lattice_shape": (C.c_int, [_handle, C.c_int32, C.c_int32, C.c_int32]),
     "bdg_set_lanes_per_row": (C.c_int, [_handle, C.c_int32]),

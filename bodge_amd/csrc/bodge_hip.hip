@@ -9,19 +9,27 @@
 #include "bodge_hip.h"
 
 #include <dlfcn.h>
+#include <fcntl.h>
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <rocsolver/rocsolver.h>
 
+#include <sys/stat.h>
+#include <unistd.h>
+
 #include <algorithm>
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <string_view>
+#include <thread>
 #include <tuple>
 #include <unordered_map>
 #include <vector>
@@ -535,32 +543,73 @@ struct SolverApi {
     decltype(&rocsolver_dsyevj) dsyevj = nullptr;
 };
 
-// Sequential read of a shared object before dlopen.  librocsolver.so is 931 MB; on a machine whose
-// page cache does not hold it yet, dlopen + first use fault it in 4 KB at a time in link order
-// (measured 1.5-7.5 minutes on fresh boxes, profiles/r01_eigh_probe.log), while a streaming read
-// with read-ahead brings the same bytes in at disk speed.  Pure I/O: no symbol is used from it.
+// Reading a shared object through the page cache before dlopen.  librocsolver.so is 931 MB; on a
+// machine whose page cache does not hold it yet, dlopen + first use fault it in a few KB at a
+// time in link order.  Measured on fresh boxes (profiles/r02_rocsolver_cold.log): 1.5-9 minutes
+// whichever way the bytes are asked for - the lazily provisioned root disk delivers ~2-3 MB/s
+// for data nobody has touched, sequential or not, and parallel readers only slow it down - and
+// well under a second once cached.  So the cost cannot be removed, only moved: `SolverPrefetch`
+// streams the files on a background thread (bdg_dense_prefetch) so that the read overlaps with
+// assembly, upload and whatever else the caller does before the first dense eigensolve above
+// 4N = 2048; load_solver() waits for it.  Pure I/O: no symbol is used from the files.
 void warm_page_cache(const char* path) {
-    FILE* fh = fopen(path, "rb");
-    if (!fh) return;
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return;
+    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
     std::vector<char> chunk((size_t)8 << 20);
-    while (fread(chunk.data(), 1, chunk.size(), fh) == chunk.size()) {
+    while (read(fd, chunk.data(), chunk.size()) > 0) {
     }
-    fclose(fh);
+    close(fd);
 }
+
+struct SolverPrefetch {
+    std::mutex lock;
+    std::condition_variable changed;
+    std::thread thread;
+    bool started = false, done = false, reported = false;
+    double seconds = 0.0;
+    void start() {
+        std::lock_guard<std::mutex> guard(lock);
+        if (started) return;
+        started = true;
+        if (getenv("BODGE_AMD_NO_PREFETCH")) {
+            done = true;
+            return;
+        }
+        thread = std::thread([this] {
+            const auto t0 = std::chrono::steady_clock::now();
+            warm_page_cache("/opt/rocm/lib/librocblas.so");
+            warm_page_cache("/opt/rocm/lib/librocsolver.so");
+            std::lock_guard<std::mutex> inner(lock);
+            seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            done = true;
+            changed.notify_all();
+        });
+    }
+    // true once the files have been read; waits at most `timeout_s` (negative: no limit)
+    bool wait(double timeout_s) {
+        start();
+        std::unique_lock<std::mutex> guard(lock);
+        if (timeout_s < 0) changed.wait(guard, [this] { return done; });
+        else changed.wait_for(guard, std::chrono::duration<double>(timeout_s), [this] { return done; });
+        if (done && !reported && getenv("BODGE_AMD_TRACE")) {
+            reported = true;
+            fprintf(stderr, "[bdg] rocBLAS/rocSOLVER files read in %.1f s\n", seconds);
+        }
+        return done;
+    }
+    ~SolverPrefetch() {
+        if (thread.joinable()) thread.join();
+    }
+};
+SolverPrefetch g_solver_prefetch;
 
 int load_solver(SolverApi** out) {
     static SolverApi api;
     static bool tried = false, ok = false;
     if (!tried) {
         tried = true;
-        if (!getenv("BODGE_AMD_NO_PREFETCH")) {
-            const auto t0 = std::chrono::steady_clock::now();
-            warm_page_cache("/opt/rocm/lib/librocblas.so");
-            warm_page_cache("/opt/rocm/lib/librocsolver.so");
-            if (getenv("BODGE_AMD_TRACE"))
-                fprintf(stderr, "[bdg] rocBLAS/rocSOLVER files read in %.1f s\n",
-                        std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count());
-        }
+        g_solver_prefetch.wait(-1.0);
         api.blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
         if (!api.blas) api.blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
         api.solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
@@ -2023,6 +2072,17 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     offdiag.release();
     info.release();
     return rc;
+}
+
+int bdg_dense_prefetch(void) {
+    g_solver_prefetch.start();
+    return BDG_OK;
+}
+
+int bdg_dense_prefetch_wait(double timeout_seconds, int32_t* ready) {
+    if (!ready) return fail(BDG_EINVAL, "null ready pointer");
+    *ready = g_solver_prefetch.wait(timeout_seconds) ? 1 : 0;
+    return BDG_OK;
 }
 
 int bdg_lanczos_begin(bdg_system* sys, int32_t n_vectors, uint64_t seed, uint64_t first_vec_id,

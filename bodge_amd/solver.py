@@ -22,6 +22,25 @@ def _default_device() -> int:
     return device % backend.device_count()
 
 
+DENSE_LIBRARY_FROM = 2048  # 4N above which dense eigensolves go to rocSOLVER (kJacobiLimit in the library)
+DENSE_LIBRARY_PREFETCH_UPTO = 16384  # = observables.DENSE_AUTO_LIMIT_T0
+
+
+def prefetch_dense_library() -> None:
+    """Start bringing the rocSOLVER / rocBLAS shared objects into the page cache in the background
+    (`bdg_dense_prefetch`; file I/O only).  From cold storage the first dense eigensolve above
+    4N = 2048 otherwise waits minutes for them."""
+    backend.check(backend.load().bdg_dense_prefetch())
+
+
+def dense_library_ready(timeout: float = 0.0) -> bool:
+    """True once the background read started by `prefetch_dense_library` has finished; waits up
+    to `timeout` seconds for it."""
+    ready = C.c_int32(0)
+    backend.check(backend.load().bdg_dense_prefetch_wait(float(timeout), C.byref(ready)))
+    return bool(ready.value)
+
+
 class DeviceSolver:
     def __init__(self, indptr, indices, data, device: int | None = None, n_cols: int | None = None,
                  row_offset: int = 0):
@@ -75,6 +94,8 @@ class DeviceSolver:
 
     @classmethod
     def from_hamiltonian(cls, system, device: int | None = None, drop_zero_blocks: bool = True):
+        if DENSE_LIBRARY_FROM < system.shape[0] <= DENSE_LIBRARY_PREFETCH_UPTO:
+            prefetch_dense_library()  # sizes method="auto" may send to rocSOLVER: overlap its file I/O
         indptr, indices, data = system.bsr_arrays(drop_zero_blocks=drop_zero_blocks)
         solver = cls(indptr, indices, data, device=device)
         from .lattice import CubicLattice

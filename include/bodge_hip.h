@@ -171,6 +171,18 @@ int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t v
  */
 int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out);
 
+/*
+ * Optional: start reading the rocSOLVER / rocBLAS shared objects into the page cache on a
+ * background thread (file I/O only; returns at once, idempotent).  The first dense eigensolve
+ * above 4*nb = 2048 loads a 931 MB library, which takes minutes from cold storage; a caller who
+ * knows it will diagonalize (the reference's diagonalize() / free_energy() call sites,
+ * hamiltonian.py:203-232, :282-302) calls this when the Hamiltonian is created so that the read
+ * overlaps with assembly and upload.  bdg_eigh_dense waits for it.
+ */
+int bdg_dense_prefetch(void);
+/* Wait up to timeout_seconds (negative: until done) for that read; *ready = 1 once it has finished. */
+int bdg_dense_prefetch_wait(double timeout_seconds, int32_t* ready);
+
 int bdg_perf_query(bdg_system* sys, bdg_perf* out);
 
 /*

@@ -13,6 +13,10 @@ for path in (ROOT, os.path.join(ROOT, "tests")):
         sys.path.insert(0, path)
 
 
+# wall-clock start of this test session (the dense-ladder tests budget their wait against it)
+os.environ["BODGE_AMD_TEST_SESSION_START"] = repr(__import__("time").time())
+
+
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with `-m gpu` on the GPU box)")
 
@@ -55,3 +59,19 @@ def hip_library():
 
     build.build_library()
     return backend.load()
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _dense_library_prefetch(request):
+    """On a GPU box, start reading the 931 MB rocSOLVER object at session start (background file
+    I/O in the library, `bdg_dense_prefetch`): the dense-ladder tests sort last, so on a fresh
+    machine the cold read overlaps with the rest of the suite instead of adding to it."""
+    if "not gpu" in (request.config.getoption("-m") or ""):
+        return
+    try:
+        from bodge_amd import backend, solver
+
+        if backend.device_count() > 0:
+            solver.prefetch_dense_library()
+    except Exception:  # library not built yet: the tests that need it say so themselves
+        pass

@@ -13,6 +13,27 @@ import systems
 pytestmark = pytest.mark.gpu
 
 
+# The driver gives the whole `-m gpu` run 900 s.  From cold storage the rocSOLVER object takes
+# 6-9 minutes to arrive (read in the background since session start, tests/conftest.py); if it
+# still has not by this point of the session, skipping these tests - loudly - is better than
+# having the limit kill the run with every other result in it.
+SESSION_BUDGET_S = 780.0
+
+
+@pytest.fixture(scope="module")
+def dense_library():
+    import os
+    import time
+
+    from bodge_amd import solver
+
+    start = float(os.environ.get("BODGE_AMD_TEST_SESSION_START", time.time()))
+    solver.prefetch_dense_library()
+    if not solver.dense_library_ready(max(0.0, SESSION_BUDGET_S - (time.time() - start))):
+        pytest.skip(f"rocSOLVER shared object (931 MB) not read from cold storage after "
+                    f"{time.time() - start:.0f} s of this session")
+
+
 def _build(api, name):
     spec = systems.CATALOG[name]
     return spec["build"](api, **spec["kwargs"])
@@ -21,7 +42,7 @@ def _build(api, name):
 # BASELINE config 5's feasible ladder: goldens are the reference's own
 # diagonalize() / free_energy() on these systems (tests/golden/make_golden.py)
 @pytest.mark.parametrize("name,driver", [("swave30_zeeman", "dsyevd"), ("peierls30", "zheevd"), ("chain300", "dsyevd")])
-def test_dense_ladder_above_the_jacobi_limit_matches_reference(api, golden, monkeypatch, name, driver):
+def test_dense_ladder_above_the_jacobi_limit_matches_reference(api, golden, monkeypatch, dense_library, name, driver):
     """n = 3600 real (dsyevd, the driver BASELINE config 5 names), n = 3600 complex (zheevd), and the
     literal "300" chain (n = 1200, sent to rocSOLVER here as well): eigenvalues within 1e-10 of the
     reference's, eigen-equation residual <= 1e-9, orthonormal finite vectors, reference shapes,
