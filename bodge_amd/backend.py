@@ -42,7 +42,7 @@ class Perf(C.Structure):
         ("strip_rows", C.c_int32),
         ("ph_packed", C.c_int32),
         ("dict_blocks", C.c_int32),
-        ("reserved", C.c_int32),
+        ("steps_per_launch", C.c_int32),
     ]
 
 

@@ -35,6 +35,7 @@
 #include <vector>
 
 #include "kernels.hpp"
+#include "sweep.hpp"
 
 namespace {
 
@@ -135,6 +136,10 @@ struct bdg_system {
     DeviceBuffer<double2> dict_full;      // n_unique x 16 complex entries
     DeviceBuffer<double2> dict_table[4];  // packed per storage mode, built on first use
     DeviceBuffer<double2> vec_a, vec_b;
+    DeviceBuffer<double2> vec_c, vec_d;  // two-steps-per-sweep form: t_{n+1}, t_{n+2} are written out of place
+    // lattice-stencil form of the matrix (sweep.hpp): 0 = not examined, 1 = table built, -1 = not a stencil
+    DeviceBuffer<uint2> stencil;
+    int stencil_state = 0;
     DeviceBuffer<double> partial, dots;
     double* host_dots = nullptr;  // pinned staging for the dot products (sized like `dots`)
     size_t host_dots_count = 0;
@@ -509,6 +514,116 @@ int prepare_tile_order(bdg_system* sys, int rows_per_tile, int n_tiles, double r
     return BDG_OK;
 }
 
+// ------------------------------------------------------- two steps per sweep (sweep.hpp)
+using SweepKernel = void (*)(bdg::SweepArgs);
+
+SweepKernel sweep_kernel(const ModeInfo& mode) {
+    switch (mode.id) {
+        case 1: return bdg::cheb_sweep<RealMode>;
+        case 2: return bdg::cheb_sweep<ComplexPHMode>;
+        case 3: return bdg::cheb_sweep<RealPHMode>;
+    }
+    return bdg::cheb_sweep<ComplexMode>;
+}
+
+struct SweepPlan {
+    SweepKernel kernel = nullptr;
+    int grid = 0;
+    size_t lds_bytes = 0;
+    bdg::SweepArgs args{};
+};
+
+// Smallest lattice the sweep form is chosen for by default: below this the x-segments get so short
+// that the two extra planes each wave recomputes at either end eat the saving, and the vectors
+// are Infinity-Cache resident anyway.  BODGE_AMD_SWEEP=0 never, =1 whenever the matrix qualifies.
+constexpr int64_t kSweepMinSites = 600000;
+
+// Stencil table of the matrix (built once per lattice shape); *ok = it is a 5-point lattice stencil.
+int ensure_stencil(bdg_system* sys, bool* ok) {
+    *ok = false;
+    const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
+    if (sys->stencil_state == 0) {
+        sys->stencil_state = -1;
+        const bool shaped = plane >= 2 * bdg::kSweepOwned && sys->shape[0] >= 8 &&
+                            (int64_t)sys->shape[0] * plane == sys->nb;
+        if (shaped && sys->ncols == sys->nb && sys->n_unique > 0 && sys->n_unique < (int)bdg::kNoBlock &&
+            sys->max_row_blocks <= 5 && sys->nnzb > 0) {
+            if (int rc = sys->stencil.reserve((size_t)sys->nb)) return rc;
+            DeviceBuffer<int> bad;
+            if (int rc = bad.reserve(1)) return rc;
+            int host_bad = 1;
+            auto body = [&]() -> int {
+                HIP_TRY(hipMemsetAsync(bad.ptr, 0, sizeof(int), sys->stream));
+                bdg::build_stencil<<<(unsigned)std::min<int64_t>(4096, (sys->nb + 255) / 256), 256, 0, sys->stream>>>(
+                    sys->indptr.ptr, sys->dict_ids.ptr, (int)sys->nb, (int)plane, sys->stencil.ptr, bad.ptr);
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipMemcpyAsync(&host_bad, bad.ptr, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
+                HIP_TRY(hipStreamSynchronize(sys->stream));
+                return BDG_OK;
+            };
+            const int rc = body();
+            bad.release();
+            if (rc) return rc;
+            if (host_bad == 0) sys->stencil_state = 1;
+            else sys->stencil.release();
+        }
+    }
+    *ok = sys->stencil_state == 1;
+    return BDG_OK;
+}
+
+// Should this batch run the sweep form?  (whole square matrix, random start vectors - unit
+// vectors use the band-limited one-step sweeps -, no per-column scalars, one lane group)
+int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, bool* wanted) {
+    *wanted = false;
+    const char* env = getenv("BODGE_AMD_SWEEP");
+    if ((env && env[0] == '0') || !random_start || col_scalars || !sys->peers.empty()) return BDG_OK;
+    if (!(env && env[0] == '1') && sys->nb < kSweepMinSites) return BDG_OK;
+    const char* dict_env = getenv("BODGE_AMD_DICT");
+    if (dict_env && dict_env[0] == '0') return BDG_OK;
+    return ensure_stencil(sys, wanted);
+}
+
+int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, SweepPlan* plan) {
+    plan->kernel = sweep_kernel(mode);
+    const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
+    if (table > kDictLdsLimit) return fail(BDG_EINVAL, "block table too large for the sweep kernel");
+    const size_t rows = (size_t)bdg::kWavesPerBlock * 2 * bdg::kWave * 4 * sizeof(double2);
+    plan->lds_bytes = table + rows;
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(plan->kernel),
+                                                         bdg::kBlockThreads, plan->lds_bytes));
+    per_cu = std::max(1, std::min(per_cu, 2));
+    if (const char* cap = getenv("BODGE_AMD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(cap));
+    const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
+    bdg::SweepArgs& a = plan->args;
+    a = bdg::SweepArgs{};
+    a.stencil = sys->stencil.ptr;
+    if (int rc = ensure_dict_table(sys, mode, &a.dict_table)) return rc;
+    a.n_unique = sys->n_unique;
+    a.nb = (int)sys->nb;
+    a.plane = (int)plane;
+    a.lx = sys->shape[0];
+    a.n_cols = (int)((plane + bdg::kSweepOwned - 1) / bdg::kSweepOwned);
+    // one unit (segment x window) per resident wave, segments of at least 8 planes
+    const int waves = per_cu * sys->num_cus * bdg::kWavesPerBlock;
+    int n_segs = (waves + a.n_cols / 2) / a.n_cols;
+    if (const char* env = getenv("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
+    a.n_segs = std::max(1, std::min(n_segs, a.lx / 8));
+    const int64_t units = (int64_t)a.n_cols * a.n_segs;
+    const int grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus, (units + bdg::kWavesPerBlock - 1) / bdg::kWavesPerBlock);
+    plan->grid = std::max(8, (grid + 7) / 8 * 8);
+    return BDG_OK;
+}
+
+// Algorithmic HBM bytes of one two-step sweep: one 8-byte stencil word per site, the block table
+// once, and four passes over 4 x RL 16-byte payloads per site (read t_n, t_{n-1}; write t_{n+1},
+// t_{n+2}).  The halo slots and segment-end planes the waves recompute are NOT counted.
+double sweep_bytes(const bdg_system* sys, const ModeInfo& mode) {
+    return 8.0 * (double)sys->nb + (mode.block_bytes - 4.0) * sys->n_unique +
+           4.0 * (4.0 * bdg::kSweepLanes * sizeof(double2)) * (double)sys->nb;
+}
+
 enum class StartKind { Random, Unit };
 
 struct StartSpec {
@@ -726,6 +841,12 @@ struct Batch {
     double2* prev = nullptr;
     float kernel_ms = 0.f;
     int n_chunks = 0;
+    // two-steps-per-sweep form
+    bool sweep = false;
+    SweepPlan splan;
+    double2 *spare1 = nullptr, *spare2 = nullptr;
+    int launch_grid = 0;   // workgroups whose dot partials one recurrence step leaves behind
+    int n_launches = 0;
 
     int begin(bdg_system* system, double scale_in, int steps, int active, const StartSpec& start,
               int force_real /* -1 auto, 0 complex, 1 real */, bool col_scalars = false) {
@@ -752,6 +873,14 @@ struct Batch {
         rv = rl * per_lane;  // vector columns in the buffers
         if (int rc = make_plan(sys, rl, mode, &plan, col_scalars)) return rc;
         if (int rc = matrix_args(sys, plan, &args)) return rc;
+        sweep = false;
+        if (rl == bdg::kSweepLanes && plan.dictionary && sys->lanes_override == 0) {
+            if (int rc = sweep_wanted(sys, start.kind == StartKind::Random, col_scalars, &sweep)) return rc;
+            if (sweep)
+                if (int rc = make_sweep_plan(sys, mode, &splan)) return rc;
+        }
+        launch_grid = sweep ? splan.grid : plan.grid;
+        n_launches = 0;
 
         vec_count = (size_t)4 * sys->ncols * rl;  // 16-byte lane payloads
         // t_n and t_{n-1} together beyond the 256 MB Infinity Cache: the write of t_{n+1} and the
@@ -764,11 +893,19 @@ struct Batch {
         if (const char* env = std::getenv("BODGE_AMD_ALTERNATE")) alternate = std::atoi(env) != 0;
         if (int rc = sys->vec_a.reserve(vec_count)) return rc;
         if (int rc = sys->vec_b.reserve(vec_count)) return rc;
+        if (sweep) {
+            if (int rc = sys->vec_c.reserve(vec_count)) return rc;
+            if (int rc = sys->vec_d.reserve(vec_count)) return rc;
+            spare1 = sys->vec_c.ptr;
+            spare2 = sys->vec_d.ptr;
+            splan.args.stream = 2 * vec_count * sizeof(double2) > kStreamVectorBytes ? 1 : 0;
+            if (const char* env = std::getenv("BODGE_AMD_SWEEP_STREAM")) splan.args.stream = std::atoi(env);
+        }
         width = (size_t)2 * rv;
         if (int rc = prepare_overlap()) return rc;
         // Dot partials are reduced every `chunk` launches.  Buffer sizes do not depend on
         // n_steps (up to 1024), so a short warm-up call leaves nothing to allocate later.
-        per_step = (size_t)(overlapped ? grid_interior + grid_boundary : plan.grid) * width;
+        per_step = (size_t)(overlapped ? grid_interior + grid_boundary : launch_grid) * width;
         constexpr int kChunk = 64;
         chunk = std::min(n_steps, kChunk);
         if (int rc = sys->partial.reserve((size_t)kChunk * per_step)) return rc;
@@ -826,6 +963,7 @@ struct Batch {
                                         (real ? 32.0 : 64.0) * rv, &args.tile_order, &strip_rows))
             return rc;
         if (args.tile_order) band_lo = band_hi = -1;  // the band is a range of naturally ordered tiles
+        if (sweep) strip_rows = 0;
         cur = sys->vec_a.ptr;
         prev = sys->vec_b.ptr;
         kernel_ms = 0.f;
@@ -1037,6 +1175,57 @@ struct Batch {
         return BDG_OK;
     }
 
+    // Steps n and n + 1 in one sweep (sweep.hpp); the last step of an odd run alone.  Buffers
+    // rotate: (t_n, t_{n-1}, spare, spare) -> (t_{n+2}, t_{n+1}, spare, spare).
+    int step_sweep(int n) {
+        HIP_TRY(hipSetDevice(sys->device));
+        hipStream_t st = sys->stream;
+        const bool two = n + 1 < n_steps;
+        const int in_chunk = n % chunk;
+        const int chunk_id = n / chunk;
+        while ((int)sys->ev_pool.size() < 2 * (chunk_id + 1)) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreate(&ev));
+            sys->ev_pool.push_back(ev);
+        }
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id], st));
+        bdg::SweepArgs& a = splan.args;
+        a.cur = cur;
+        a.prev = prev;
+        a.out1 = spare1;
+        a.out2 = spare2;
+        a.coef1 = (n == 0 ? 1.0 : 2.0) / scale;
+        a.coef2 = 2.0 / scale;
+        a.two = two ? 1 : 0;
+        a.partial1 = sys->partial.ptr + (size_t)in_chunk * per_step;
+        a.partial2 = a.partial1 + per_step;  // chunk lengths are even (or the whole run): same chunk
+        splan.kernel<<<splan.grid, bdg::kBlockThreads, splan.lds_bytes, st>>>(a);
+        ++n_launches;
+        double2* old_cur = cur;
+        double2* old_prev = prev;
+        if (two) {
+            cur = spare2;
+            prev = spare1;
+            spare1 = old_prev;
+            spare2 = old_cur;
+        } else {
+            cur = spare1;
+            prev = old_cur;
+            spare1 = old_prev;
+        }
+        const int last = n + (two ? 1 : 0);
+        const int last_in_chunk = last % chunk;
+        if (last_in_chunk == chunk - 1 || last == n_steps - 1) {
+            const int s0 = last - last_in_chunk;
+            HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id + 1], st));
+            bdg::reduce_partials<<<last_in_chunk + 1, 256, 0, st>>>(
+                sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, launch_grid, (int)width);
+            HIP_TRY(hipGetLastError());
+            n_chunks = chunk_id + 1;
+        }
+        return BDG_OK;
+    }
+
     // d/e of this handle's rows into columns [col0, col0 + n_active) of (n_steps x ld) arrays;
     // accumulate = true adds to what is there (summing the slabs of a group).
     int finish(double* d_out, double* e_out, int ld, int col0, bool accumulate, bool first_batch) {
@@ -1061,17 +1250,18 @@ struct Batch {
         bdg_perf& p = sys->perf;
         if (first_batch) p = bdg_perf{};
         p.kernel_ms += kernel_ms;
-        p.launches += n_steps;
+        p.launches += sweep ? n_launches : n_steps;
         p.vector_steps += (int64_t)n_steps * n_active;
-        p.bytes_per_launch = algorithmic_bytes(sys, rv, mode, plan.dictionary);
+        p.bytes_per_launch = sweep ? sweep_bytes(sys, mode) : algorithmic_bytes(sys, rv, mode, plan.dictionary);
+        p.steps_per_launch = sweep ? 2 : 1;
         p.lanes_per_row = rl;
         p.vectors_per_launch = rv;
         p.real_arithmetic = real ? 1 : 0;
         p.ph_packed = mode.ph ? 1 : 0;
         p.dict_blocks = plan.dictionary ? sys->n_unique : 0;
         p.strip_rows = strip_rows;
-        p.grid = plan.grid;
-        p.lds_bytes = (int32_t)plan.lds_footprint;
+        p.grid = launch_grid;
+        p.lds_bytes = (int32_t)(sweep ? splan.lds_bytes : plan.lds_footprint);
         p.pipelined = plan.pipelined ? 1 : 0;
         return BDG_OK;
     }
@@ -1099,10 +1289,14 @@ StartSpec batch_start(const StartSpec& start, int col) {
 // to 200x200 sites, 32 at 300x300, 16 at 400x400, 8 from 64^3 on (10^6 sites: 18.0 us per
 // vector-step at 8 per batch, 21.3 us at 64).  Rule: the largest power of two that keeps one
 // vector buffer within 96 MB, at least one full lane group (8 real / 4 complex), at most 64.
-int batch_width(const bdg_system* sys, const StartSpec& start, int n_vectors) {
+int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors) {
     if (const char* env = getenv("BODGE_AMD_BATCH")) return std::clamp(atoi(env), 1, 64);
     const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
-    const bool real = sys->is_real && start_is_real;
+    const char* real_env = getenv("BODGE_AMD_REAL");
+    const bool real = sys->is_real && start_is_real && !(real_env && real_env[0] == '0');
+    bool sweep = false;
+    if (sys->lanes_override == 0 && sweep_wanted(sys, start.kind == StartKind::Random, false, &sweep) == BDG_OK && sweep)
+        return std::min(bdg::kSweepLanes * (real ? 2 : 1), std::max(n_vectors, 1));  // one lane group per sweep
     const double per_vector = (double)sys->ncols * 4 * (real ? 8.0 : 16.0);
     const int granule = real ? 8 : 4;
     constexpr double kBufferTarget = 96.0 * 1024 * 1024;
@@ -1127,6 +1321,11 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
             return rc;
         const auto t1 = now();
         for (int n = 0; n < n_steps; ++n) {
+            if (batch.sweep) {
+                if (int rc = batch.step_sweep(n)) return rc;
+                ++n;  // (a lone last step leaves the loop through its bound)
+                continue;
+            }
             if (batch.overlapped) {
                 if (int rc = batch.step_overlapped(n)) return rc;
                 continue;
@@ -1773,6 +1972,9 @@ int bdg_destroy(bdg_system* sys) {
     sys->dict_full.release();
     sys->vec_a.release();
     sys->vec_b.release();
+    sys->vec_c.release();
+    sys->vec_d.release();
+    sys->stencil.release();
     sys->partial.release();
     sys->dots.release();
     sys->rows.release();
@@ -1805,6 +2007,7 @@ int bdg_set_lattice_shape(bdg_system* sys, int32_t lx, int32_t ly, int32_t lz) {
     sys->shape[1] = ly;
     sys->shape[2] = lz;
     sys->order_rows_per_tile = 0;
+    sys->stencil_state = 0;
     return BDG_OK;
 }
 

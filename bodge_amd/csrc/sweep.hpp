@@ -1,0 +1,281 @@
+// K7  cheb_sweep  - the Chebyshev recurrence on a nearest-neighbour lattice stencil, TWO steps per
+//                   sweep of the vectors (or one), for matrices that pass the stencil test below.
+//
+// Why: the one-step kernels (kernels.hpp) read t_n and t_{n-1} and write t_{n+1}: three array
+// passes per step, and they already run at what a trivial 2-read-1-write stream reaches on this
+// chip (tools/stream_probe2.hip).  More steps per second therefore needs fewer bytes.  Here one
+// launch reads t_n and t_{n-1} once and writes t_{n+1} AND t_{n+2}: four passes per two steps
+// instead of six.  t_{n+1} never comes back from memory: every value of it that step two needs is
+// still in a register of the lane that made it, or of a neighbouring lane of the same wave.
+//
+// How: block rows are lattice sites numbered p + P*x (P = rows per x-plane; reference
+// lattice.py:108 with z + Lz*y = p), and the matrix is a stencil: block (i, j) is stored only for
+// j - i in {-P, -1, 0, +1, +P}, with +-1 inside one plane.  (Open boundaries in a 2-D lattice;
+// anything else - periodic wrap blocks, 3-D, general sparsity - fails the test made on the device
+// by `build_stencil` and runs the one-step kernels.)
+//
+// A wave owns a window of 12 consecutive in-plane positions and marches along x through one
+// segment of planes.  Its 16 site slots are [ghost, halo, 12 owned, halo, ghost]; lane (slot s,
+// vector group r) keeps, for its own position p:
+//     t_n     at planes k-1, k, k+1        (rolling registers)
+//     t_{n+1} at planes k-2, k-1, k        (rolling registers; plane k is made this iteration)
+// so the +-P neighbours are the lane's own registers and the +-1 neighbours are the registers of
+// lanes s-1 and s+1, handed over through a wave-private LDS row.  Per iteration k the wave
+//     loads   t_n[plane k+2], t_{n-1}[plane k+1]   (one plane ahead of their use: prefetch)
+//     step 1  t_{n+1}[k] = c1 H t_n - t_{n-1}      on slots 1..14  (halo slots redundantly)
+//     step 2  t_{n+2}[k-1] = c2 H t_{n+1} - t_n    on slots 2..13
+//     stores  t_{n+1}[k], t_{n+2}[k-1] of the owned slots (6 whole 128-byte lines each)
+// There are no gathers: every global access is a unit-stride 1 KiB wave access, every byte of the
+// four arrays is touched once per launch (plus the halo slots and the two extra planes at each
+// segment end, which are served by L1/L2 when the neighbouring window runs on the same CU/XCD).
+// Waves never communicate: halo values are recomputed, not exchanged, so there is no barrier, no
+// flag and no ordering requirement between workgroups.  Same Mode::mac_row on the same numbers in
+// the same (CSR) order as the one-step kernels => t_{n+1}, t_{n+2} are bit-identical to theirs;
+// only the summation order of the dot products differs.
+//
+// Algorithmic bytes per launch (two steps of RV vectors, 16-byte lane payloads, RL = 4 lanes per
+// site): 8 nb (stencil words) + table + 4 arrays x 256 nb.
+#pragma once
+
+#include "kernels.hpp"
+
+namespace bdg {
+
+constexpr int kSweepLanes = 4;                      // lanes per site (RL)
+constexpr int kSweepSlots = kWave / kSweepLanes;    // 16 site slots per wave
+constexpr int kSweepOwned = kSweepSlots - 4;        // 12 owned positions per wave window
+constexpr unsigned kNoBlock = 0xFFu;
+
+struct SweepArgs {
+    const uint2* stencil;    // per block row: table ids of the blocks at offsets -P, -1, 0, +1, +P
+                             // (bytes 0..4 of the 8-byte word, kNoBlock = not stored)
+    const void* dict_table;  // the distinct blocks, packed for the mode
+    int n_unique;
+    const double2* cur;      // t_n
+    const double2* prev;     // t_{n-1}
+    double2* out1;           // t_{n+1}
+    double2* out2;           // t_{n+2}
+    double* partial1;        // [gridDim.x][RL * kVec][2]  dots of step 1: <t_n|t_n>, <t_{n+1}|t_n>
+    double* partial2;        //                            dots of step 2: <t_{n+1}|t_{n+1}>, <t_{n+2}|t_{n+1}>
+    double coef1, coef2;
+    int nb;                  // block rows = lx * plane
+    int plane;               // P
+    int lx;
+    int n_cols;              // windows per plane = ceil(P / 12)
+    int n_segs;              // segments along x
+    int two;                 // 1 = both steps, 0 = step 1 only (odd tail of a run)
+    int stream;              // non-temporal hints: bit 0 t_{n-1} loads, bit 1 stores, bit 2 t_n loads
+};
+
+// Stencil table + eligibility test, on the device from the uploaded arrays.  `words` is the
+// dictionary form of the matrix (column | id << 24 per stored block).  bad[0] is raised if any
+// stored block is not one of the five stencil offsets.
+__global__ void build_stencil(const int* __restrict__ indptr, const int* __restrict__ words, int nb, int plane,
+                              uint2* __restrict__ stencil, int* __restrict__ bad) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        unsigned id[5] = {kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock};
+        const int p = i % plane;
+        bool ok = true;
+        for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
+            const unsigned w = (unsigned)words[k];
+            const int off = (int)(w & 0xFFFFFFu) - i;
+            int slot = -1;
+            if (off == -plane) slot = 0;
+            else if (off == -1 && p >= 1) slot = 1;
+            else if (off == 0) slot = 2;
+            else if (off == 1 && p <= plane - 2) slot = 3;
+            else if (off == plane) slot = 4;
+            if (slot < 0 || (w >> 24) == kNoBlock) ok = false;
+            else id[slot] = w >> 24;
+        }
+        if (!ok) atomicOr(bad, 1);
+        stencil[i] = make_uint2(id[0] | (id[1] << 8) | (id[2] << 16) | (id[3] << 24), id[4]);
+    }
+}
+
+template <typename Mode>
+__global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep(SweepArgs a) {
+    extern __shared__ double2 lds[];
+    constexpr int RL = kSweepLanes;
+    constexpr int SPB = Mode::kSlotsPerBlock;
+    constexpr int STRIDE = Mode::kBlockStride;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int s = lane / RL;
+    const int r = lane % RL;
+
+    // LDS: [table: n_unique x STRIDE slots][per wave: two rows of 64 lanes x 4 entries]
+    const double2* table = static_cast<const double2*>(a.dict_table);
+    for (int e = threadIdx.x; e < a.n_unique * SPB; e += kBlockThreads)
+        lds[(e / SPB) * STRIDE + (e % SPB)] = table[e];
+    double2* row_n = lds + a.n_unique * STRIDE + wave * (2 * kWave * 4);  // t_n of plane k
+    double2* row_1 = row_n + kWave * 4;                                   // t_{n+1} of plane k-1
+    __syncthreads();
+
+    // units = (segment, window); the workgroups of one XCD (b, b+8, ...) take one contiguous
+    // eighth of them, neighbouring windows on the waves of one workgroup (shared halos: same L1)
+    const int n_units = a.n_cols * a.n_segs;
+    const int xcd = blockIdx.x & 7;
+    const int u_lo = (int)(((int64_t)n_units * xcd) >> 3);
+    const int u_hi = (int)(((int64_t)n_units * (xcd + 1)) >> 3);
+    const int waves_per_xcd = (gridDim.x >> 3) * kWavesPerBlock;
+
+    double dot1[4] = {0.0, 0.0, 0.0, 0.0}, dot2[4] = {0.0, 0.0, 0.0, 0.0};
+    const double2 zero = make_double2(0.0, 0.0);
+    const size_t nb = (size_t)a.nb;
+    const bool nt_prev = a.stream & 1, nt_store = a.stream & 2, nt_cur = a.stream & 4;
+
+    for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
+        const int seg = u / a.n_cols, col = u - seg * a.n_cols;
+        const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
+        const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
+        const int p = col * kSweepOwned - 2 + s;
+        const bool valid = p >= 0 && p < a.plane;
+        const bool does1 = valid && s >= 1 && s <= kSweepSlots - 2;
+        const bool owned = valid && s >= 2 && s <= kSweepSlots - 3;
+
+        auto load_plane = [&](const double2* buf, bool nt, int k, bool wanted, double2 out[4]) {
+            if (wanted && k >= 0 && k < a.lx) {
+                const size_t site = (size_t)k * a.plane + p;
+#pragma unroll
+                for (int al = 0; al < 4; ++al)
+                    out[al] = nt ? load_stream(buf + vslot(al, site, r, nb, RL)) : buf[vslot(al, site, r, nb, RL)];
+            } else {
+#pragma unroll
+                for (int al = 0; al < 4; ++al) out[al] = zero;
+            }
+        };
+        auto load_ids = [&](int k) {
+            uint2 w = make_uint2(0xFFFFFFFFu, 0xFFu);
+            if (does1 && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + p];
+            return w;
+        };
+        auto id_of = [](uint2 w, int slot) { return slot < 4 ? (w.x >> (8 * slot)) & 0xFFu : w.y & 0xFFu; };
+        // acc += Σ_offsets block * x, in CSR (ascending column) order: -P, -1, 0, +1, +P
+        auto apply = [&](uint2 w, const double2 lo[4], const double2* row, const double2 mid[4],
+                         const double2 hi[4], double2 acc[4]) {
+            double2 x[4];
+            unsigned id = id_of(w, 0);
+            if (id != kNoBlock) Mode::mac_row(acc, lds + id * STRIDE, lo);
+            id = id_of(w, 1);
+            if (id != kNoBlock) {
+#pragma unroll
+                for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane - RL, be)];
+                Mode::mac_row(acc, lds + id * STRIDE, x);
+            }
+            id = id_of(w, 2);
+            if (id != kNoBlock) Mode::mac_row(acc, lds + id * STRIDE, mid);
+            id = id_of(w, 3);
+            if (id != kNoBlock) {
+#pragma unroll
+                for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane + RL, be)];
+                Mode::mac_row(acc, lds + id * STRIDE, x);
+            }
+            id = id_of(w, 4);
+            if (id != kNoBlock) Mode::mac_row(acc, lds + id * STRIDE, hi);
+        };
+
+        // Step 1 runs on planes k_first..k_last: the segment itself, plus one plane on either side
+        // when step 2 follows (its +-P neighbours at the segment ends).
+        const int k_first = a.two ? x0 - 1 : x0, k_last = a.two ? x1 : x1 - 1;
+
+        // ---- prologue: t_n of planes k_first-1, k_first, k_first+1; t_{n-1} and ids of plane k_first
+        double2 cn_m[4], cn_0[4], cn_p[4], pv[4], c1_m[4], c1_0[4];
+        load_plane(a.cur, nt_cur, k_first - 1, valid, cn_m);
+        load_plane(a.cur, nt_cur, k_first, valid, cn_0);
+        load_plane(a.cur, nt_cur, k_first + 1, valid, cn_p);
+        load_plane(a.prev, nt_prev, k_first, does1, pv);
+        uint2 ids_0 = load_ids(k_first), ids_m = make_uint2(0xFFFFFFFFu, 0xFFu);
+#pragma unroll
+        for (int al = 0; al < 4; ++al) c1_m[al] = c1_0[al] = zero;
+
+        for (int k = k_first; k <= k_last; ++k) {
+            // ---- prefetch what the next iteration consumes
+            double2 nx_cn[4], nx_pv[4];
+            const bool more = k < k_last;
+            load_plane(a.cur, nt_cur, k + 2, valid && more, nx_cn);
+            load_plane(a.prev, nt_prev, k + 1, does1 && more, nx_pv);
+            const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFu);
+
+            // ---- step 1 on plane k: t_{n+1} = c1 H t_n - t_{n-1}
+#pragma unroll
+            for (int be = 0; be < 4; ++be) row_n[SHARE_SLOT(lane, be)] = cn_0[be];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+            double2 new1[4];
+#pragma unroll
+            for (int al = 0; al < 4; ++al) new1[al] = zero;
+            const bool plane_ok = k >= 0 && k < a.lx;
+            if (does1 && plane_ok) {
+                double2 acc[4];
+#pragma unroll
+                for (int al = 0; al < 4; ++al) acc[al] = zero;
+                apply(ids_0, cn_m, row_n, cn_0, cn_p, acc);
+#pragma unroll
+                for (int al = 0; al < 4; ++al) {
+                    new1[al].x = fma(a.coef1, acc[al].x, -pv[al].x);
+                    new1[al].y = fma(a.coef1, acc[al].y, -pv[al].y);
+                }
+                if (owned && k >= x0 && k < x1) {
+                    const size_t site = (size_t)k * a.plane + p;
+#pragma unroll
+                    for (int al = 0; al < 4; ++al) {
+                        if (nt_store) store_stream(a.out1 + vslot(al, site, r, nb, RL), new1[al]);
+                        else a.out1[vslot(al, site, r, nb, RL)] = new1[al];
+                        Mode::dots(dot1, cn_0[al], new1[al]);
+                    }
+                }
+            }
+
+            // ---- step 2 on plane k-1: t_{n+2} = c2 H t_{n+1} - t_n   (row_1 holds t_{n+1}[k-1])
+            if (a.two) {
+                if (owned && k - 1 >= x0 && k - 1 < x1) {
+                    double2 acc[4];
+#pragma unroll
+                    for (int al = 0; al < 4; ++al) acc[al] = zero;
+                    apply(ids_m, c1_m, row_1, c1_0, new1, acc);
+                    const size_t site = (size_t)(k - 1) * a.plane + p;
+#pragma unroll
+                    for (int al = 0; al < 4; ++al) {
+                        double2 nx;
+                        nx.x = fma(a.coef2, acc[al].x, -cn_m[al].x);
+                        nx.y = fma(a.coef2, acc[al].y, -cn_m[al].y);
+                        if (nt_store) store_stream(a.out2 + vslot(al, site, r, nb, RL), nx);
+                        else a.out2[vslot(al, site, r, nb, RL)] = nx;
+                        Mode::dots(dot2, c1_0[al], nx);
+                    }
+                }
+                // t_{n+1}[k] takes the place of t_{n+1}[k-1] in the hand-over row (same wave: ordered)
+                __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+#pragma unroll
+                for (int be = 0; be < 4; ++be) row_1[SHARE_SLOT(lane, be)] = new1[be];
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+
+            // ---- roll
+#pragma unroll
+            for (int al = 0; al < 4; ++al) {
+                cn_m[al] = cn_0[al];
+                cn_0[al] = cn_p[al];
+                cn_p[al] = nx_cn[al];
+                pv[al] = nx_pv[al];
+                c1_m[al] = c1_0[al];
+                c1_0[al] = new1[al];
+            }
+            ids_m = ids_0;
+            ids_0 = nx_ids;
+        }
+    }
+
+    __syncthreads();  // table / hand-over rows are done with: the reductions reuse the front of the LDS
+    reduce_dots<Mode, RL>(dot1, reinterpret_cast<double*>(lds), a.partial1, lane, wave);
+    if (a.two) {
+        __syncthreads();
+        reduce_dots<Mode, RL>(dot2, reinterpret_cast<double*>(lds), a.partial2, lane, wave);
+    }
+}
+
+}  // namespace bdg

@@ -59,7 +59,7 @@ typedef struct bdg_perf {
     int32_t strip_rows;    /* strip width of the tile order in block rows, 0 = natural order */
     int32_t ph_packed;     /* 1 = particle-hole packed blocks (12 of 16 entries stored)      */
     int32_t dict_blocks;   /* >0 = dictionary form: number of distinct blocks in the table   */
-    int32_t reserved;
+    int32_t steps_per_launch; /* 2 = two recurrence steps per sweep of the vectors (lattice stencils), else 1 */
 } bdg_perf;
 
 const char* bdg_last_error(void);
