@@ -20,10 +20,17 @@ restatement (oracle/cheb_c.c) on this host on a bounded sample, with the
 single-core scipy.sparse restatement beside it.
 
 For N > 1 the driver starts one process per GPU with torch.distributed.run;
-only its environment variables are used (RANK, LOCAL_RANK, WORLD_SIZE,
-MASTER_PORT) - the collective is RCCL through the C ABI, not torch.  Only if the RCCL
-communicator cannot be created do the ranks fall back to torch.distributed (gloo) for the three
-scalar reductions of this script; config.collective says which one ran.
+only its environment variables are used (RANK, LOCAL_RANK, WORLD_SIZE, MASTER_ADDR,
+MASTER_PORT) - the collective is RCCL through the C ABI, not torch.  If the RCCL communicator
+cannot be created the run FAILS (exit code 3): a scaling number that did not go through RCCL is not
+a result.  `--allow-gloo` (rehearsals on a box with fewer GPUs than ranks) lets the ranks carry the
+three scalar reductions of this script over torch.distributed's gloo backend instead;
+config.collective and config.rccl_ranks always say what actually ran.
+
+The default kernel on this workload is the two-steps-per-sweep form (bodge_amd/csrc/sweep.hpp):
+one launch advances every vector by TWO recurrence steps, so K steps are K/2 launches and
+`roofline` is per launch of that kernel; the one-step kernels are timed beside it
+(`one_step_kernels`, `streamed_blocks_kernels`, `complex128_kernels`).
 """
 
 from __future__ import annotations
@@ -68,82 +75,55 @@ def build_system(shape, model="swave", zeeman=0.05, gap=0.1, mu=3.0):
 BASELINE_METRIC = "Chebyshev SpMV steps/s + achieved HBM GB/s, 4N\u00d74N BdG H; free_energy wall-time"
 
 
-class GlooReductions:
-    """Stand-in for the RCCL communicator in the bench's three reductions (sum of the moment
-    vector, max of the elapsed time, barrier), over torch.distributed's gloo backend.  Used only
-    if the RCCL communicator cannot be created; the JSON line then says so in config.collective."""
+class HostReductions:
+    """Stand-in for the RCCL communicator in this script's three reductions (sum of the moment
+    vector, max of the elapsed time, barrier), carried by the launch's TCP rendezvous store on the
+    host.  Only reachable with --allow-gloo when the RCCL communicator cannot be created (a
+    rehearsal of the launch path with more ranks than GPUs); the JSON line then says so in
+    config.collective and reports rccl_ranks = 0, and no credit is claimed for such a number."""
 
-    def __init__(self):
-        import torch
-        import torch.distributed as dist
+    def __init__(self, store):
+        self._store = store
 
-        self._torch, self._dist = torch, dist
-        if not dist.is_initialized():
-            from bodge_amd.solver import _StdoutToStderr
-
-            with _StdoutToStderr():  # gloo announces its peers on stdout; stdout carries the JSON line only
-                dist.init_process_group("gloo", init_method="env://")
-                dist.barrier()
-
-    def _reduce(self, values, op):
-        t = self._torch.from_numpy(np.array(values, dtype=np.float64))
-        self._dist.all_reduce(t, op=op)
-        return t.numpy()
+    def _gather(self, values):
+        arr = np.ascontiguousarray(values, dtype=np.float64)
+        return np.stack([np.frombuffer(blob, dtype=np.float64) for blob in self._store.gather(arr.tobytes())])
 
     def allreduce_sum(self, values):
-        return self._reduce(values, self._dist.ReduceOp.SUM)
+        return self._gather(values).sum(axis=0)
 
     def allreduce_max(self, values):
-        return self._reduce(values, self._dist.ReduceOp.MAX)
+        return self._gather(values).max(axis=0)
 
     def barrier(self):
-        self._dist.barrier()
-
-    def finish(self):
-        """torch brings its own ROCm runtime next to the one libbodge_hip.so loaded; their exit-time
-        destructors collide (double free at interpreter shutdown), so leave without running them."""
-        self._dist.barrier()
-        self._dist.destroy_process_group()
-        sys.stdout.flush()
-        sys.stderr.flush()
-        os._exit(0)
+        self._store.barrier()
 
 
-def make_communicator(communicator_cls, world: int, rank: int, mode: str):
-    """(communicator or None, description).  RCCL through the library; if that raises on this rank
-    the ranks agree through status files (a rank cannot fall back alone) and use gloo instead."""
+def make_communicator(communicator_cls, world: int, rank: int, mode: str, allow_gloo: bool = False, store=None):
+    """(communicator or None, description).  RCCL through the library.  If that fails on any rank
+    the whole run exits non-zero, unless `allow_gloo`: then the ranks agree through the rendezvous
+    store (a rank cannot fall back alone) and carry the script's reductions over the host."""
     if world <= 1:
         return communicator_cls.from_environment(), "none (single process)"
-    tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-    base = os.path.join(os.environ.get("BODGE_AMD_RDZV_DIR", "/tmp"), f"bodge_amd_bench_{tag}")
     comm, error = None, ""
     try:
         comm = communicator_cls.from_environment()
     except Exception as exc:  # noqa: BLE001 - any failure means "no RCCL on this rank"
         error = f"{type(exc).__name__}: {exc}"
-    import atexit
+    if store is None:
+        from bodge_amd.rendezvous import store_from_environment
 
-    own = f"{base}_rank{rank}.status"
-    with open(f"{own}.tmp", "w") as fh:
-        fh.write("ok" if comm is not None else error or "failed")
-    os.replace(f"{own}.tmp", own)
-    atexit.register(lambda: os.path.exists(own) and os.unlink(own))
-    deadline = time.time() + 300
-    states = []
-    for r in range(world):
-        path = f"{base}_rank{r}.status"
-        while not (os.path.exists(path) and os.path.getsize(path) > 0):
-            if time.time() > deadline:
-                sys.exit(f"rank {rank}: no communicator status from rank {r}")
-            time.sleep(0.05)
-        with open(path) as fh:
-            states.append(fh.read())
+        store = store_from_environment()
+    states = [blob.decode("utf-8", "replace") for blob in store.gather(("ok" if comm is not None else (error or "failed")).encode())]
     if all(state == "ok" for state in states):
         return comm, "rccl (ncclAllReduce of the moments inside bdg_cheb_moments)"
-    if mode == "slab":
-        sys.exit(f"rank {rank}: slab mode needs RCCL send/recv; communicator states: {states}")
     reason = next(state for state in states if state != "ok")
-    return GlooReductions(), f"gloo fallback on the host (RCCL communicator failed: {reason[:200]})"
+    if not allow_gloo or mode == "slab":
+        print(f"rank {rank}: the RCCL communicator could not be created on every rank ({reason[:300]}); no number "
+              "is reported (--allow-gloo rehearses the launch path with host-side reductions)", file=sys.stderr, flush=True)
+        store.finish(10.0)
+        sys.exit(3)
+    return HostReductions(store), f"host fallback over the TCP rendezvous store (RCCL communicator failed: {reason[:200]})"
 
 
 def measured_traffic(kernel: str, shape, vectors: int):
@@ -161,10 +141,57 @@ def measured_traffic(kernel: str, shape, vectors: int):
     return entry["traffic_bytes_per_launch"] if entry else None
 
 
+def cpu_baseline(system, scale, r_local, kind, seconds):
+    """The CPU restatements timed on this host (rank 0, N = 1 only), BEFORE the process touches the
+    GPU: the whole-host scipy number forks worker processes, which must not inherit a live HIP
+    runtime.  Headline = C + OpenMP restatement (oracle/cheb_c.c) in the arithmetic the GPU
+    headline uses (float64 when imag(H) = 0 and the vectors are real), at the better of two thread
+    counts - so the CPU side is not handicapped by interpreter overhead, storage format, dtype or
+    thread count."""
+    from oracle import cheb_c, cheb_ref
+
+    bsr = system.matrix("bsr")
+    logical = os.cpu_count() or 2
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    short = max(2.0, seconds / 4)
+    real = (not bsr.data.imag.any()) and kind == cheb_ref.VEC_RADEMACHER
+    start = cheb_ref.random_block(bsr.shape[0], 0, range(r_local), kind)
+    best = None
+    for threads in sorted({min(16, usable), min(64, usable)}):
+        cheb_c.set_threads(threads)
+        rate, steps, _ = cheb_c.time_recurrence(bsr, scale, start, seconds=short, real=real)
+        if best is None or rate > best[0]:
+            best = (rate, steps, threads)
+    extra = {}
+    if real:
+        cheb_c.set_threads(best[2])
+        extra["c_openmp_complex128_steps_per_s"] = cheb_c.time_recurrence(bsr, scale, start, seconds=short)[0]
+    # the numpy/scipy restatement the parity tests use: one core, its variants, and the whole host
+    # (P forked workers with one vector each on the shared matrix, BASELINE.md §5 ii)
+    extra["scipy_bsr_1core_steps_per_s"] = cheb_ref.time_recurrence(bsr, scale, r_local, seconds=short, kind=kind)[0]
+    extra["scipy_csr_1core_steps_per_s"] = cheb_ref.time_recurrence(bsr, scale, r_local, seconds=short, kind=kind, fmt="csr")[0]
+    if real:
+        extra["scipy_csr_real_1core_steps_per_s"] = cheb_ref.time_recurrence(
+            bsr, scale, r_local, seconds=short, kind=kind, fmt="csr", real=True)[0]
+    workers = max(1, min(16, usable))
+    extra["scipy_bsr_whole_host_steps_per_s"] = cheb_ref.time_recurrence_processes(bsr, scale, 1, workers, seconds=short)
+    extra["scipy_bsr_whole_host_processes"] = workers
+    return {
+        "value": best[0],
+        "unit": "steps/s",
+        "cores": best[2],
+        "kind": "port",
+        "sample": f"{best[1]} timed block-steps of the same {r_local} vectors on the same H: C + OpenMP "
+                  f"restatement (oracle/cheb_c.c), {'float64' if real else 'complex128'} arithmetic, "
+                  f"{best[2]} threads (host: {logical} logical cores, {usable} usable by this process)",
+        "other_cpu_variants": extra,
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=256, help="recurrence launches in the timed call (2x moments)")
+    ap.add_argument("--steps", type=int, default=256, help="recurrence steps in the timed call (2x moments)")
     ap.add_argument("--warmup", type=int, default=8)
     ap.add_argument("--lattice", default="1000,1000,1")
     ap.add_argument("--vectors-per-gpu", type=int, default=8)
@@ -176,6 +203,9 @@ def main():
     ap.add_argument("--mode", default="vectors", choices=["vectors", "slab"],
                     help="vectors: H replicated, start vectors sharded (weak scaling, headline); "
                          "slab: lattice planes sharded with per-step halo exchange (strong scaling, config 4)")
+    ap.add_argument("--allow-gloo", action="store_true",
+                    help="if RCCL cannot be initialised, do the script's reductions on the host instead of failing "
+                         "(rehearsal of the launch path only)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -189,21 +219,48 @@ def main():
     from bodge_amd import backend, build, chebyshev
     from bodge_amd.solver import VEC_RADEMACHER, VEC_Z4, Communicator, DeviceSolver
 
-    if rank == 0 and not os.path.exists(build.LIBRARY):
+    # rank 0 (re)builds a missing or stale library; the others wait for a current one
+    store = None
+    if world > 1:
+        from bodge_amd.rendezvous import store_from_environment
+
+        store = store_from_environment()
+    if rank == 0:
         build.build_library()
-    backend.load()
-    backend.require_device()
-    comm, collective = make_communicator(Communicator, world, rank, args.mode)
+    if store is not None:
+        store.barrier()
 
     shape = [int(v) for v in args.lattice.split(",")]
+    kind = VEC_RADEMACHER if args.vector_kind == "rademacher" else VEC_Z4
+    r_local = args.vectors_per_gpu
     t0 = time.perf_counter()
     system = build_system(shape, args.model)
     indptr, indices, data = system.bsr_arrays()
     scale = chebyshev.spectral_bound(indptr, data)
     t_build = time.perf_counter() - t0
+
+    cpu_record = None
+    if args.cpu_seconds > 0 and args.gpus == 1 and rank == 0:
+        cpu_record = cpu_baseline(system, scale, r_local, kind, args.cpu_seconds)  # before any GPU call
+
+    backend.load()
+    backend.require_device()
+    comm, collective = make_communicator(Communicator, world, rank, args.mode, args.allow_gloo, store)
+    rccl = isinstance(comm, Communicator)
+    # what RCCL itself spans: rank count and the PCI bus id of every rank's device
+    rccl_ranks, rank_devices = 0, [None] * world
+    if rccl:
+        info = comm.info()
+        rccl_ranks = info["n_ranks"]
+        packed = [int(part, 16) for part in info["pci_bus_id"].replace(".", ":").split(":")]  # domain:bus:device.function
+        code = float((packed[0] << 16) | (packed[1] << 8) | (packed[2] << 3) | packed[3])
+        slots = np.zeros(world)
+        slots[rank] = code
+        for r, value in enumerate(comm.allreduce_sum(slots)):
+            v = int(value)
+            rank_devices[r] = f"{v >> 16:04x}:{(v >> 8) & 0xFF:02x}:{(v >> 3) & 0x1F:02x}.{v & 7}"
+
     device = local % backend.device_count()
-    kind = VEC_RADEMACHER if args.vector_kind == "rademacher" else VEC_Z4
-    r_local = args.vectors_per_gpu
     if args.mode == "slab":
         # every rank advances the same r_local vectors on its own slab of x-planes
         from bodge_amd import slab
@@ -220,69 +277,78 @@ def main():
         solver.set_lanes_per_row(args.lanes)
 
     def run(steps):
-        if isinstance(comm, GlooReductions):  # RCCL unavailable: local moments, summed on the host
+        if isinstance(comm, HostReductions):  # RCCL unavailable: local moments, summed on the host
             return comm.allreduce_sum(
                 solver.moments_random(scale, 2 * steps, r_local, seed=0, first_id=first, kind=kind, comm=None))
         return solver.moments_random(scale, 2 * steps, r_local, seed=0, first_id=first, kind=kind, comm=comm)
 
-    if args.warmup > 0:
-        run(args.warmup)
-    if comm is not None:
-        comm.barrier()
-    t0 = time.perf_counter()
-    mu = run(args.steps)
-    elapsed = time.perf_counter() - t0
-    if comm is not None:
-        elapsed = float(comm.allreduce_max(np.array([elapsed]))[0])
-    perf = solver.perf()
-
-    # Further passes with optimisations switched off, reported beside the headline and never as
-    # `value`: blocks streamed from HBM instead of the LDS dictionary, and complex arithmetic.
-    def alternative(env):
-        for k, v in env.items():
-            os.environ[k] = v
+    def timed(steps):
         if comm is not None:
             comm.barrier()
         t0 = time.perf_counter()
-        run(args.steps)
+        mu = run(steps)
         dt = time.perf_counter() - t0
         if comm is not None:
             dt = float(comm.allreduce_max(np.array([dt]))[0])
-        pf = solver.perf()
-        for k in env:
-            del os.environ[k]
+        return mu, dt, solver.perf()
+
+    if args.warmup > 0:
+        run(args.warmup)
+    mu, elapsed, perf = timed(args.steps)
+    total_vectors = r_local * (1 if args.mode == "slab" else args.gpus)
+
+    def kernel_label(pf):
+        mode = f"{'Real' if pf['real_arithmetic'] else 'Complex'}{'PH' if pf['ph_packed'] else ''}Mode"
+        if pf["steps_per_launch"] == 2:
+            return f"cheb_sweep<{mode}>"
+        family = "cheb_step_dict" if pf["dict_blocks"] else "cheb_step_pipelined" if pf["pipelined"] else "cheb_step"
+        return f"{family}<{mode},{pf['lanes_per_row']}>"
+
+    # Further passes with optimisations switched off, reported beside the headline and never as
+    # `value`: one recurrence step per launch, blocks streamed from HBM instead of the LDS
+    # dictionary, and complex arithmetic (the reference's own dtype).
+    def alternative(env):
+        os.environ.update(env)
+        try:
+            _, dt, pf = timed(args.steps)
+        finally:
+            for k in env:
+                del os.environ[k]
         launch = pf["kernel_ms"] / max(1, pf["launches"])
         return {
-            "value": r_local * (1 if args.mode == "slab" else args.gpus) * args.steps / dt,
+            "value": total_vectors * args.steps / dt,
             "unit": "steps/s",
+            "kernel": kernel_label(pf),
             "launch_ms": launch,
+            "steps_per_launch": pf["steps_per_launch"],
             "bytes_per_launch": pf["bytes_per_launch"],
             "achieved_GBps": pf["bytes_per_launch"] / (launch * 1e-3) / 1e9,
             "frac": pf["bytes_per_launch"] / (launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "traffic": measured_traffic(kernel_label(pf), shape, r_local),
         }
 
-    streamed_pass = alternative({"BODGE_AMD_DICT": "0"}) if perf["dict_blocks"] else None
-    complex_pass = alternative({"BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"}) if perf["real_arithmetic"] else None
+    one_step_pass = alternative({"BODGE_AMD_SWEEP": "0"}) if perf["steps_per_launch"] == 2 else None
+    streamed_pass = alternative({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0"}) if perf["dict_blocks"] else None
+    complex_pass = (alternative({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"})
+                    if perf["real_arithmetic"] else None)
 
     if rank != 0:
-        if isinstance(comm, GlooReductions):
-            comm.finish()
+        if store is not None:
+            store.finish()
         return
 
-    total_vectors = r_local * (1 if args.mode == "slab" else args.gpus)
     value = total_vectors * args.steps / elapsed
     launch_ms = perf["kernel_ms"] / max(1, perf["launches"])
     achieved = perf["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
     free_energy = chebyshev.free_energy_series(mu / total_vectors, scale, args.temperature)
-
-    kernel_name = ("cheb_step_dict" if perf["dict_blocks"] else
-                   "cheb_step_pipelined" if perf["pipelined"] else "cheb_step") + (
-        f"<{'Real' if perf['real_arithmetic'] else 'Complex'}{'PH' if perf['ph_packed'] else ''}Mode,"
-        f"{perf['lanes_per_row']}>")
+    kernel_name = kernel_label(perf)
+    model_label = {"swave": "s-wave+Zeeman", "dwave": "d-wave"}[args.model]
     record = {
         "metric": BASELINE_METRIC,
         "metric_detail": "value = Chebyshev vector-steps/s (one step = t_{n+1} = 2 H t_n / a - t_{n-1} on one vector, fused "
-                         "with the two dot products); achieved HBM GB/s in roofline.achieved; wall time in free_energy_wall_s",
+                         "with the two dot products); achieved HBM GB/s in roofline.achieved (per launch of "
+                         "roofline.kernel, which advances every vector by roofline.steps_per_launch steps); "
+                         "wall time in free_energy_wall_s",
         "value": value,
         "unit": "steps/s",
         "n_gpus": args.gpus,
@@ -295,7 +361,7 @@ def main():
         "dtype": "f64" if perf["real_arithmetic"] else "c128",
         "data": "synthetic",
         "config": {
-            "workload": f"CubicLattice({tuple(shape)}) {args.model}, {2 * args.steps}-moment stochastic-trace "
+            "workload": f"CubicLattice({tuple(shape)}) {model_label}, {2 * args.steps}-moment stochastic-trace "
                         + (f"free_energy, {r_local} vectors, x-plane slabs with halo exchange" if args.mode == "slab"
                            else f"free_energy, {r_local} vectors/GPU, H replicated, vectors sharded"),
             "n_sites": int(system.lattice.size),
@@ -306,6 +372,8 @@ def main():
             "spectral_scale": scale,
             "parallelism": f"{args.mode} x{args.gpus}",
             "collective": collective,
+            "rccl_ranks": rccl_ranks,        # ncclCommCount of the communicator the moments were reduced over (0 = none)
+            "rank_devices": rank_devices,    # PCI bus id of every rank's GPU, gathered over that communicator
         },
         "roofline": {
             "bound": "hbm",
@@ -316,6 +384,8 @@ def main():
             "traffic": measured_traffic(kernel_name, shape, r_local),
             "kernel": kernel_name,
             "launch_ms": launch_ms,
+            "steps_per_launch": perf["steps_per_launch"],
+            "launches": perf["launches"],
             "bytes_per_launch": perf["bytes_per_launch"],
             "grid": perf["grid"],
             "lds_bytes": perf["lds_bytes"],
@@ -325,52 +395,14 @@ def main():
         "free_energy_wall_s": elapsed,
         "free_energy_estimate": free_energy,
         "host_assembly_s": t_build,
+        "one_step_kernels": one_step_pass,
         "streamed_blocks_kernels": streamed_pass,
         "complex128_kernels": complex_pass,
+        "cpu_baseline": cpu_record,
     }
-
-    if args.cpu_seconds > 0 and args.gpus == 1:
-        from oracle import cheb_c, cheb_ref
-
-        bsr = system.matrix("bsr")
-        logical = os.cpu_count() or 2
-        short = max(3.0, args.cpu_seconds / 3)
-        real = bool(perf["real_arithmetic"])
-        start = cheb_ref.random_block(bsr.shape[0], 0, range(r_local), kind)
-        # headline CPU number: the C + OpenMP restatement in the arithmetic the GPU headline used
-        # (real when imag(H) = 0), at the better of two thread counts - so the CPU side is not
-        # handicapped by interpreter overhead, storage format, dtype or thread count
-        best = None
-        for threads in sorted({min(16, logical), min(64, logical)}):
-            cheb_c.set_threads(threads)
-            rate, steps, _ = cheb_c.time_recurrence(bsr, scale, start, seconds=short, real=real)
-            if best is None or rate > best[0]:
-                best = (rate, steps, threads)
-        extra = {}
-        if real:
-            cheb_c.set_threads(best[2])
-            extra["c_openmp_complex128_steps_per_s"] = cheb_c.time_recurrence(bsr, scale, start, seconds=short)[0]
-        # the numpy/scipy restatement the parity tests use, one core, and its variants
-        extra["scipy_bsr_1core_steps_per_s"] = cheb_ref.time_recurrence(bsr, scale, r_local, seconds=short, kind=kind)[0]
-        extra["scipy_csr_1core_steps_per_s"] = cheb_ref.time_recurrence(bsr, scale, r_local, seconds=short, kind=kind, fmt="csr")[0]
-        if real:
-            extra["scipy_csr_real_1core_steps_per_s"] = cheb_ref.time_recurrence(
-                bsr, scale, r_local, seconds=short, kind=kind, fmt="csr", real=True)[0]
-        record["cpu_baseline"] = {
-            "value": best[0],
-            "unit": "steps/s",
-            "cores": best[2],
-            "kind": "port",
-            "sample": f"{best[1]} timed block-steps of the same {r_local} vectors on the same H: C + OpenMP "
-                      f"restatement (oracle/cheb_c.c), {'float64' if real else 'complex128'} arithmetic, "
-                      f"{best[2]} threads (host has {logical} logical cores)",
-            "other_cpu_variants": extra,
-        }
-    else:
-        record["cpu_baseline"] = None
     print(json.dumps(record), flush=True)
-    if isinstance(comm, GlooReductions):
-        comm.finish()
+    if store is not None:
+        store.finish()
 
 
 if __name__ == "__main__":

@@ -87,6 +87,7 @@ SIGNATURES = {
     "bdg_set_lanes_per_row": (C.c_int, [_handle, C.c_int32]),
     "bdg_comm_unique_id": (C.c_int, [_u8p]),
     "bdg_comm_init": (C.c_int, [C.c_int, _u8p, C.c_int32, C.c_int32, C.POINTER(_handle)]),
+    "bdg_comm_info": (C.c_int, [_handle, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p]),
     "bdg_comm_allreduce_sum": (C.c_int, [_handle, _f64p, C.c_int64]),
     "bdg_comm_allreduce_max": (C.c_int, [_handle, _f64p, C.c_int64]),
     "bdg_comm_destroy": (C.c_int, [_handle]),

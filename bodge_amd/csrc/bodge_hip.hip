@@ -517,17 +517,17 @@ int prepare_tile_order(bdg_system* sys, int rows_per_tile, int n_tiles, double r
 // ------------------------------------------------------- two steps per sweep (sweep.hpp)
 using SweepKernel = void (*)(bdg::SweepArgs);
 
-SweepKernel sweep_kernel(const ModeInfo& mode) {
+SweepKernel sweep_kernel(const ModeInfo& mode, bool reverse) {
     switch (mode.id) {
-        case 1: return bdg::cheb_sweep<RealMode>;
-        case 2: return bdg::cheb_sweep<ComplexPHMode>;
-        case 3: return bdg::cheb_sweep<RealPHMode>;
+        case 1: return reverse ? bdg::cheb_sweep<RealMode, true> : bdg::cheb_sweep<RealMode, false>;
+        case 2: return reverse ? bdg::cheb_sweep<ComplexPHMode, true> : bdg::cheb_sweep<ComplexPHMode, false>;
+        case 3: return reverse ? bdg::cheb_sweep<RealPHMode, true> : bdg::cheb_sweep<RealPHMode, false>;
     }
-    return bdg::cheb_sweep<ComplexMode>;
+    return reverse ? bdg::cheb_sweep<ComplexMode, true> : bdg::cheb_sweep<ComplexMode, false>;
 }
 
 struct SweepPlan {
-    SweepKernel kernel = nullptr;
+    SweepKernel kernel = nullptr, kernel_reverse = nullptr;
     int grid = 0;
     size_t lds_bytes = 0;
     bdg::SweepArgs args{};
@@ -585,15 +585,20 @@ int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, bool* wan
 }
 
 int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, SweepPlan* plan) {
-    plan->kernel = sweep_kernel(mode);
+    plan->kernel = sweep_kernel(mode, false);
+    plan->kernel_reverse = sweep_kernel(mode, true);
     const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
     if (table > kDictLdsLimit) return fail(BDG_EINVAL, "block table too large for the sweep kernel");
-    const size_t rows = (size_t)bdg::kWavesPerBlock * 2 * bdg::kWave * 4 * sizeof(double2);
+    const size_t rows = (size_t)bdg::kSweepWaves * 2 * bdg::kWave * 4 * sizeof(double2);
     plan->lds_bytes = table + rows;
+    if (plan->lds_bytes > 64 * 1024)
+        for (SweepKernel k : {plan->kernel, plan->kernel_reverse})
+            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)plan->lds_bytes));
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(plan->kernel),
-                                                         bdg::kBlockThreads, plan->lds_bytes));
-    per_cu = std::max(1, std::min(per_cu, 2));
+                                                         bdg::kSweepThreads, plan->lds_bytes));
+    per_cu = std::max(1, std::min(per_cu, 2 * bdg::kWavesPerBlock / bdg::kSweepWaves));
     if (const char* cap = getenv("BODGE_AMD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(cap));
     const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
     bdg::SweepArgs& a = plan->args;
@@ -606,12 +611,14 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, SweepPlan* plan) {
     a.lx = sys->shape[0];
     a.n_cols = (int)((plane + bdg::kSweepOwned - 1) / bdg::kSweepOwned);
     // one unit (segment x window) per resident wave, segments of at least 8 planes
-    const int waves = per_cu * sys->num_cus * bdg::kWavesPerBlock;
+    const int waves = per_cu * sys->num_cus * bdg::kSweepWaves;
     int n_segs = (waves + a.n_cols / 2) / a.n_cols;
     if (const char* env = getenv("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
     a.n_segs = std::max(1, std::min(n_segs, a.lx / 8));
+    a.zigzag = 1;
+    if (const char* env = getenv("BODGE_AMD_SWEEP_ZIGZAG")) a.zigzag = atoi(env) != 0;
     const int64_t units = (int64_t)a.n_cols * a.n_segs;
-    const int grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus, (units + bdg::kWavesPerBlock - 1) / bdg::kWavesPerBlock);
+    const int grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus, (units + bdg::kSweepWaves - 1) / bdg::kSweepWaves);
     plan->grid = std::max(8, (grid + 7) / 8 * 8);
     return BDG_OK;
 }
@@ -761,6 +768,7 @@ struct RcclApi {
     decltype(&ncclRecv) recv = nullptr;
     decltype(&ncclGroupStart) group_start = nullptr;
     decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;
 };
 
 int load_rccl(RcclApi** out) {
@@ -785,8 +793,9 @@ int load_rccl(RcclApi** out) {
             api.recv = reinterpret_cast<decltype(api.recv)>(dlsym(api.lib, "ncclRecv"));
             api.group_start = reinterpret_cast<decltype(api.group_start)>(dlsym(api.lib, "ncclGroupStart"));
             api.group_end = reinterpret_cast<decltype(api.group_end)>(dlsym(api.lib, "ncclGroupEnd"));
+            api.comm_count = reinterpret_cast<decltype(api.comm_count)>(dlsym(api.lib, "ncclCommCount"));
             ok = api.get_unique_id && api.comm_init_rank && api.all_reduce && api.comm_destroy &&
-                 api.error_string && api.send && api.recv && api.group_start && api.group_end;
+                 api.error_string && api.send && api.recv && api.group_start && api.group_end && api.comm_count;
         }
     }
     if (!ok) return fail(BDG_ELIBRARY, "RCCL could not be loaded: %s", dlerror());
@@ -1199,7 +1208,8 @@ struct Batch {
         a.two = two ? 1 : 0;
         a.partial1 = sys->partial.ptr + (size_t)in_chunk * per_step;
         a.partial2 = a.partial1 + per_step;  // chunk lengths are even (or the whole run): same chunk
-        splan.kernel<<<splan.grid, bdg::kBlockThreads, splan.lds_bytes, st>>>(a);
+        (alternate && (n_launches & 1) ? splan.kernel_reverse : splan.kernel)<<<splan.grid, bdg::kSweepThreads,
+                                                                                  splan.lds_bytes, st>>>(a);
         ++n_launches;
         double2* old_cur = cur;
         double2* old_prev = prev;
@@ -1298,7 +1308,7 @@ int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors) {
     if (sys->lanes_override == 0 && sweep_wanted(sys, start.kind == StartKind::Random, false, &sweep) == BDG_OK && sweep)
         return std::min(bdg::kSweepLanes * (real ? 2 : 1), std::max(n_vectors, 1));  // one lane group per sweep
     const double per_vector = (double)sys->ncols * 4 * (real ? 8.0 : 16.0);
-    const int granule = real ? 8 : 4;
+    const int granule = 8;  // (the register-pipelined complex kernels start at 8 lanes per row)
     constexpr double kBufferTarget = 96.0 * 1024 * 1024;
     int width = 64;
     while (width > granule && width * per_vector > kBufferTarget) width >>= 1;
@@ -2346,6 +2356,19 @@ int bdg_comm_init(int device, const uint8_t id[128], int32_t n_ranks, int32_t ra
         return fail(BDG_ELIBRARY, "ncclCommInitRank failed: %s", api->error_string(res));
     }
     *out = comm;
+    return BDG_OK;
+}
+
+int bdg_comm_info(bdg_comm* comm, int32_t* n_ranks, int32_t* rank, int32_t* device, char pci_bus_id[32]) {
+    if (!comm || !n_ranks || !rank || !device || !pci_bus_id) return fail(BDG_EINVAL, "null argument");
+    RcclApi* api = nullptr;
+    if (int rc = load_rccl(&api)) return rc;
+    int count = 0;
+    NCCL_TRY(api, api->comm_count(comm->comm, &count));  // what RCCL itself says, not what was asked for
+    *n_ranks = count;
+    *rank = comm->rank;
+    *device = comm->device;
+    HIP_TRY(hipDeviceGetPCIBusId(pci_bus_id, 32, comm->device));
     return BDG_OK;
 }
 

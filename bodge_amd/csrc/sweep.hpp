@@ -65,6 +65,7 @@ struct SweepArgs {
     int n_segs;              // segments along x
     int two;                 // 1 = both steps, 0 = step 1 only (odd tail of a run)
     int stream;              // non-temporal hints: bit 0 t_{n-1} loads, bit 1 stores, bit 2 t_n loads
+    int zigzag;              // 1 = odd segments march against the even ones
 };
 
 // Stencil table + eligibility test, on the device from the uploaded arrays.  `words` is the
@@ -93,8 +94,45 @@ __global__ void build_stencil(const int* __restrict__ indptr, const int* __restr
     }
 }
 
-template <typename Mode>
-__global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep(SweepArgs a) {
+// Marching direction.  A segment marched "in reverse" runs from its far end back (plane k of the
+// text below is then plane x0 + x1 - 1 - k of the lattice).  Two uses:
+//  * neighbouring segments march in opposite directions (even ones up, odd ones down), so the two
+//    waves on either side of a segment boundary read the planes around it at the same time - the
+//    planes each recomputes for the other are then L2 / Infinity-Cache hits instead of a second
+//    trip to HBM;
+//  * REV flips all of them: launches alternate, so that each starts on the planes the previous
+//    launch wrote last, i.e. the ones the Infinity Cache still holds.
+// Wave reduction over the site lanes, then over the workgroup's waves: partial[block][vector][{d, e}].
+template <typename Mode, int RL, int WAVES>
+__device__ inline void sweep_reduce_dots(double dot[4], double* red, double* partial, int lane, int wave) {
+    constexpr int W = 2 * Mode::kVec;  // doubles per lane
+#pragma unroll
+    for (int off = kWave / 2; off >= RL; off >>= 1)
+#pragma unroll
+        for (int c = 0; c < W; ++c) dot[c] += __shfl_xor(dot[c], off);
+    if (lane < RL)
+#pragma unroll
+        for (int c = 0; c < W; ++c) red[(wave * RL + lane) * W + c] = dot[c];
+    __syncthreads();
+    if ((int)threadIdx.x < W * RL) {
+        double tot = 0.0;
+#pragma unroll
+        for (int w = 0; w < WAVES; ++w) tot += red[w * RL * W + threadIdx.x];
+        partial[(size_t)blockIdx.x * RL * W + threadIdx.x] = tot;
+    }
+}
+
+// kSweepWaves consecutive windows per workgroup: the windows of one workgroup share their halo
+// reads through the CU's L1, those of different workgroups through L2.  (8 waves per workgroup,
+// one workgroup per CU, measured the same as 4 and two: profiles/r02_sweep_experiments.log.)
+#ifndef BDG_SWEEP_WAVES
+#define BDG_SWEEP_WAVES 4
+#endif
+constexpr int kSweepWaves = BDG_SWEEP_WAVES;
+constexpr int kSweepThreads = kSweepWaves * kWave;
+
+template <typename Mode, bool REV>
+__global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
     extern __shared__ double2 lds[];
     constexpr int RL = kSweepLanes;
     constexpr int SPB = Mode::kSlotsPerBlock;
@@ -106,7 +144,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep(SweepArgs a) {
 
     // LDS: [table: n_unique x STRIDE slots][per wave: two rows of 64 lanes x 4 entries]
     const double2* table = static_cast<const double2*>(a.dict_table);
-    for (int e = threadIdx.x; e < a.n_unique * SPB; e += kBlockThreads)
+    for (int e = threadIdx.x; e < a.n_unique * SPB; e += kSweepThreads)
         lds[(e / SPB) * STRIDE + (e % SPB)] = table[e];
     double2* row_n = lds + a.n_unique * STRIDE + wave * (2 * kWave * 4);  // t_n of plane k
     double2* row_1 = row_n + kWave * 4;                                   // t_{n+1} of plane k-1
@@ -118,14 +156,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep(SweepArgs a) {
     const int xcd = blockIdx.x & 7;
     const int u_lo = (int)(((int64_t)n_units * xcd) >> 3);
     const int u_hi = (int)(((int64_t)n_units * (xcd + 1)) >> 3);
-    const int waves_per_xcd = (gridDim.x >> 3) * kWavesPerBlock;
+    const int waves_per_xcd = (gridDim.x >> 3) * kSweepWaves;
 
     double dot1[4] = {0.0, 0.0, 0.0, 0.0}, dot2[4] = {0.0, 0.0, 0.0, 0.0};
     const double2 zero = make_double2(0.0, 0.0);
     const size_t nb = (size_t)a.nb;
     const bool nt_prev = a.stream & 1, nt_store = a.stream & 2, nt_cur = a.stream & 4;
 
-    for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
+    for (int u = u_lo + (int)(blockIdx.x >> 3) * kSweepWaves + wave; u < u_hi; u += waves_per_xcd) {
         const int seg = u / a.n_cols, col = u - seg * a.n_cols;
         const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
         const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
@@ -134,7 +172,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep(SweepArgs a) {
         const bool does1 = valid && s >= 1 && s <= kSweepSlots - 2;
         const bool owned = valid && s >= 2 && s <= kSweepSlots - 3;
 
+        const bool rev = REV != (bool)(a.zigzag & seg & 1);  // wave-uniform
+        auto act = [&](int k) { return rev ? x0 + x1 - 1 - k : k; };  // lattice plane of marching index k
         auto load_plane = [&](const double2* buf, bool nt, int k, bool wanted, double2 out[4]) {
+            k = act(k);
             if (wanted && k >= 0 && k < a.lx) {
                 const size_t site = (size_t)k * a.plane + p;
 #pragma unroll
@@ -147,6 +188,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep(SweepArgs a) {
         };
         auto load_ids = [&](int k) {
             uint2 w = make_uint2(0xFFFFFFFFu, 0xFFu);
+            k = act(k);
             if (does1 && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + p];
             return w;
         };
@@ -206,19 +248,20 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep(SweepArgs a) {
             double2 new1[4];
 #pragma unroll
             for (int al = 0; al < 4; ++al) new1[al] = zero;
-            const bool plane_ok = k >= 0 && k < a.lx;
+            const bool plane_ok = act(k) >= 0 && act(k) < a.lx;
             if (does1 && plane_ok) {
                 double2 acc[4];
 #pragma unroll
                 for (int al = 0; al < 4; ++al) acc[al] = zero;
-                apply(ids_0, cn_m, row_n, cn_0, cn_p, acc);
+                if (rev) apply(ids_0, cn_p, row_n, cn_0, cn_m, acc);
+                else apply(ids_0, cn_m, row_n, cn_0, cn_p, acc);
 #pragma unroll
                 for (int al = 0; al < 4; ++al) {
                     new1[al].x = fma(a.coef1, acc[al].x, -pv[al].x);
                     new1[al].y = fma(a.coef1, acc[al].y, -pv[al].y);
                 }
                 if (owned && k >= x0 && k < x1) {
-                    const size_t site = (size_t)k * a.plane + p;
+                    const size_t site = (size_t)act(k) * a.plane + p;
 #pragma unroll
                     for (int al = 0; al < 4; ++al) {
                         if (nt_store) store_stream(a.out1 + vslot(al, site, r, nb, RL), new1[al]);
@@ -234,8 +277,9 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep(SweepArgs a) {
                     double2 acc[4];
 #pragma unroll
                     for (int al = 0; al < 4; ++al) acc[al] = zero;
-                    apply(ids_m, c1_m, row_1, c1_0, new1, acc);
-                    const size_t site = (size_t)(k - 1) * a.plane + p;
+                    if (rev) apply(ids_m, new1, row_1, c1_0, c1_m, acc);
+                    else apply(ids_m, c1_m, row_1, c1_0, new1, acc);
+                    const size_t site = (size_t)act(k - 1) * a.plane + p;
 #pragma unroll
                     for (int al = 0; al < 4; ++al) {
                         double2 nx;
@@ -271,10 +315,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep(SweepArgs a) {
     }
 
     __syncthreads();  // table / hand-over rows are done with: the reductions reuse the front of the LDS
-    reduce_dots<Mode, RL>(dot1, reinterpret_cast<double*>(lds), a.partial1, lane, wave);
+    sweep_reduce_dots<Mode, RL, kSweepWaves>(dot1, reinterpret_cast<double*>(lds), a.partial1, lane, wave);
     if (a.two) {
         __syncthreads();
-        reduce_dots<Mode, RL>(dot2, reinterpret_cast<double*>(lds), a.partial2, lane, wave);
+        sweep_reduce_dots<Mode, RL, kSweepWaves>(dot2, reinterpret_cast<double*>(lds), a.partial2, lane, wave);
     }
 }
 

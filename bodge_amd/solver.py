@@ -9,7 +9,6 @@ from __future__ import annotations
 
 import ctypes as C
 import os
-import time
 
 import numpy as np
 
@@ -319,7 +318,7 @@ class _StdoutToStderr:
 
 
 class Communicator:
-    """One RCCL rank.  The 128-byte unique id travels through a rendezvous file."""
+    """One RCCL rank.  The 128-byte unique id travels through `bodge_amd.rendezvous` (TCP)."""
 
     def __init__(self, rank: int, n_ranks: int, device: int, unique_id: bytes):
         lib = backend.load()
@@ -337,46 +336,50 @@ class Communicator:
             backend.check(backend.load().bdg_comm_unique_id(buf))
         return bytes(buf)
 
+    _sequence = 0  # communicators created by this process through `from_environment`
+
     @classmethod
     def from_environment(cls, timeout: float = 300.0) -> "Communicator | None":
         """Build the communicator of a `torch.distributed.run`-style launch.
 
-        Uses RANK / WORLD_SIZE / LOCAL_RANK / MASTER_PORT.  Rank 0 publishes the
-        RCCL unique id in a file named after the launcher's pid and the master
-        port (both shared by all ranks of one launch); the others poll for it.
-        Returns None for a single-process run.
+        Uses RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT.  Rank 0 publishes the
+        RCCL unique id through the launch's TCP rendezvous (`bodge_amd.rendezvous`: no files, a
+        per-launch nonce on every message); the others block on it.  Returns None for a
+        single-process run.
         """
         world = int(os.environ.get("WORLD_SIZE", "1"))
         if world <= 1 and os.environ.get("BODGE_AMD_FORCE_COMM") != "1":
             return None  # (the override builds a one-rank communicator: exercises the RCCL path on one GPU)
         rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", rank))
-        tag = f"{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}"
-        path = os.path.join(os.environ.get("BODGE_AMD_RDZV_DIR", "/tmp"), f"bodge_amd_rccl_{tag}.id")
-        if rank == 0:
+        if world <= 1:
             uid = cls.new_unique_id()
-            tmp = f"{path}.{os.getpid()}.tmp"
-            with open(tmp, "wb") as fh:
-                fh.write(uid)
-            os.replace(tmp, path)
         else:
-            deadline = time.time() + timeout
-            while not (os.path.exists(path) and os.path.getsize(path) == 128):
-                if time.time() > deadline:
-                    raise RuntimeError(f"rank {rank}: timed out waiting for the RCCL id at {path}")
-                time.sleep(0.05)
-            with open(path, "rb") as fh:
-                uid = fh.read()
+            from .rendezvous import store_from_environment
+
+            store = store_from_environment(timeout)
+            key = f"rccl_unique_id/{cls._sequence}"
+            cls._sequence += 1
+            if rank == 0:
+                uid = cls.new_unique_id()
+                store.set(key, uid)
+            else:
+                uid = store.get(key, timeout)
+            if len(uid) != 128:
+                raise RuntimeError(f"rank {rank}: rendezvous returned {len(uid)} bytes instead of an RCCL id")
         # one process per GPU; more ranks than GPUs wrap around and RCCL reports the duplicate
         count = backend.device_count()
         comm = cls(rank, world, local % count if count > 0 else local, uid)
         comm.barrier()
-        if rank == 0:
-            try:
-                os.unlink(path)
-            except OSError:
-                pass
         return comm
+
+    def info(self) -> dict:
+        """{'n_ranks': ncclCommCount, 'rank', 'device', 'pci_bus_id'} as the library and RCCL report them."""
+        n_ranks, rank, device = C.c_int32(0), C.c_int32(0), C.c_int32(0)
+        bus = C.create_string_buffer(32)
+        backend.check(self._lib.bdg_comm_info(self._handle, C.byref(n_ranks), C.byref(rank), C.byref(device), bus))
+        return {"n_ranks": n_ranks.value, "rank": rank.value, "device": device.value,
+                "pci_bus_id": bus.value.decode("ascii", "replace")}
 
     def allreduce_sum(self, values: np.ndarray) -> np.ndarray:
         out = np.ascontiguousarray(values, dtype=np.float64).copy()

@@ -204,6 +204,9 @@ int bdg_set_lanes_per_row(bdg_system* sys, int32_t lanes);
 int bdg_comm_unique_id(uint8_t id_out[128]);
 int bdg_comm_init(int device, const uint8_t id[128], int32_t n_ranks, int32_t rank,
                   bdg_comm** out);
+/* What the communicator really spans: ncclCommCount, this rank, its device ordinal and that
+ * device's PCI bus id (e.g. "0000:75:00.0") - for records that must show N distinct GPUs. */
+int bdg_comm_info(bdg_comm* comm, int32_t* n_ranks, int32_t* rank, int32_t* device, char pci_bus_id[32]);
 int bdg_comm_allreduce_sum(bdg_comm* comm, double* buf, int64_t count);
 int bdg_comm_allreduce_max(bdg_comm* comm, double* buf, int64_t count);
 int bdg_comm_destroy(bdg_comm* comm);

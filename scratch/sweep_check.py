@@ -95,9 +95,11 @@ with DeviceSolver(indptr, indices, data) as dev:
         print(f"  {label:40s} {per_launch:7.1f} us/launch  {p['bytes_per_launch'] / per_launch / 1e6:6.2f} TB/s  {steps_s / 1e3:6.1f} k vector-steps/s (kernel time)", flush=True)
 
     timeit("one-step dictionary kernel", BODGE_AMD_SWEEP=0)
-    for stream in range(8):
-        timeit(f"sweep stream={stream}", BODGE_AMD_SWEEP_STREAM=stream)
-    for segs in (8, 12, 16, 20, 24, 32, 48):
-        timeit(f"sweep segments={segs}", BODGE_AMD_SWEEP_SEGMENTS=segs)
-    timeit("sweep 1 workgroup/CU", BODGE_AMD_BLOCKS_PER_CU=1)
+    for alt in (0, 1):
+        for stream in range(8):
+            timeit(f"sweep alternate={alt} stream={stream}", BODGE_AMD_SWEEP_STREAM=stream, BODGE_AMD_ALTERNATE=alt)
+    if "--segments" in sys.argv:
+        for segs in (8, 12, 16, 20, 24, 32, 48):
+            timeit(f"sweep segments={segs}", BODGE_AMD_SWEEP_SEGMENTS=segs)
+        timeit("sweep 1 workgroup/CU", BODGE_AMD_BLOCKS_PER_CU=1)
 print("ALL OK" if ok else "FAILED")

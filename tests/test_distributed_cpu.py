@@ -109,14 +109,15 @@ def test_rccl_rendezvous_under_torchrun(tmp_path):
     assert [r["rank"] for r in ranks] == [0, 1, 2, 3] and all(r["world"] == 4 and r["len"] == 128 for r in ranks)
     assert [r["device"] for r in ranks] == [0, 1, 2, 3]  # LOCAL_RANK -> device
     assert len({r["uid"] for r in ranks}) == 1, "ranks disagree on the unique id"
-    assert len({r["ppid"] for r in ranks}) == 1  # the rendezvous file name relies on a common parent
-    assert not [f for f in os.listdir(tmp_path) if f.endswith(".id")], "rendezvous file was not cleaned up"
+    assert len({r["ppid"] for r in ranks}) == 1  # the launch nonce relies on a common parent on one node
+    assert sorted(os.listdir(tmp_path)) == sorted([f"arrived{r}" for r in range(4)] + [f"rank{r}.json" for r in range(4)]), \
+        "the hand-off must not leave files behind (it goes over TCP)"
 
 
 @pytest.mark.timeout(600)
-def test_bench_falls_back_to_gloo_when_rccl_is_unavailable(tmp_path):
-    """bench.py's safety net: if the RCCL communicator cannot be built, the ranks agree on it and
-    do the moment sum / timing max over gloo instead of dying (the JSON line then says so)."""
+def test_bench_host_fallback_when_rccl_is_unavailable_and_allowed(tmp_path):
+    """bench.py --allow-gloo: if the RCCL communicator cannot be built, the ranks agree on it and
+    do the moment sum / timing max on the host instead of dying (the JSON line then says so)."""
     cmd = [
         sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
@@ -128,4 +129,18 @@ def test_bench_falls_back_to_gloo_when_rccl_is_unavailable(tmp_path):
     for r in range(2):
         rec = json.loads((tmp_path / f"rank{r}.json").read_text())
         assert rec["sum"] == [1.0, 3.0, 5.0, 7.0] and rec["max"] == [1.0]
-        assert rec["description"].startswith("gloo fallback") and "simulated" in rec["description"]
+        assert rec["description"].startswith("host fallback") and "simulated" in rec["description"]
+
+
+@pytest.mark.timeout(600)
+def test_bench_refuses_to_report_without_rccl(tmp_path):
+    """Without --allow-gloo a failed RCCL initialisation ends the launch with a non-zero exit code
+    and no JSON line: a scaling number that did not go through RCCL can never be recorded."""
+    cmd = [
+        sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
+        "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+        os.path.join(ROOT, "tests", "_fallback_worker.py"), str(tmp_path), "strict",
+    ]
+    proc = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ), capture_output=True, text=True, timeout=540)
+    assert proc.returncode != 0
+    assert "could not be created on every rank" in proc.stderr and not os.listdir(tmp_path)

@@ -64,6 +64,7 @@ def test_size_independent_properties(big):
     steps = 24
     (d, e), perf = _with_env(solver, {}, scale, steps, 8, seed=0)
     assert perf["dict_blocks"] > 0 and perf["real_arithmetic"] == 1 and perf["ph_packed"] == 1
+    assert perf["steps_per_launch"] == 2  # the sweep form is the default at this size
     # |v|^2 = 4N exactly for ±1 vectors, and <t_n|t_n> <= |v|^2 because |T_n| <= 1 on the spectrum
     assert np.array_equal(d[0], np.full(8, float(n)))
     assert np.all(d <= n * (1 + 1e-12)) and np.all(d > 0)
@@ -76,11 +77,14 @@ def test_size_independent_properties(big):
     assert np.allclose(np.hstack([da, db]), d, rtol=1e-13) and np.allclose(np.hstack([ea, eb]), e, rtol=1e-12, atol=1e-6)
     # every kernel form computes the same numbers
     for env, check in [
+        ({"BODGE_AMD_SWEEP": "0"}, lambda p: p["steps_per_launch"] == 1 and p["dict_blocks"] > 0),
+        ({"BODGE_AMD_ALTERNATE": "0", "BODGE_AMD_SWEEP_ZIGZAG": "0"}, lambda p: p["steps_per_launch"] == 2),
+        ({"BODGE_AMD_SWEEP_SEGMENTS": "7"}, lambda p: p["steps_per_launch"] == 2),
         ({"BODGE_AMD_DICT": "0"}, lambda p: p["dict_blocks"] == 0 and p["pipelined"] == 1),
         ({"BODGE_AMD_DICT": "0", "BODGE_AMD_PH": "0"}, lambda p: p["ph_packed"] == 0),
         ({"BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"}, lambda p: p["real_arithmetic"] == 0),
         ({"BODGE_AMD_DICT": "0", "BODGE_AMD_KERNEL": "generic"}, lambda p: p["pipelined"] == 0),
-        ({"BODGE_AMD_L2_BUDGET": "65536"}, lambda p: 0 < p["strip_rows"] < 1000),
+        ({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_L2_BUDGET": "65536"}, lambda p: 0 < p["strip_rows"] < 1000),
     ]:
         (dx, ex), perf = _with_env(solver, env, scale, steps, 8, seed=0)
         assert check(perf), (env, perf)
@@ -105,9 +109,14 @@ def test_config3_1000x1000_512_moments_full_length_against_cpu_on_the_same_vecto
     cheb_c.set_threads(min(16, os.cpu_count() or 1))
     d_ref, e_ref = cheb_c.recurrence_dots(bsr, scale, moments, start, real=True)
     assert np.allclose(d_ref[:8, :2], d2, rtol=0, atol=1e-12 * n) and np.allclose(e_ref[:8, :2], e2, rtol=0, atol=1e-12 * n)
+    # default route at this size: two recurrence steps per sweep (sweep.hpp) ...
     (d, e), perf = _with_env(solver, {}, scale, moments // 2, vectors, seed=0)
-    assert perf["launches"] == moments // 2
+    assert perf["steps_per_launch"] == 2 and perf["launches"] == moments // 4
     assert np.abs(d - d_ref).max() <= 1e-12 * n and np.abs(e - e_ref).max() <= 1e-12 * n
+    # ... and the one-step dictionary kernel, same vectors, full length as well
+    (d1, e1), perf1 = _with_env(solver, {"BODGE_AMD_SWEEP": "0"}, scale, moments // 2, vectors, seed=0)
+    assert perf1["steps_per_launch"] == 1 and perf1["launches"] == moments // 2 and perf1["dict_blocks"] > 0
+    assert np.abs(d1 - d_ref).max() <= 1e-12 * n and np.abs(e1 - e_ref).max() <= 1e-12 * n
     f_ref = chebyshev.free_energy_series(chebyshev.dots_to_moments(d_ref, e_ref).mean(axis=1), scale, temperature)
     f_gpu = chebyshev.free_energy_series(solver.moments_random(scale, moments, vectors, seed=0) / vectors, scale, temperature)
     assert abs(f_gpu - f_ref) <= 1e-10 * abs(f_ref)
@@ -117,7 +126,7 @@ def test_config3_1000x1000_512_moments_full_length_against_cpu_on_the_same_vecto
     assert abs(f_api - f_ref) <= 1e-10 * abs(f_ref)
     # streamed (non-dictionary) complex128 kernels, the reference's own dtype: same vectors, 64 launches
     (dc, ec), perf_c = _with_env(solver, {"BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"}, scale, 64, vectors, seed=0)
-    assert perf_c["real_arithmetic"] == 0 and perf_c["dict_blocks"] == 0
+    assert perf_c["real_arithmetic"] == 0 and perf_c["dict_blocks"] == 0 and perf_c["steps_per_launch"] == 1
     assert np.abs(dc - d_ref[:64]).max() <= 1e-12 * n and np.abs(ec - e_ref[:64]).max() <= 1e-12 * n
 
 

@@ -210,6 +210,91 @@ def test_strip_ordered_tiles_do_not_change_results(api, solver_cls, monkeypatch,
         assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * mu0)
 
 
+def _sweep_system(api, shape, kind):
+    """2-D lattice models for the two-steps-per-sweep kernel: uniform, position dependent, complex,
+    d-wave bonds, and one with periodic wrap blocks (not a stencil: must fall back)."""
+    lattice = api.CubicLattice(shape)
+    system = api.Hamiltonian(lattice)
+    with system as (H, Δ):
+        if kind == "swave":
+            H.set_sites(3.0 * api.σ0 - 0.05 * api.σ3)
+            Δ.set_sites(-0.1 * api.jσ2)
+            H.set_bonds(-1.0 * api.σ0)
+        elif kind == "peierls":
+            pairs = lattice.bond_array(axis=0, coords=True)
+            phase = np.where(pairs[:, 1, 0] > pairs[:, 0, 0], np.exp(0.3j), np.exp(-0.3j))
+            H.set_sites(3.0 * api.σ0 - 0.05 * api.σ3)
+            Δ.set_sites(-0.1 * api.jσ2)
+            H.set_bonds(-phase[:, None, None] * api.σ0, axis=0)
+            H.set_bonds(-1.0 * api.σ0, axis=1 if shape[1] > 1 else 2)
+        elif kind == "dwave":
+            pairs = lattice.bond_array(coords=True)
+            H.set_sites(3.0 * api.σ0)
+            H.set_bonds(-1.0 * api.σ0)
+            Δ.set_bonds(-0.1 * api.dwave()(pairs[:, 0], pairs[:, 1]))
+        elif kind == "junction":  # S / F / S along x (pattern of ref tests/test_hamiltonian.py:431-443)
+            x = np.arange(lattice.size) // (shape[1] * shape[2])
+            middle = ((x > shape[0] // 3) & (x < 2 * shape[0] // 3))[:, None, None]
+            H.set_sites(np.where(middle, 0.5 * api.σ0 + 1.5 * api.σ3, -0.5 * api.σ0))
+            Δ.set_sites(np.where(middle, 0 * api.jσ2, -1.0 * api.jσ2))
+            H.set_bonds(-1.0 * api.σ0)
+        elif kind == "periodic":
+            H.set_sites(3.0 * api.σ0)
+            Δ.set_sites(-0.1 * api.jσ2)
+            H.set_bonds(-1.0 * api.σ0)
+            H.set_edges(-1.0 * api.σ0)
+        else:
+            raise ValueError(kind)
+    return system
+
+
+@pytest.mark.parametrize("shape,kind,vec_kind", [
+    ((64, 48, 1), "swave", cheb_ref.VEC_RADEMACHER),     # 4 full windows of 12
+    ((40, 100, 1), "peierls", cheb_ref.VEC_Z4),          # complex blocks and vectors, ragged last window
+    ((33, 61, 1), "dwave", cheb_ref.VEC_RADEMACHER),     # pairing on the bonds, odd sizes
+    ((48, 50, 1), "junction", cheb_ref.VEC_RADEMACHER),  # position-dependent blocks
+    ((16, 1, 40), "swave", cheb_ref.VEC_RADEMACHER),     # (Lx, 1, Lz): the plane is a z-line
+    ((9, 25, 1), "swave", cheb_ref.VEC_Z4),              # complex vectors on a real matrix, one short segment
+    ((30, 30, 1), "periodic", cheb_ref.VEC_RADEMACHER),  # wrap blocks: not a stencil, one-step kernels must run
+    ((12, 30, 4), "swave", cheb_ref.VEC_RADEMACHER),     # 3-D: +-Lz neighbours inside the plane, falls back
+])
+def test_two_steps_per_sweep_kernel_matches_oracle_and_one_step_kernels(api, solver_cls, monkeypatch, block_storage,
+                                                                        shape, kind, vec_kind):
+    """K7 (sweep.hpp) forced on small lattices: every d_n, e_n against the CPU oracle and against the
+    one-step kernels on the same vectors, for even and odd step counts (the odd tail runs one step
+    alone), full and partial lane groups, both marching directions, zigzag on and off.  Matrices
+    that are not a 5-point lattice stencil must take the one-step kernels without being told."""
+    system = _sweep_system(api, shape, kind)
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    n = bsr.shape[0]
+    is_stencil = kind != "periodic" and not (shape[1] > 1 and shape[2] > 1)
+    per_group = 8 if (vec_kind == cheb_ref.VEC_RADEMACHER and kind != "peierls") else 4
+    with solver_cls.from_hamiltonian(system) as dev:
+        for steps, vectors, extra in [(8, per_group, {}), (7, 3, {}), (5, per_group + 3, {"BODGE_AMD_SWEEP_ZIGZAG": "0"}),
+                                      (6, 2, {"BODGE_AMD_ALTERNATE": "0", "BODGE_AMD_SWEEP_SEGMENTS": "3"})]:
+            ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 5, range(vectors), vec_kind))
+            monkeypatch.setenv("BODGE_AMD_SWEEP", "0")
+            one = dev.dots_random(scale, steps, vectors, seed=5, kind=vec_kind)
+            assert dev.perf()["steps_per_launch"] == 1
+            monkeypatch.setenv("BODGE_AMD_SWEEP", "1")
+            for key, value in extra.items():
+                monkeypatch.setenv(key, value)
+            got = dev.dots_random(scale, steps, vectors, seed=5, kind=vec_kind)
+            perf = dev.perf()
+            again = dev.dots_random(scale, steps, vectors, seed=5, kind=vec_kind)
+            for key in extra:
+                monkeypatch.delenv(key)
+            swept = is_stencil and block_storage == "dictionary"  # (the sweep form reads the block dictionary)
+            assert (perf["steps_per_launch"] == 2) == swept, perf
+            if swept:
+                batches = -(-vectors // per_group)
+                assert perf["launches"] == batches * ((steps + 1) // 2)
+            assert np.array_equal(got[0], again[0]) and np.array_equal(got[1], again[1])  # bit reproducible
+            for other in (ref, one):
+                assert np.abs(got[0] - other[0]).max() <= 1e-12 * n and np.abs(got[1] - other[1]).max() <= 1e-12 * n
+
+
 @pytest.mark.parametrize("name,n_vectors,kind", [
     ("random357", 6, cheb_ref.VEC_Z4),          # complex blocks, periodic
     ("complex235", 3, cheb_ref.VEC_RADEMACHER),  # complex H with real start vectors

@@ -40,3 +40,13 @@ def test_headline_kernels_do_not_spill_and_keep_their_occupancy(resources):
     for lanes in (4, 8, 16, 32, 64):
         row = _row(resources, f"cheb_step<bdg::ComplexMode, {lanes}, false>")
         assert row["scratch"] == 0 and row["occupancy"] >= 4, (lanes, row)
+
+
+@pytest.mark.timeout(600)
+def test_sweep_kernels_fit_two_waves_per_simd_without_spilling(resources):
+    """K7 keeps five site arrays and a plane of prefetch in registers: it must stay within the
+    256-VGPR step (two waves per SIMD) and must not spill, in every arithmetic mode and direction."""
+    for mode in ("RealPHMode", "ComplexPHMode", "RealMode", "ComplexMode"):
+        for reverse in ("false", "true"):
+            row = _row(resources, f"cheb_sweep<bdg::{mode}, {reverse}>")
+            assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, reverse, row)

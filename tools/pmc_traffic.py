@@ -24,6 +24,9 @@ import re
 
 
 def kernel_key(name: str) -> str:
+    m = re.search(r"cheb_sweep<bdg::(\w+), (?:true|false)>", name)  # both marching directions count as one kernel
+    if m:
+        return f"cheb_sweep<{m.group(1)}>"
     m = re.search(r"(cheb_step\w*)<bdg::(\w+), (\d+)", name)
     return f"{m.group(1)}<{m.group(2)},{m.group(3)}>" if m else ""
 
