@@ -687,7 +687,6 @@ void warm_page_cache(const char* path) {
 struct SolverPrefetch {
     std::mutex lock;
     std::condition_variable changed;
-    std::thread thread;
     bool started = false, done = false, reported = false;
     double seconds = 0.0;
     void start() {
@@ -698,7 +697,9 @@ struct SolverPrefetch {
             done = true;
             return;
         }
-        thread = std::thread([this] {
+        // detached: a process that ends before the read has finished must not wait for it
+        // (the object itself is never destroyed, see g_solver_prefetch)
+        std::thread([this] {
             const auto t0 = std::chrono::steady_clock::now();
             warm_page_cache("/opt/rocm/lib/librocblas.so");
             warm_page_cache("/opt/rocm/lib/librocsolver.so");
@@ -706,7 +707,7 @@ struct SolverPrefetch {
             seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             done = true;
             changed.notify_all();
-        });
+        }).detach();
     }
     // true once the files have been read; waits at most `timeout_s` (negative: no limit)
     bool wait(double timeout_s) {
@@ -720,11 +721,8 @@ struct SolverPrefetch {
         }
         return done;
     }
-    ~SolverPrefetch() {
-        if (thread.joinable()) thread.join();
-    }
 };
-SolverPrefetch g_solver_prefetch;
+SolverPrefetch& g_solver_prefetch = *new SolverPrefetch();  // deliberately immortal: outlives every exit path
 
 int load_solver(SolverApi** out) {
     static SolverApi api;
