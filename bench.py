@@ -301,6 +301,8 @@ def main():
         mode = f"{'Real' if pf['real_arithmetic'] else 'Complex'}{'PH' if pf['ph_packed'] else ''}Mode"
         if pf["steps_per_launch"] == 2:
             return f"cheb_sweep<{mode}>"
+        if pf["rolling"]:
+            return f"cheb_roll3<{mode}>"
         family = "cheb_step_dict" if pf["dict_blocks"] else "cheb_step_pipelined" if pf["pipelined"] else "cheb_step"
         return f"{family}<{mode},{pf['lanes_per_row']}>"
 
@@ -327,7 +329,7 @@ def main():
             "traffic": measured_traffic(kernel_label(pf), shape, r_local),
         }
 
-    one_step_pass = alternative({"BODGE_AMD_SWEEP": "0"}) if perf["steps_per_launch"] == 2 else None
+    one_step_pass = alternative({"BODGE_AMD_SWEEP": "0"}) if perf["steps_per_launch"] == 2 or perf["rolling"] else None
     streamed_pass = alternative({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0"}) if perf["dict_blocks"] else None
     complex_pass = (alternative({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"})
                     if perf["real_arithmetic"] else None)
@@ -385,6 +387,7 @@ def main():
             "kernel": kernel_name,
             "launch_ms": launch_ms,
             "steps_per_launch": perf["steps_per_launch"],
+            "x_neighbours_in_registers": bool(perf["steps_per_launch"] == 2 or perf["rolling"]),
             "launches": perf["launches"],
             "bytes_per_launch": perf["bytes_per_launch"],
             "grid": perf["grid"],

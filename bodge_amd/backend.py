@@ -43,6 +43,8 @@ class Perf(C.Structure):
         ("ph_packed", C.c_int32),
         ("dict_blocks", C.c_int32),
         ("steps_per_launch", C.c_int32),
+        ("rolling", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 

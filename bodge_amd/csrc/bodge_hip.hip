@@ -137,7 +137,8 @@ struct bdg_system {
     DeviceBuffer<double2> dict_table[4];  // packed per storage mode, built on first use
     DeviceBuffer<double2> vec_a, vec_b;
     DeviceBuffer<double2> vec_c, vec_d;  // two-steps-per-sweep form: t_{n+1}, t_{n+2} are written out of place
-    // lattice-stencil form of the matrix (sweep.hpp): 0 = not examined, 1 = table built, -1 = not a stencil
+    // lattice-stencil form of the matrix (sweep.hpp): 0 = not examined, 1 = 5-point table built (planes
+    // are lines), 2 = 7-point table built (3-D), -1 = not a stencil
     DeviceBuffer<uint2> stencil;
     int stencil_state = 0;
     DeviceBuffer<double> partial, dots;
@@ -526,6 +527,25 @@ SweepKernel sweep_kernel(const ModeInfo& mode, bool reverse) {
     return reverse ? bdg::cheb_sweep<ComplexMode, true> : bdg::cheb_sweep<ComplexMode, false>;
 }
 
+// Segments along x for the marching kernels.  The waves of a launch take the (segment, window)
+// units in rounds, so the launch lasts  ceil(units / waves) x (planes per segment + the planes a
+// unit recomputes at its ends);  fewer, longer segments also re-read less.  Smallest count within
+// 3 % of the best duration.
+int choose_segments(int n_cols, int lx, int waves, int extra_planes, int min_planes) {
+    int best = 1;
+    double best_cost = 0.0;
+    for (int segs = 1; segs <= std::max(1, lx / min_planes); ++segs) {
+        const int64_t units = (int64_t)n_cols * segs;
+        const double rounds = (double)((units + waves - 1) / waves);
+        const double cost = rounds * ((double)((lx + segs - 1) / segs) + extra_planes);
+        if (segs == 1 || cost < 0.97 * best_cost) {
+            best = segs;
+            best_cost = cost;
+        }
+    }
+    return best;
+}
+
 struct SweepPlan {
     SweepKernel kernel = nullptr, kernel_reverse = nullptr;
     int grid = 0;
@@ -538,24 +558,32 @@ struct SweepPlan {
 // are Infinity-Cache resident anyway.  BODGE_AMD_SWEEP=0 never, =1 whenever the matrix qualifies.
 constexpr int64_t kSweepMinSites = 600000;
 
-// Stencil table of the matrix (built once per lattice shape); *ok = it is a 5-point lattice stencil.
-int ensure_stencil(bdg_system* sys, bool* ok) {
-    *ok = false;
+// Stencil table of the matrix (built once per lattice shape).  *kind = 1: 5-point stencil whose
+// planes are lines (2-D lattice: the two-steps-per-sweep kernel applies), 2: 7-point stencil of a
+// 3-D lattice (one-step kernel with the x-neighbours in registers), 0: neither.
+int ensure_stencil(bdg_system* sys, int* kind) {
+    *kind = 0;
     const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
     if (sys->stencil_state == 0) {
         sys->stencil_state = -1;
         const bool shaped = plane >= 2 * bdg::kSweepOwned && sys->shape[0] >= 8 &&
                             (int64_t)sys->shape[0] * plane == sys->nb;
+        const bool three_d = sys->shape[1] > 1 && sys->shape[2] > 1;
         if (shaped && sys->ncols == sys->nb && sys->n_unique > 0 && sys->n_unique < (int)bdg::kNoBlock &&
-            sys->max_row_blocks <= 5 && sys->nnzb > 0) {
+            sys->max_row_blocks <= (three_d ? 7 : 5) && sys->nnzb > 0) {
             if (int rc = sys->stencil.reserve((size_t)sys->nb)) return rc;
             DeviceBuffer<int> bad;
             if (int rc = bad.reserve(1)) return rc;
             int host_bad = 1;
             auto body = [&]() -> int {
                 HIP_TRY(hipMemsetAsync(bad.ptr, 0, sizeof(int), sys->stream));
-                bdg::build_stencil<<<(unsigned)std::min<int64_t>(4096, (sys->nb + 255) / 256), 256, 0, sys->stream>>>(
-                    sys->indptr.ptr, sys->dict_ids.ptr, (int)sys->nb, (int)plane, sys->stencil.ptr, bad.ptr);
+                const unsigned grid = (unsigned)std::min<int64_t>(4096, (sys->nb + 255) / 256);
+                if (three_d)
+                    bdg::build_stencil3<<<grid, 256, 0, sys->stream>>>(sys->indptr.ptr, sys->dict_ids.ptr, (int)sys->nb,
+                                                                        (int)plane, sys->shape[2], sys->stencil.ptr, bad.ptr);
+                else
+                    bdg::build_stencil<<<grid, 256, 0, sys->stream>>>(sys->indptr.ptr, sys->dict_ids.ptr, (int)sys->nb,
+                                                                       (int)plane, sys->stencil.ptr, bad.ptr);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(&host_bad, bad.ptr, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
                 HIP_TRY(hipStreamSynchronize(sys->stream));
@@ -564,24 +592,24 @@ int ensure_stencil(bdg_system* sys, bool* ok) {
             const int rc = body();
             bad.release();
             if (rc) return rc;
-            if (host_bad == 0) sys->stencil_state = 1;
+            if (host_bad == 0) sys->stencil_state = three_d ? 2 : 1;
             else sys->stencil.release();
         }
     }
-    *ok = sys->stencil_state == 1;
+    *kind = std::max(0, sys->stencil_state);
     return BDG_OK;
 }
 
-// Should this batch run the sweep form?  (whole square matrix, random start vectors - unit
-// vectors use the band-limited one-step sweeps -, no per-column scalars, one lane group)
-int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, bool* wanted) {
-    *wanted = false;
+// Should this batch run a stencil form, and which (see ensure_stencil)?  Whole square matrix,
+// random start vectors (unit vectors use the band-limited one-step sweeps), no per-column scalars.
+int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, int* kind) {
+    *kind = 0;
     const char* env = getenv("BODGE_AMD_SWEEP");
     if ((env && env[0] == '0') || !random_start || col_scalars || !sys->peers.empty()) return BDG_OK;
     if (!(env && env[0] == '1') && sys->nb < kSweepMinSites) return BDG_OK;
     const char* dict_env = getenv("BODGE_AMD_DICT");
     if (dict_env && dict_env[0] == '0') return BDG_OK;
-    return ensure_stencil(sys, wanted);
+    return ensure_stencil(sys, kind);
 }
 
 int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, SweepPlan* plan) {
@@ -612,7 +640,7 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, SweepPlan* plan) {
     a.n_cols = (int)((plane + bdg::kSweepOwned - 1) / bdg::kSweepOwned);
     // one unit (segment x window) per resident wave, segments of at least 8 planes
     const int waves = per_cu * sys->num_cus * bdg::kSweepWaves;
-    int n_segs = (waves + a.n_cols / 2) / a.n_cols;
+    int n_segs = choose_segments(a.n_cols, a.lx, waves, 4, 8);
     if (const char* env = getenv("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
     a.n_segs = std::max(1, std::min(n_segs, a.lx / 8));
     a.zigzag = 1;
@@ -629,6 +657,63 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, SweepPlan* plan) {
 double sweep_bytes(const bdg_system* sys, const ModeInfo& mode) {
     return 8.0 * (double)sys->nb + (mode.block_bytes - 4.0) * sys->n_unique +
            4.0 * (4.0 * bdg::kSweepLanes * sizeof(double2)) * (double)sys->nb;
+}
+
+// ---- 3-D: one step per launch with the x-neighbours in registers (cheb_roll3)
+using RollKernel = void (*)(bdg::RollArgs);
+
+RollKernel roll_kernel(const ModeInfo& mode) {
+    switch (mode.id) {
+        case 1: return bdg::cheb_roll3<RealMode>;
+        case 2: return bdg::cheb_roll3<ComplexPHMode>;
+        case 3: return bdg::cheb_roll3<RealPHMode>;
+    }
+    return bdg::cheb_roll3<ComplexMode>;
+}
+
+struct RollPlan {
+    RollKernel kernel = nullptr;
+    int grid = 0;
+    size_t lds_bytes = 0;
+    bdg::RollArgs args{};
+};
+
+int make_roll_plan(bdg_system* sys, const ModeInfo& mode, RollPlan* plan) {
+    plan->kernel = roll_kernel(mode);
+    const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
+    if (table > kDictLdsLimit) return fail(BDG_EINVAL, "block table too large for the rolling kernel");
+    plan->lds_bytes = table + (size_t)bdg::kWavesPerBlock * bdg::kWave * 4 * sizeof(double2);
+    int per_cu = 0;
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(plan->kernel),
+                                                         bdg::kBlockThreads, plan->lds_bytes));
+    per_cu = std::max(1, std::min(per_cu, 2));
+    if (const char* cap = getenv("BODGE_AMD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(cap));
+    const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
+    bdg::RollArgs& a = plan->args;
+    a = bdg::RollArgs{};
+    a.stencil = sys->stencil.ptr;
+    if (int rc = ensure_dict_table(sys, mode, &a.dict_table)) return rc;
+    a.n_unique = sys->n_unique;
+    a.nb = (int)sys->nb;
+    a.plane = (int)plane;
+    a.lz = sys->shape[2];
+    a.lx = sys->shape[0];
+    a.n_cols = (int)((plane + bdg::kRollOwned - 1) / bdg::kRollOwned);
+    const int waves = per_cu * sys->num_cus * bdg::kWavesPerBlock;
+    int n_segs = choose_segments(a.n_cols, a.lx, waves, 2, 4);
+    if (const char* env = getenv("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
+    a.n_segs = std::max(1, std::min(n_segs, a.lx / 4));
+    const int64_t units = (int64_t)a.n_cols * a.n_segs;
+    const int grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus,
+                                            (units + bdg::kWavesPerBlock - 1) / bdg::kWavesPerBlock);
+    plan->grid = std::max(8, (grid + 7) / 8 * 8);
+    return BDG_OK;
+}
+
+// Algorithmic bytes of one launch of the rolling kernel: stencil word + three passes per site.
+double roll_bytes(const bdg_system* sys, const ModeInfo& mode) {
+    return 8.0 * (double)sys->nb + (mode.block_bytes - 4.0) * sys->n_unique +
+           3.0 * (4.0 * bdg::kSweepLanes * sizeof(double2)) * (double)sys->nb;
 }
 
 enum class StartKind { Random, Unit };
@@ -849,8 +934,9 @@ struct Batch {
     float kernel_ms = 0.f;
     int n_chunks = 0;
     // two-steps-per-sweep form
-    bool sweep = false;
+    bool sweep = false, roll = false;
     SweepPlan splan;
+    RollPlan rplan;
     double2 *spare1 = nullptr, *spare2 = nullptr;
     int launch_grid = 0;   // workgroups whose dot partials one recurrence step leaves behind
     int n_launches = 0;
@@ -880,13 +966,18 @@ struct Batch {
         rv = rl * per_lane;  // vector columns in the buffers
         if (int rc = make_plan(sys, rl, mode, &plan, col_scalars)) return rc;
         if (int rc = matrix_args(sys, plan, &args)) return rc;
-        sweep = false;
+        sweep = roll = false;
         if (rl == bdg::kSweepLanes && plan.dictionary && sys->lanes_override == 0) {
-            if (int rc = sweep_wanted(sys, start.kind == StartKind::Random, col_scalars, &sweep)) return rc;
+            int kind = 0;
+            if (int rc = sweep_wanted(sys, start.kind == StartKind::Random, col_scalars, &kind)) return rc;
+            sweep = kind == 1;
+            roll = kind == 2;
             if (sweep)
                 if (int rc = make_sweep_plan(sys, mode, &splan)) return rc;
+            if (roll)
+                if (int rc = make_roll_plan(sys, mode, &rplan)) return rc;
         }
-        launch_grid = sweep ? splan.grid : plan.grid;
+        launch_grid = sweep ? splan.grid : roll ? rplan.grid : plan.grid;
         n_launches = 0;
 
         vec_count = (size_t)4 * sys->ncols * rl;  // 16-byte lane payloads
@@ -970,7 +1061,10 @@ struct Batch {
                                         (real ? 32.0 : 64.0) * rv, &args.tile_order, &strip_rows))
             return rc;
         if (args.tile_order) band_lo = band_hi = -1;  // the band is a range of naturally ordered tiles
-        if (sweep) strip_rows = 0;
+        if (sweep || roll) {
+            strip_rows = 0;
+            band_lo = band_hi = -1;
+        }
         cur = sys->vec_a.ptr;
         prev = sys->vec_b.ptr;
         kernel_ms = 0.f;
@@ -1169,13 +1263,24 @@ struct Batch {
             args.tile_base = first;
             args.n_tiles = std::min(plan.n_tiles, last) - first;
         }
-        plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
+        if (roll) {
+            bdg::RollArgs& ra = rplan.args;
+            ra.cur = cur;
+            ra.prev = prev;
+            ra.coef = args.coef;
+            ra.partial = args.partial;
+            ra.reverse = args.reverse;
+            ra.stream = args.stream_vectors;
+            rplan.kernel<<<rplan.grid, bdg::kBlockThreads, rplan.lds_bytes, st>>>(ra);
+        } else {
+            plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
+        }
         std::swap(cur, prev);
         if (in_chunk == chunk - 1 || n == n_steps - 1) {
             const int s0 = n - in_chunk;
             HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id + 1], st));
             bdg::reduce_partials<<<in_chunk + 1, 256, 0, st>>>(
-                sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, plan.grid, (int)width);
+                sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, launch_grid, (int)width);
             HIP_TRY(hipGetLastError());
             n_chunks = chunk_id + 1;
         }
@@ -1260,8 +1365,11 @@ struct Batch {
         p.kernel_ms += kernel_ms;
         p.launches += sweep ? n_launches : n_steps;
         p.vector_steps += (int64_t)n_steps * n_active;
-        p.bytes_per_launch = sweep ? sweep_bytes(sys, mode) : algorithmic_bytes(sys, rv, mode, plan.dictionary);
+        p.bytes_per_launch = sweep  ? sweep_bytes(sys, mode)
+                             : roll ? roll_bytes(sys, mode)
+                                    : algorithmic_bytes(sys, rv, mode, plan.dictionary);
         p.steps_per_launch = sweep ? 2 : 1;
+        p.rolling = roll ? 1 : 0;
         p.lanes_per_row = rl;
         p.vectors_per_launch = rv;
         p.real_arithmetic = real ? 1 : 0;
@@ -1269,7 +1377,7 @@ struct Batch {
         p.dict_blocks = plan.dictionary ? sys->n_unique : 0;
         p.strip_rows = strip_rows;
         p.grid = launch_grid;
-        p.lds_bytes = (int32_t)(sweep ? splan.lds_bytes : plan.lds_footprint);
+        p.lds_bytes = (int32_t)(sweep ? splan.lds_bytes : roll ? rplan.lds_bytes : plan.lds_footprint);
         p.pipelined = plan.pipelined ? 1 : 0;
         return BDG_OK;
     }
@@ -1302,9 +1410,10 @@ int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors) {
     const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
     const char* real_env = getenv("BODGE_AMD_REAL");
     const bool real = sys->is_real && start_is_real && !(real_env && real_env[0] == '0');
-    bool sweep = false;
-    if (sys->lanes_override == 0 && sweep_wanted(sys, start.kind == StartKind::Random, false, &sweep) == BDG_OK && sweep)
-        return std::min(bdg::kSweepLanes * (real ? 2 : 1), std::max(n_vectors, 1));  // one lane group per sweep
+    int stencil_kind = 0;
+    if (sys->lanes_override == 0 && sweep_wanted(sys, start.kind == StartKind::Random, false, &stencil_kind) == BDG_OK &&
+        stencil_kind != 0)
+        return std::min(bdg::kSweepLanes * (real ? 2 : 1), std::max(n_vectors, 1));  // one lane group per launch
     const double per_vector = (double)sys->ncols * 4 * (real ? 8.0 : 16.0);
     const int granule = 8;  // (the register-pipelined complex kernels start at 8 lanes per row)
     constexpr double kBufferTarget = 96.0 * 1024 * 1024;

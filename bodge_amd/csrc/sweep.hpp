@@ -322,4 +322,211 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
     }
 }
 
+
+// =====================================================================================
+// K8  cheb_roll3 - one recurrence step on a 3-D lattice stencil with the x-neighbours in registers.
+//
+// The one-step kernels gather all six neighbours of a site from L2.  On a 100^3 lattice the two
+// x-neighbours are a whole plane (10^4 rows x 256 B per 8 real vectors = 2.5 MB) away in either
+// direction, so by the time a row's +x neighbour is needed its line has often left the XCD's 4 MB
+// L2: 1.15 x the algorithmic HBM traffic (profiles/r01: pmc3d).  Here a wave owns 14 consecutive
+// in-plane positions p = z + Lz*y and marches along x through one segment of planes, exactly as
+// cheb_sweep does, keeping t_n of planes k-1, k, k+1 of its own positions in registers: every
+// row of t_n is read from HBM once (plus one ghost slot at either end of the window and one extra
+// plane at either end of a segment).  The +-1 (z) neighbours come from the neighbouring lanes
+// through a wave-private LDS row, the +-Lz (y) neighbours are gathered from L2, where the waves
+// 7 windows away - same workgroup or the next - have just put them.
+// Block (i, j) may be stored for j - i in {-P, -Lz, -1, 0, +1, +Lz, +P} with the z and y
+// neighbours inside the lattice (open boundaries); anything else runs the one-step kernels.
+// Two steps per sweep are not possible here: step two would need t_{n+1} of the y-neighbours,
+// which other waves make.
+constexpr int kRollOwned = kSweepSlots - 2;  // 14 owned positions per wave window
+
+struct RollArgs {
+    const uint2* stencil;    // per block row: table ids at offsets -P, -Lz, -1, 0, +1, +Lz, +P (bytes 0..6)
+    const void* dict_table;
+    int n_unique;
+    const double2* cur;      // t_n
+    double2* prev;           // t_{n-1} in, t_{n+1} out (same lane reads and writes a row: in place)
+    double* partial;         // [gridDim.x][RL * kVec][2]
+    double coef;
+    int nb, plane, lz, lx;
+    int n_cols;              // windows per plane = ceil(P / 14)
+    int n_segs;
+    int stream;              // non-temporal hints: bit 0 t_{n-1} loads, bit 1 stores
+    int reverse;             // 1 = march every segment from its far end (launches alternate)
+};
+
+__global__ void build_stencil3(const int* __restrict__ indptr, const int* __restrict__ words, int nb, int plane,
+                               int lz, uint2* __restrict__ stencil, int* __restrict__ bad) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        unsigned id[8] = {kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock};
+        const int p = i % plane, z = p % lz, y = p / lz, ly = plane / lz;
+        bool ok = true;
+        for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
+            const unsigned w = (unsigned)words[k];
+            const int off = (int)(w & 0xFFFFFFu) - i;
+            int slot = -1;
+            if (off == -plane) slot = 0;
+            else if (off == -lz && y >= 1) slot = 1;
+            else if (off == -1 && z >= 1) slot = 2;
+            else if (off == 0) slot = 3;
+            else if (off == 1 && z <= lz - 2) slot = 4;
+            else if (off == lz && y <= ly - 2) slot = 5;
+            else if (off == plane) slot = 6;
+            if (slot < 0 || (w >> 24) == kNoBlock) ok = false;
+            else id[slot] = w >> 24;
+        }
+        if (!ok) atomicOr(bad, 1);
+        stencil[i] = make_uint2(id[0] | (id[1] << 8) | (id[2] << 16) | (id[3] << 24), id[4] | (id[5] << 8) | (id[6] << 16) | (id[7] << 24));
+    }
+}
+
+template <typename Mode>
+__global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
+    extern __shared__ double2 lds[];
+    constexpr int RL = kSweepLanes;
+    constexpr int SPB = Mode::kSlotsPerBlock;
+    constexpr int STRIDE = Mode::kBlockStride;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int s = lane / RL;
+    const int r = lane % RL;
+
+    const double2* table = static_cast<const double2*>(a.dict_table);
+    for (int e = threadIdx.x; e < a.n_unique * SPB; e += kBlockThreads)
+        lds[(e / SPB) * STRIDE + (e % SPB)] = table[e];
+    double2* row_n = lds + a.n_unique * STRIDE + wave * (kWave * 4);  // t_n of plane k, all 16 slots
+    __syncthreads();
+
+    const int n_units = a.n_cols * a.n_segs;
+    const int xcd = blockIdx.x & 7;
+    const int u_lo = (int)(((int64_t)n_units * xcd) >> 3);
+    const int u_hi = (int)(((int64_t)n_units * (xcd + 1)) >> 3);
+    const int waves_per_xcd = (gridDim.x >> 3) * kWavesPerBlock;
+
+    double dot[4] = {0.0, 0.0, 0.0, 0.0};
+    const double2 zero = make_double2(0.0, 0.0);
+    const size_t nb = (size_t)a.nb;
+    const bool nt_prev = a.stream & 1, nt_store = a.stream & 2;
+
+    for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
+        const int seg = u / a.n_cols, col = u - seg * a.n_cols;
+        const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
+        const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
+        const int p = col * kRollOwned - 1 + s;
+        const bool valid = p >= 0 && p < a.plane;
+        const bool owned = valid && s >= 1 && s <= kSweepSlots - 2;
+        const bool rev = a.reverse != 0;  // wave-uniform
+        auto act = [&](int k) { return rev ? x0 + x1 - 1 - k : k; };
+
+        auto load_plane = [&](const double2* buf, bool nt, int k, int shift, bool wanted, double2 out[4]) {
+            k = act(k);
+            if (wanted && k >= 0 && k < a.lx) {
+                const size_t site = (size_t)k * a.plane + (p + shift);
+#pragma unroll
+                for (int al = 0; al < 4; ++al)
+                    out[al] = nt ? load_stream(buf + vslot(al, site, r, nb, RL)) : buf[vslot(al, site, r, nb, RL)];
+            } else {
+#pragma unroll
+                for (int al = 0; al < 4; ++al) out[al] = zero;
+            }
+        };
+        auto load_ids = [&](int k) {
+            uint2 w = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            k = act(k);
+            if (owned && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + p];
+            return w;
+        };
+        auto id_of = [](uint2 w, int slot) { return slot < 4 ? (w.x >> (8 * slot)) & 0xFFu : (w.y >> (8 * (slot - 4))) & 0xFFu; };
+
+        // ---- prologue: t_n of planes x0-1, x0, x0+1; t_{n-1}, ids and y-neighbours of plane x0
+        double2 cn_m[4], cn_0[4], cn_p[4], pv[4], ym[4], yp[4];
+        load_plane(a.cur, false, x0 - 1, 0, valid, cn_m);
+        load_plane(a.cur, false, x0, 0, valid, cn_0);
+        load_plane(a.cur, false, x0 + 1, 0, valid, cn_p);
+        load_plane(a.prev, nt_prev, x0, 0, owned, pv);
+        uint2 ids = load_ids(x0);
+        load_plane(a.cur, false, x0, -a.lz, owned && id_of(ids, 1) != kNoBlock, ym);
+        load_plane(a.cur, false, x0, +a.lz, owned && id_of(ids, 5) != kNoBlock, yp);
+
+        for (int k = x0; k < x1; ++k) {
+            // ---- prefetch for the next iteration
+            double2 nx_cn[4], nx_pv[4], nx_ym[4], nx_yp[4];
+            const bool more = k + 1 < x1;
+            load_plane(a.cur, false, k + 2, 0, valid && more, nx_cn);
+            load_plane(a.prev, nt_prev, k + 1, 0, owned && more, nx_pv);
+            const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
+            load_plane(a.cur, false, k + 1, -a.lz, owned && more && id_of(nx_ids, 1) != kNoBlock, nx_ym);
+            load_plane(a.cur, false, k + 1, +a.lz, owned && more && id_of(nx_ids, 5) != kNoBlock, nx_yp);
+
+#pragma unroll
+            for (int be = 0; be < 4; ++be) row_n[SHARE_SLOT(lane, be)] = cn_0[be];
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+
+            if (owned) {
+                double2 acc[4], x[4];
+#pragma unroll
+                for (int al = 0; al < 4; ++al) acc[al] = zero;
+                // CSR order: -P, -Lz, -1, 0, +1, +Lz, +P  (a reversed march swaps which register is -P)
+                unsigned id = id_of(ids, 0);
+                if (id != kNoBlock) {
+                    if (rev) Mode::mac_row(acc, lds + id * STRIDE, cn_p);
+                    else Mode::mac_row(acc, lds + id * STRIDE, cn_m);
+                }
+                id = id_of(ids, 1);
+                if (id != kNoBlock) Mode::mac_row(acc, lds + id * STRIDE, ym);
+                id = id_of(ids, 2);
+                if (id != kNoBlock) {
+#pragma unroll
+                    for (int be = 0; be < 4; ++be) x[be] = row_n[SHARE_SLOT(lane - RL, be)];
+                    Mode::mac_row(acc, lds + id * STRIDE, x);
+                }
+                id = id_of(ids, 3);
+                if (id != kNoBlock) Mode::mac_row(acc, lds + id * STRIDE, cn_0);
+                id = id_of(ids, 4);
+                if (id != kNoBlock) {
+#pragma unroll
+                    for (int be = 0; be < 4; ++be) x[be] = row_n[SHARE_SLOT(lane + RL, be)];
+                    Mode::mac_row(acc, lds + id * STRIDE, x);
+                }
+                id = id_of(ids, 5);
+                if (id != kNoBlock) Mode::mac_row(acc, lds + id * STRIDE, yp);
+                id = id_of(ids, 6);
+                if (id != kNoBlock) {
+                    if (rev) Mode::mac_row(acc, lds + id * STRIDE, cn_m);
+                    else Mode::mac_row(acc, lds + id * STRIDE, cn_p);
+                }
+                const size_t site = (size_t)act(k) * a.plane + p;
+#pragma unroll
+                for (int al = 0; al < 4; ++al) {
+                    double2 nx;
+                    nx.x = fma(a.coef, acc[al].x, -pv[al].x);
+                    nx.y = fma(a.coef, acc[al].y, -pv[al].y);
+                    if (nt_store) store_stream(a.prev + vslot(al, site, r, nb, RL), nx);
+                    else a.prev[vslot(al, site, r, nb, RL)] = nx;
+                    Mode::dots(dot, cn_0[al], nx);
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int al = 0; al < 4; ++al) {
+                cn_m[al] = cn_0[al];
+                cn_0[al] = cn_p[al];
+                cn_p[al] = nx_cn[al];
+                pv[al] = nx_pv[al];
+                ym[al] = nx_ym[al];
+                yp[al] = nx_yp[al];
+            }
+            ids = nx_ids;
+        }
+    }
+
+    __syncthreads();
+    reduce_dots<Mode, RL>(dot, reinterpret_cast<double*>(lds), a.partial, lane, wave);
+}
+
 }  // namespace bdg

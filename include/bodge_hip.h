@@ -60,6 +60,8 @@ typedef struct bdg_perf {
     int32_t ph_packed;     /* 1 = particle-hole packed blocks (12 of 16 entries stored)      */
     int32_t dict_blocks;   /* >0 = dictionary form: number of distinct blocks in the table   */
     int32_t steps_per_launch; /* 2 = two recurrence steps per sweep of the vectors (lattice stencils), else 1 */
+    int32_t rolling;       /* 1 = 3-D stencil kernel with the x-neighbours in registers (cheb_roll3) */
+    int32_t reserved;
 } bdg_perf;
 
 const char* bdg_last_error(void);

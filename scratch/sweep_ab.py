@@ -13,7 +13,12 @@ shape = tuple(int(v) for v in os.environ.get("AB_LATTICE", "1000,1000,1").split(
 lat = ba.CubicLattice(shape)
 sysm = ba.Hamiltonian(lat)
 with sysm as (H, D):
-    H.set_sites(3.0 * ba.σ0 - 0.05 * ba.σ3); D.set_sites(-0.1 * ba.jσ2); H.set_bonds(-1.0 * ba.σ0)
+    if os.environ.get("AB_MODEL", "swave") == "dwave":
+        pairs = lat.bond_array(coords=True)
+        H.set_sites(3.0 * ba.σ0); H.set_bonds(-1.0 * ba.σ0)
+        D.set_bonds(-0.1 * ba.dwave()(pairs[:, 0], pairs[:, 1]))
+    else:
+        H.set_sites(3.0 * ba.σ0 - 0.05 * ba.σ3); D.set_sites(-0.1 * ba.jσ2); H.set_bonds(-1.0 * ba.σ0)
 indptr, indices, data = sysm.bsr_arrays()
 scale = chebyshev.spectral_bound(indptr, data)
 variants = []
@@ -42,4 +47,5 @@ with DeviceSolver(indptr, indices, data) as dev:
         t = statistics.median(times[label])
         p = info[label]
         print(f"{label:34s} {t:7.1f} us/launch (min {min(times[label]):6.1f})  {p['bytes_per_launch'] / t / 1e6:5.2f} TB/s alg  "
-              f"{8 * p['steps_per_launch'] / t * 1e3:6.1f} k vector-steps/s  grid={p['grid']}", flush=True)
+              f"{8 * p['steps_per_launch'] / t * 1e3:6.1f} k vector-steps/s  grid={p['grid']} rolling={p['rolling']} "
+              f"steps/launch={p['steps_per_launch']}", flush=True)

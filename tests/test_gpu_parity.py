@@ -227,6 +227,8 @@ def _sweep_system(api, shape, kind):
             Δ.set_sites(-0.1 * api.jσ2)
             H.set_bonds(-phase[:, None, None] * api.σ0, axis=0)
             H.set_bonds(-1.0 * api.σ0, axis=1 if shape[1] > 1 else 2)
+            if shape[1] > 1 and shape[2] > 1:
+                H.set_bonds(-0.7 * api.σ0, axis=2)
         elif kind == "dwave":
             pairs = lattice.bond_array(coords=True)
             H.set_sites(3.0 * api.σ0)
@@ -256,19 +258,24 @@ def _sweep_system(api, shape, kind):
     ((16, 1, 40), "swave", cheb_ref.VEC_RADEMACHER),     # (Lx, 1, Lz): the plane is a z-line
     ((9, 25, 1), "swave", cheb_ref.VEC_Z4),              # complex vectors on a real matrix, one short segment
     ((30, 30, 1), "periodic", cheb_ref.VEC_RADEMACHER),  # wrap blocks: not a stencil, one-step kernels must run
-    ((12, 30, 4), "swave", cheb_ref.VEC_RADEMACHER),     # 3-D: +-Lz neighbours inside the plane, falls back
+    ((12, 30, 4), "swave", cheb_ref.VEC_RADEMACHER),     # 3-D: one step per launch, x-neighbours in registers (K8)
+    ((9, 7, 13), "dwave", cheb_ref.VEC_RADEMACHER),      # 3-D d-wave (zero z-bond pairing blocks), odd sizes
+    ((10, 6, 8), "peierls", cheb_ref.VEC_Z4),            # 3-D complex
+    ((8, 5, 6), "periodic", cheb_ref.VEC_RADEMACHER),    # 3-D with wrap blocks: falls back
 ])
 def test_two_steps_per_sweep_kernel_matches_oracle_and_one_step_kernels(api, solver_cls, monkeypatch, block_storage,
                                                                         shape, kind, vec_kind):
-    """K7 (sweep.hpp) forced on small lattices: every d_n, e_n against the CPU oracle and against the
-    one-step kernels on the same vectors, for even and odd step counts (the odd tail runs one step
-    alone), full and partial lane groups, both marching directions, zigzag on and off.  Matrices
-    that are not a 5-point lattice stencil must take the one-step kernels without being told."""
+    """K7 / K8 (sweep.hpp) forced on small lattices: every d_n, e_n against the CPU oracle and against
+    the one-step kernels on the same vectors, for even and odd step counts (the odd tail of a
+    two-step run goes alone), full and partial lane groups, both marching directions, zigzag on
+    and off.  2-D stencils take two steps per sweep, 3-D stencils the rolling one-step kernel, and
+    matrices that are no lattice stencil must take the generic kernels without being told."""
     system = _sweep_system(api, shape, kind)
     bsr = system.matrix("bsr")
     scale = cheb_ref.spectral_bound(bsr)
     n = bsr.shape[0]
-    is_stencil = kind != "periodic" and not (shape[1] > 1 and shape[2] > 1)
+    three_d = shape[1] > 1 and shape[2] > 1
+    is_stencil = kind != "periodic"
     per_group = 8 if (vec_kind == cheb_ref.VEC_RADEMACHER and kind != "peierls") else 4
     with solver_cls.from_hamiltonian(system) as dev:
         for steps, vectors, extra in [(8, per_group, {}), (7, 3, {}), (5, per_group + 3, {"BODGE_AMD_SWEEP_ZIGZAG": "0"}),
@@ -285,11 +292,14 @@ def test_two_steps_per_sweep_kernel_matches_oracle_and_one_step_kernels(api, sol
             again = dev.dots_random(scale, steps, vectors, seed=5, kind=vec_kind)
             for key in extra:
                 monkeypatch.delenv(key)
-            swept = is_stencil and block_storage == "dictionary"  # (the sweep form reads the block dictionary)
-            assert (perf["steps_per_launch"] == 2) == swept, perf
+            stencil = is_stencil and block_storage == "dictionary"  # (the stencil forms read the block dictionary)
+            swept, rolled = stencil and not three_d, stencil and three_d
+            assert (perf["steps_per_launch"] == 2) == swept and (perf["rolling"] == 1) == rolled, perf
+            batches = -(-vectors // per_group)
             if swept:
-                batches = -(-vectors // per_group)
                 assert perf["launches"] == batches * ((steps + 1) // 2)
+            if rolled:
+                assert perf["launches"] == batches * steps
             assert np.array_equal(got[0], again[0]) and np.array_equal(got[1], again[1])  # bit reproducible
             for other in (ref, one):
                 assert np.abs(got[0] - other[0]).max() <= 1e-12 * n and np.abs(got[1] - other[1]).max() <= 1e-12 * n
