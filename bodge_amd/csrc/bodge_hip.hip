@@ -91,6 +91,13 @@ int next_pow2(int v) {
 
 }  // namespace
 
+struct bdg_system;
+namespace {
+// A Lanczos run keeps pointers into the handle's vector buffers; any other call that refills or
+// reallocates them ends the run first (bdg_lanczos_advance then reports that begin is needed).
+void lanczos_free(bdg_system* sys);
+}
+
 struct ExchangePeer {
     int rank = 0;            // peer's rank (RCCL) or member index (same-process group)
     int64_t send_begin = 0;  // offset into send_rows / send buffer rows
@@ -113,6 +120,10 @@ struct bdg_system {
     DeviceBuffer<double2> send_buf, recv_buf;
     int64_t send_total = 0, recv_total = 0;
     bdg_comm* slab_comm = nullptr;  // RCCL transport for the halo exchange (not owned)
+    // agreed over slab_comm in bdg_slab_set_exchange: every rank must choose the same arithmetic
+    // mode and batch width, or the ncclSend/ncclRecv counts of the halo exchange do not match
+    bool slab_all_real = false;
+    int64_t slab_max_ncols = 0;
     // overlap of the halo exchange with the rows that do not need it
     std::vector<uint8_t> row_needs_halo;  // host: block row reads at least one halo column
     hipStream_t comm_stream = nullptr;
@@ -952,7 +963,8 @@ struct Batch {
         // (±1 or unit vectors): every t_n then stays real.  BODGE_AMD_REAL=0 forces complex.
         const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
         const char* real_env = getenv("BODGE_AMD_REAL");
-        real = sys->is_real && start_is_real && !(real_env && real_env[0] == '0');
+        const bool matrix_real = sys->slab_comm ? sys->slab_all_real : sys->is_real;  // slabs: agreed over all ranks
+        real = matrix_real && start_is_real && !(real_env && real_env[0] == '0');
         if (force_real >= 0) real = force_real != 0;
         const char* ph_env = getenv("BODGE_AMD_PH");
         mode = mode_info(real, sys->is_ph && !(ph_env && ph_env[0] == '0'));
@@ -964,6 +976,14 @@ struct Batch {
             sys->lanes_override * per_lane <= 64)
             rl = sys->lanes_override;
         rv = rl * per_lane;  // vector columns in the buffers
+        if (sys->slab_comm && sys->slab_comm->n_ranks > 1) {
+            // the halo messages are 4 * rl payloads per row: a rank with another rl would hang or mis-unpack
+            double probe[2] = {(double)(rl * 2 + (real ? 1 : 0)), -(double)(rl * 2 + (real ? 1 : 0))};
+            if (int rc = comm_allreduce(sys->slab_comm, probe, 2, ncclMax)) return rc;
+            if (probe[0] != -probe[1])
+                return fail(BDG_EINVAL, "slab ranks chose different kernel configurations (lanes x mode %d here)",
+                            rl * 2 + (real ? 1 : 0));
+        }
         if (int rc = make_plan(sys, rl, mode, &plan, col_scalars)) return rc;
         if (int rc = matrix_args(sys, plan, &args)) return rc;
         sweep = roll = false;
@@ -1409,12 +1429,14 @@ int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors) {
     if (const char* env = getenv("BODGE_AMD_BATCH")) return std::clamp(atoi(env), 1, 64);
     const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
     const char* real_env = getenv("BODGE_AMD_REAL");
-    const bool real = sys->is_real && start_is_real && !(real_env && real_env[0] == '0');
+    const bool real = (sys->slab_comm ? sys->slab_all_real : sys->is_real) && start_is_real &&
+                      !(real_env && real_env[0] == '0');
     int stencil_kind = 0;
     if (sys->lanes_override == 0 && sweep_wanted(sys, start.kind == StartKind::Random, false, &stencil_kind) == BDG_OK &&
         stencil_kind != 0)
         return std::min(bdg::kSweepLanes * (real ? 2 : 1), std::max(n_vectors, 1));  // one lane group per launch
-    const double per_vector = (double)sys->ncols * 4 * (real ? 8.0 : 16.0);
+    // (slabs: the widest slab of the run decides, so that every rank cuts the same batches)
+    const double per_vector = (double)std::max(sys->ncols, sys->slab_max_ncols) * 4 * (real ? 8.0 : 16.0);
     const int granule = 8;  // (the register-pipelined complex kernels start at 8 lanes per row)
     constexpr double kBufferTarget = 96.0 * 1024 * 1024;
     int width = 64;
@@ -1426,6 +1448,7 @@ int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors) {
 int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, StartSpec start,
                    double* d_out, double* e_out) {
     if (int rc = check_recurrence_args(sys, scale, n_steps, n_vectors, d_out, e_out)) return rc;
+    lanczos_free(sys);
     const bool trace = getenv("BODGE_AMD_TRACE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
@@ -1469,7 +1492,10 @@ int run_group(bdg_group* group, double scale, int n_steps, int n_vectors, StartS
     if (int rc = check_recurrence_args(group, scale, n_steps, n_vectors, d_out, e_out)) return rc;
     const size_t n_members = group->members.size();
     bool all_real = true;
-    for (bdg_system* m : group->members) all_real = all_real && m->is_real;
+    for (bdg_system* m : group->members) {
+        all_real = all_real && m->is_real;
+        lanczos_free(m);
+    }
     // (storage packing is per member: it changes what a member reads, not what it exchanges)
     const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
     const char* real_env = getenv("BODGE_AMD_REAL");
@@ -1580,7 +1606,19 @@ int lanczos_begin(bdg_system* sys, int n_vectors, const StartSpec& start, int ma
     if (max_iter < 1 || max_iter > (1 << 20)) return fail(BDG_EINVAL, "bad iteration limit");
     lanczos_free(sys);
     LanczosState* lz = new LanczosState();
-    sys->lanczos = lz;
+    // the handle learns about the run only once everything below has succeeded
+    struct Guard {
+        LanczosState* lz;
+        bool keep = false;
+        ~Guard() {
+            if (keep) return;
+            lz->work.release();
+            lz->scalars.release();
+            lz->sums.release();
+            lz->norm_partial.release();
+            delete lz;
+        }
+    } guard{lz};
     Batch& b = lz->batch;
     if (int rc = b.begin(sys, 1.0, 1, n_vectors, start, -1, /*col_scalars=*/true)) return rc;  // W_0 in vec_a
     lz->cols = b.rv;
@@ -1608,6 +1646,8 @@ int lanczos_begin(bdg_system* sys, int n_vectors, const StartSpec& start, int ma
     if (int rc = lanczos_norms(sys, lz, lz->w_cur, nullptr, false)) return rc;
     bdg::lanczos_scalars<<<1, 128, 0, sys->stream>>>(lz->z, lz->sums.ptr, lz->cols, 0, 0);
     HIP_TRY(hipGetLastError());
+    guard.keep = true;
+    sys->lanczos = lz;
     return BDG_OK;
 }
 
@@ -2010,6 +2050,16 @@ int bdg_slab_set_exchange(bdg_system* sys, bdg_comm* comm, int32_t n_peers, cons
     sys->send_total = send_total;
     sys->recv_total = recv_total;
     sys->slab_comm = comm;
+    sys->slab_all_real = sys->is_real;
+    sys->slab_max_ncols = sys->ncols;
+    if (comm && comm->n_ranks > 1) {
+        // collective: every rank of the communicator sets its exchange lists at this point.
+        // min over ranks of "my slab is real" and max of the buffer rows decide mode and batch width for all.
+        double agree[2] = {sys->is_real ? 0.0 : 1.0, (double)sys->ncols};
+        if (int rc = comm_allreduce(comm, agree, 2, ncclMax)) return rc;
+        sys->slab_all_real = agree[0] == 0.0;
+        sys->slab_max_ncols = (int64_t)agree[1];
+    }
     return BDG_OK;
 }
 
@@ -2138,6 +2188,7 @@ int bdg_set_lanes_per_row(bdg_system* sys, int32_t lanes) {
 int bdg_spmv(bdg_system* sys, const double* x, double* y) {
     if (!sys || !x || !y) return fail(BDG_EINVAL, "null argument");
     if (sys->ncols != sys->nb) return fail(BDG_EINVAL, "bdg_spmv needs a whole (square) matrix, not a slab");
+    lanczos_free(sys);
     HIP_TRY(hipSetDevice(sys->device));
     constexpr int kCols = 4;  // narrowest kernel configuration; columns 1..3 stay zero
     StepPlan plan;
@@ -2233,6 +2284,7 @@ int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t v
     if (!sys || !v_out) return fail(BDG_EINVAL, "null argument");
     if (vec_kind != BDG_VEC_RADEMACHER && vec_kind != BDG_VEC_Z4)
         return fail(BDG_EINVAL, "unknown start-vector kind %d", vec_kind);
+    lanczos_free(sys);
     HIP_TRY(hipSetDevice(sys->device));
     const size_t n = (size_t)4 * sys->nb;
     if (int rc = sys->vec_a.reserve(n)) return rc;
@@ -2258,6 +2310,7 @@ int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t v
 int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     if (!sys || !w_out) return fail(BDG_EINVAL, "null argument");
     if (sys->ncols != sys->nb) return fail(BDG_EINVAL, "bdg_eigh_dense needs a whole (square) matrix, not a slab");
+    lanczos_free(sys);
     HIP_TRY(hipSetDevice(sys->device));
     const int64_t n = 4 * sys->nb;
     {

@@ -128,6 +128,7 @@ class DeviceSolver:
 
     # ------------------------------------------------------------------- kernels
     def spmv(self, x: np.ndarray) -> np.ndarray:
+        self._lanczos_vectors = 0  # any other use of the handle ends a Lanczos run (library: lanczos_free)
         x = np.ascontiguousarray(x, dtype=np.complex128).reshape(-1)
         if x.size != self.dim:
             raise ValueError(f"expected a vector of {self.dim} entries")
@@ -139,6 +140,7 @@ class DeviceSolver:
         return y
 
     def random_vector(self, seed: int, vec_id: int, kind: int = VEC_RADEMACHER) -> np.ndarray:
+        self._lanczos_vectors = 0  # any other use of the handle ends a Lanczos run (library: lanczos_free)
         v = np.empty(self.dim, dtype=np.complex128)
         backend.check(
             self._lib.bdg_random_vector(self._handle, seed, vec_id, kind, backend.as_f64p(v.view(np.float64)))
@@ -146,6 +148,7 @@ class DeviceSolver:
         return v
 
     def dots_random(self, scale, n_steps, n_vectors, seed=0, first_id=0, kind=VEC_RADEMACHER):
+        self._lanczos_vectors = 0  # any other use of the handle ends a Lanczos run (library: lanczos_free)
         d = np.empty((n_steps, n_vectors))
         e = np.empty((n_steps, n_vectors))
         backend.check(
@@ -157,6 +160,7 @@ class DeviceSolver:
         return d, e
 
     def dots_unit(self, scale, n_steps, rows):
+        self._lanczos_vectors = 0  # any other use of the handle ends a Lanczos run (library: lanczos_free)
         rows = np.ascontiguousarray(rows, dtype=np.int64)
         d = np.empty((n_steps, rows.size))
         e = np.empty((n_steps, rows.size))
@@ -171,6 +175,7 @@ class DeviceSolver:
     def moments_random(self, scale, n_moments, n_vectors, seed=0, first_id=0, kind=VEC_RADEMACHER,
                        comm: "Communicator | None" = None) -> np.ndarray:
         """Σ_r <v_r|T_m(H/scale)|v_r> for m < n_moments (summed over ranks if `comm`)."""
+        self._lanczos_vectors = 0  # any other use of the handle ends a Lanczos run (library: lanczos_free)
         mu = np.empty(n_moments)
         backend.check(
             self._lib.bdg_cheb_moments(
@@ -182,6 +187,7 @@ class DeviceSolver:
 
     def moments_unit(self, scale, n_moments, rows) -> np.ndarray:
         """(n_moments, len(rows)) array of <e_row|T_m(H/scale)|e_row>."""
+        self._lanczos_vectors = 0  # any other use of the handle ends a Lanczos run (library: lanczos_free)
         rows = np.ascontiguousarray(rows, dtype=np.int64)
         mu = np.empty((n_moments, rows.size))
         backend.check(
@@ -210,6 +216,7 @@ class DeviceSolver:
     def eigh(self, vectors: bool = True):
         """All eigenvalues ascending (and eigenvectors as columns): own Jacobi kernels up to 4N = 2048,
         rocSOLVER above (dsyevd when imag(H) = 0, else zheevd)."""
+        self._lanczos_vectors = 0  # any other use of the handle ends a Lanczos run (library: lanczos_free)
         w = np.empty(self.dim)
         if not vectors:
             backend.check(self._lib.bdg_eigh_dense(self._handle, backend.as_f64p(w), None))

@@ -820,3 +820,24 @@ def test_lanczos_tridiagonal_matches_oracle(api, solver_cls):
         b = np.linalg.norm(w)
         assert np.isclose(alpha[j, 0], a, rtol=1e-11) and np.isclose(beta[j, 0], b, rtol=1e-9)
         v_prev, v_cur, b_prev = v_cur, w / b, b
+
+
+def test_lanczos_run_is_ended_by_any_other_use_of_the_handle(api, solver_cls):
+    """A Lanczos run keeps pointers into the handle's vector buffers.  Any other call that refills
+    or reallocates them (here a wide recurrence call) must end the run: the next advance is refused
+    with an error instead of iterating on stale or freed device memory; a fresh begin works."""
+    system = _build(api, "snf")
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    with solver_cls.from_hamiltonian(system) as dev:
+        dev.lanczos_begin(2, seed=1, max_iter=40)
+        first = dev.lanczos_advance(5)
+        dev.dots_random(scale, 4, 64, seed=3)  # 64 vectors: the vector buffers grow
+        with pytest.raises(ValueError):
+            dev.lanczos_advance(5)
+        dev._lanczos_vectors = 2  # get past the Python-side guard: the library must refuse on its own
+        with pytest.raises(ValueError):
+            dev.lanczos_advance(5)
+        dev.lanczos_begin(2, seed=1, max_iter=40)
+        again = dev.lanczos_advance(5)
+    assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
