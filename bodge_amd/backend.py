@@ -44,7 +44,7 @@ class Perf(C.Structure):
         ("dict_blocks", C.c_int32),
         ("steps_per_launch", C.c_int32),
         ("rolling", C.c_int32),
-        ("reserved", C.c_int32),
+        ("dict_skipped", C.c_int32),
     ]
 
 
@@ -82,6 +82,7 @@ SIGNATURES = {
     "bdg_lanczos_advance": (C.c_int, [_handle, C.c_int32, _f64p, _f64p]),
     "bdg_random_vector": (C.c_int, [_handle, C.c_uint64, C.c_uint64, C.c_int32, _f64p]),
     "bdg_eigh_dense": (C.c_int, [_handle, _f64p, _f64p]),
+    "bdg_hermiticity_defect": (C.c_int, [_handle, _f64p]),
     "bdg_dense_prefetch": (C.c_int, []),
     "bdg_dense_prefetch_wait": (C.c_int, [C.c_double, C.POINTER(C.c_int32)]),
     "bdg_perf_query": (C.c_int, [_handle, C.POINTER(Perf)]),

@@ -143,6 +143,8 @@ struct bdg_system {
     double gershgorin = 0.0;           // max over scalar rows of sum |H_rc| (bound on |H|)
     // dictionary form: the distinct blocks and one id per stored block (0 entries = not used)
     int n_unique = 0;
+    int dict_skipped = 0;  // why there is no dictionary: 0 = there is one, 1 = > 256 distinct blocks,
+                           // 2 = more than 2^24 block columns (the packed word holds 24 bits), 3 = switched off
     DeviceBuffer<int> dict_ids;
     DeviceBuffer<double2> dict_full;      // n_unique x 16 complex entries
     DeviceBuffer<double2> dict_table[4];  // packed per storage mode, built on first use
@@ -1390,6 +1392,7 @@ struct Batch {
                                     : algorithmic_bytes(sys, rv, mode, plan.dictionary);
         p.steps_per_launch = sweep ? 2 : 1;
         p.rolling = roll ? 1 : 0;
+        p.dict_skipped = sys->dict_skipped;
         p.lanes_per_row = rl;
         p.vectors_per_launch = rv;
         p.real_arithmetic = real ? 1 : 0;
@@ -1846,11 +1849,13 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     // A lattice matrix repeats a handful of blocks, mostly in runs: the four most recent ones are
     // compared directly before the hash map is asked.
     constexpr int kMaxDistinct = 256;  // table index shares a 32-bit word with the 24-bit column
+    int dict_skipped = 0;
     std::vector<int> ids;
     std::vector<double> distinct;  // n_unique x 32 doubles
     {
         const char* env = getenv("BODGE_AMD_DICT");
         bool wanted = !(env && env[0] == '0') && nnzb > 0 && ncols <= (1 << 24);
+        dict_skipped = (env && env[0] == '0') ? 3 : ncols > (1 << 24) ? 2 : 0;
         if (wanted) {
             std::unordered_map<std::string_view, int> seen;
             const double* recent_key[4] = {nullptr, nullptr, nullptr, nullptr};
@@ -1868,6 +1873,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
                     if (it == seen.end()) {
                         if ((int)seen.size() == kMaxDistinct) {
                             wanted = false;
+                            dict_skipped = 1;
                             break;
                         }
                         it = seen.emplace(key, (int)seen.size()).first;
@@ -1964,6 +1970,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
             for (int k = indptr[i]; k < indptr[i + 1]; ++k)
                 if (indices[k] >= nb) sys->row_needs_halo[(size_t)i] = 1;
     }
+    sys->dict_skipped = dict_skipped;
     sys->is_real = is_real;
     sys->is_ph = is_ph;
     sys->gershgorin = gershgorin;
@@ -2445,6 +2452,31 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     offdiag.release();
     info.release();
     return rc;
+}
+
+int bdg_hermiticity_defect(bdg_system* sys, double* defect_out) {
+    if (!sys || !defect_out) return fail(BDG_EINVAL, "null argument");
+    if (sys->ncols != sys->nb) return fail(BDG_EINVAL, "bdg_hermiticity_defect needs a whole (square) matrix, not a slab");
+    HIP_TRY(hipSetDevice(sys->device));
+    const int grid = (int)std::min<int64_t>(2048, (sys->nb + 255) / 256);
+    DeviceBuffer<double> partial;
+    if (int rc = partial.reserve((size_t)grid)) return rc;
+    std::vector<double> host((size_t)grid);
+    auto body = [&]() -> int {
+        bdg::hermiticity_defect<<<grid, 256, 0, sys->stream>>>(sys->indptr.ptr, sys->indices.ptr, sys->blocks.ptr,
+                                                              (int)sys->nb, partial.ptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host.data(), partial.ptr, sizeof(double) * grid, hipMemcpyDeviceToHost, sys->stream));
+        HIP_TRY(hipStreamSynchronize(sys->stream));
+        return BDG_OK;
+    };
+    const int rc = body();
+    partial.release();
+    if (rc) return rc;
+    double worst = 0.0;
+    for (double v : host) worst = std::isnan(v) ? v : std::max(worst, v);
+    *defect_out = worst;
+    return BDG_OK;
 }
 
 int bdg_dense_prefetch(void) {

@@ -1204,6 +1204,49 @@ __global__ __launch_bounds__(256) void jacobi_eigenvalues(const T* __restrict__ 
     if (threadIdx.x == 0) eig[blockIdx.x] = sqrt(red[0]) - shift;
 }
 
+// max |H - H^†| over the stored entries (reference hamiltonian.py:121-122, `M - M.getH()`): block
+// (i, j) against the conjugate transpose of block (j, i), found by binary search in the sorted
+// row j; a block without a stored partner counts with its own magnitude.  One thread per block
+// row, one partial maximum per workgroup.
+__global__ __launch_bounds__(256) void hermiticity_defect(const int* __restrict__ indptr,
+                                                          const int* __restrict__ indices,
+                                                          const double2* __restrict__ blocks, int nb,
+                                                          double* __restrict__ partial) {
+    __shared__ double red[256];
+    double worst = 0.0;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x)
+        for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
+            const int j = indices[k];
+            int lo = indptr[j], hi = indptr[j + 1] - 1, m = -1;
+            while (lo <= hi) {
+                const int mid = (lo + hi) >> 1;
+                const int c = indices[mid];
+                if (c == i) {
+                    m = mid;
+                    break;
+                }
+                if (c < i) lo = mid + 1;
+                else hi = mid - 1;
+            }
+            for (int el = 0; el < 16; ++el) {
+                const double2 a = blocks[(size_t)k * 16 + el];
+                double2 b = make_double2(0.0, 0.0);
+                if (m >= 0) {
+                    const double2 t = blocks[(size_t)m * 16 + (el & 3) * 4 + (el >> 2)];
+                    b = make_double2(t.x, -t.y);
+                }
+                worst = fmax(worst, hypot(a.x - b.x, a.y - b.y));
+            }
+        }
+    red[threadIdx.x] = worst;
+    __syncthreads();
+    for (int stride = 128; stride > 0; stride >>= 1) {
+        if ((int)threadIdx.x < stride) red[threadIdx.x] = fmax(red[threadIdx.x], red[threadIdx.x + stride]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) partial[blockIdx.x] = red[0];
+}
+
 // count of non-finite doubles in x[0..n) (eigensolver results are checked on the device, before
 // any copy to the host): one atomicAdd per workgroup that saw one
 __global__ void count_nonfinite(const double* __restrict__ x, int64_t n, int* __restrict__ count) {

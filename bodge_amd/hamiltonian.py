@@ -30,6 +30,21 @@ from .common import Coord, Coords, Index, Indices, Matrix, jσ2, σ, typecheck, 
 from .lattice import CubicLattice, Lattice
 
 
+# `with` blocks that wrote at least this many blocks have their Hermiticity test made on the GPU
+# (bdg_hermiticity_defect) when one is present; smaller ones - every reference-sized lattice - on
+# the host, where the chunked comparison takes milliseconds.
+DEVICE_HERMITICITY_MIN_BLOCKS = 500_000
+
+
+def _gpu_present() -> bool:
+    try:
+        from . import backend
+
+        return backend.device_count() > 0
+    except (RuntimeError, OSError):
+        return False
+
+
 # ---------------------------------------------------------------------------
 class TermTable(dict):
     """Mapping {(coord_i, coord_j): 2x2 matrix} handed out by `with system as ...`.
@@ -165,7 +180,12 @@ class Hamiltonian:
         # Blocks this `with` did not write were checked when they were written (and start out zero),
         # unless that earlier check failed and left the matrix in a non-Hermitian state.
         everything = self._recheck_all or bool(touched.all())
-        defect = self._hermiticity_defect(None if everything else np.flatnonzero(touched))
+        if int(touched.sum()) >= DEVICE_HERMITICITY_MIN_BLOCKS and _gpu_present():
+            # large fills: the matrix goes to the GPU now (the observables need it there anyway)
+            # and is compared with its conjugate transpose on the device, block against block
+            defect = self._solver().hermiticity_defect()
+        else:
+            defect = self._hermiticity_defect(None if everything else np.flatnonzero(touched))
         self._recheck_all = defect > 1e-6
         if self._recheck_all:
             raise RuntimeError("The constructed Hamiltonian is not Hermitian!")
@@ -255,22 +275,25 @@ class Hamiltonian:
         return self._memo[name]
 
     # ------------------------------------------------------------- observables
-    def _solver(self, lane: int = 0):
+    def _solver(self, lane=0, device: int | None = None):
         """Device mirror of the current matrix (re-uploaded after every `with`).
 
         `lane` > 0 gives further independent mirrors (own stream and buffers): mid-size exact
         traces drive two of them from two host threads to overlap their launch latencies.
+        `device` puts the mirror on that GPU of this process (`free_energy(devices=[...])`
+        keeps one mirror per listed entry); default: `BODGE_AMD_DEVICE` / `LOCAL_RANK` / 0.
         """
         from .solver import DeviceSolver
 
         if self._device_revision != self._revision:
-            for device in self._devices.values():
-                device.close()
+            for mirror in self._devices.values():
+                mirror.close()
             self._devices = {}
             self._device_revision = self._revision
-        if lane not in self._devices:
-            self._devices[lane] = DeviceSolver.from_hamiltonian(self)
-        return self._devices[lane]
+        key = lane if device is None else (lane, int(device))
+        if key not in self._devices:
+            self._devices[key] = DeviceSolver.from_hamiltonian(self, device=device)
+        return self._devices[key]
 
     def diagonalize(self, cuda: bool = False, format: str = "reshape"):
         """Positive-energy eigenpairs (E, v[n, site, α]) or raw (E, X[:, n]).

@@ -30,6 +30,13 @@ GAP_SURROGATE_RATIO = 20.0  # T = 0 is expanded at T = gap / this (see free_ener
 EXACT_TRACE_LIMIT = 65536  # largest 4N for which trace="auto" is exact (128x128 sites: ~2 s at T = 0.1)
 
 
+def _warn(message: str) -> None:
+    """RuntimeWarning for results that are not what the reference's call would have computed."""
+    import warnings
+
+    warnings.warn(message, RuntimeWarning, stacklevel=4)
+
+
 def _scale_of(system, pad: float = 1.01) -> float:
     # zero blocks add nothing to the row sums: the skeleton arrays give the same bound as the
     # trimmed ones, without the copy; cached until the next `with` block
@@ -137,6 +144,7 @@ def free_energy(
     damping: bool = False,
     comm=None,
     decomposition: str = "vectors",
+    devices=None,
 ) -> float:
     """Free energy of `system` at `temperature` (reference hamiltonian.py:254-321).
 
@@ -147,6 +155,12 @@ def free_energy(
     gap_surrogate  at T = 0 with the Chebyshev method and no explicit `moments`: expand f at
              T = gap/20 instead (gap from `lowest_eigenvalues`), which differs from f_0 by ~1e-14 on a
              gapped spectrum but converges geometrically; False keeps the plain T = 0 coefficients
+    devices  optional list of GPU ordinals of THIS process, e.g. `devices=[0, 1, 2, 3]` or
+             `range(8)`: H is replicated on each, the start vectors (or the unit vectors of an exact
+             trace) are shared out over them, one host thread drives each GPU, and the moments are
+             summed on the host in device order - the single-process way to use a whole node from the
+             reference's call site `system.free_energy(T)` (no launcher, no communicator).  An ordinal
+             may repeat (`[0, 0]`: two mirrors on one GPU).  Not combined with `comm`.
     comm     optional `Communicator` (one process per GPU)
     decomposition  how the ranks of `comm` share the work:
              "vectors" - H replicated, each rank owns a contiguous share of the start
@@ -167,8 +181,15 @@ def free_energy(
             "(pairing terms with Δ_ij = -Δ_ji^T); use method='dense' for this matrix."
         )
 
+    if devices is not None:
+        devices = [int(d) for d in devices]
+        if comm is not None:
+            raise ValueError("free_energy: pass either devices=[...] (one process) or comm= (one process per GPU)")
+        if not devices:
+            raise ValueError("free_energy: devices=[] names no GPU")
+
     if method == "dense":
-        eps, _ = system._solver().eigh(vectors=False)
+        eps, _ = system._solver(device=None if devices is None else devices[0]).eigh(vectors=False)
         eps = eps[eps > 0]
         internal = -0.5 * np.sum(eps)
         entropy = 0.0 if temperature == 0 else np.sum(np.log1p(np.exp(-eps / temperature)))
@@ -179,6 +200,8 @@ def free_energy(
 
     if decomposition not in ("vectors", "slab"):
         raise RuntimeError(f"Decomposition '{decomposition}' is not supported")
+    if decomposition == "slab" and comm is None:
+        raise ValueError("decomposition='slab' shares the lattice planes out over the ranks of a communicator: pass comm=")
     scale = _scale_of(system) if scale is None else float(scale)
     series_temperature = temperature
     if temperature == 0 and moments is None and gap_surrogate and decomposition != "slab":
@@ -191,25 +214,56 @@ def free_energy(
         gap = _gap_estimate(system)
         if gap > 1e-9 * scale:
             series_temperature = gap / GAP_SURROGATE_RATIO
+    if series_temperature != temperature:
+        _warn(f"free_energy(0.0) on a {dim}x{dim} matrix is beyond the dense eigensolver: evaluated by the Chebyshev "
+              f"expansion at the surrogate temperature gap/{GAP_SURROGATE_RATIO:g} = {series_temperature:.3g} "
+              "(agrees with T = 0 to ~1e-14 relative on a gapped spectrum; method='dense' forces the reference's algorithm)")
     if moments is None:
         moments = cheb.moments_for_free_energy(scale, series_temperature)
     moments += moments & 1
+    chosen_for_the_caller = trace == "auto"
     if trace == "auto":
         trace = "exact" if dim <= EXACT_TRACE_LIMIT else "stochastic"
 
     if decomposition == "slab" and comm is not None:
         solver = _slab_solver(system, comm)
         steps = moments // 2
+        if temperature == 0 and series_temperature == 0:
+            _warn("free_energy(0.0, decomposition='slab') uses the plain T = 0 series (|ε| is not analytic at 0: "
+                  "~1e-8 at 4096 moments): the gap-sized surrogate temperature needs the whole matrix on one GPU; "
+                  "pass moments= or a small positive temperature for more digits")
         if trace == "exact":
-            d, e = solver.dots_unit(scale, steps, _electron_rows(dim))
-            total = 0.5  # the hole rows contribute the same again (see _electron_rows)
-        elif trace == "stochastic":
+            # rows in slices, as _unit_moment_sum does: the (steps x rows) tables stay within ~128 MB
+            rows = _electron_rows(dim)
+            width = max(64, ((1 << 23) // max(1, steps)) // 64 * 64)
+            mu_local = np.zeros(moments)
+            for lo in range(0, len(rows), width):
+                d, e = solver.dots_unit(scale, steps, rows[lo : lo + width])
+                mu_local += cheb.dots_to_moments(d, e).sum(axis=1)
+            mu = comm.allreduce_sum(mu_local) / 0.5  # the hole rows contribute the same again (see _electron_rows)
+            return cheb.free_energy_series(mu, scale, series_temperature, damping=damping)
+        if trace == "stochastic":
             kind = {"rademacher": VEC_RADEMACHER, "z4": VEC_Z4}[vector_kind]
             total = 64 if vectors is None else int(vectors)
             d, e = solver.dots_random(scale, steps, total, seed=seed, first_id=0, kind=kind)
         else:
             raise RuntimeError(f"Trace mode '{trace}' is not supported")
         mu = comm.allreduce_sum(cheb.dots_to_moments(d, e).sum(axis=1)) / total
+        return cheb.free_energy_series(mu, scale, series_temperature, damping=damping)
+
+    if devices is not None:
+        if trace == "exact":
+            mu = 2.0 * _unit_moment_sum_devices(system, scale, moments, _electron_rows(dim), devices)
+        elif trace == "stochastic":
+            kind = {"rademacher": VEC_RADEMACHER, "z4": VEC_Z4}[vector_kind]
+            total = 64 if vectors is None else int(vectors)
+            d, e = dots_random_devices(system, scale, moments // 2, total, devices, seed=seed, kind=kind)
+            mu = cheb.dots_to_moments(d, e).sum(axis=1) / total
+            if chosen_for_the_caller:
+                _warn(f"free_energy() on a {dim}x{dim} matrix is a stochastic-trace estimate from {total} random "
+                      "vectors (4N beyond the exact trace); free_energy_stochastic() reports its standard error")
+        else:
+            raise RuntimeError(f"Trace mode '{trace}' is not supported")
         return cheb.free_energy_series(mu, scale, series_temperature, damping=damping)
 
     solver = system._solver()
@@ -225,11 +279,79 @@ def free_energy(
         kind = {"rademacher": VEC_RADEMACHER, "z4": VEC_Z4}[vector_kind]
         total = 64 if vectors is None else int(vectors)
         first, count = shard_vectors(total, comm)
-        mu = solver.moments_random(scale, moments, count, seed=seed, first_id=first, kind=kind, comm=comm)
-        mu = mu / total
+        if comm is None and chosen_for_the_caller:
+            # the caller asked for "the free energy" and gets an estimate: say so, with its standard error
+            d, e = solver.dots_random(scale, moments // 2, count, seed=seed, first_id=first, kind=kind)
+            per_vector_mu = cheb.dots_to_moments(d, e)
+            coeff = cheb.chebyshev_coefficients(lambda x: cheb._f_density(scale * x, series_temperature), moments)
+            per_vector = coeff @ per_vector_mu
+            sigma = float(np.std(per_vector, ddof=1) / np.sqrt(total)) if total > 1 else float("nan")
+            _warn(f"free_energy() on a {dim}x{dim} matrix is beyond the exact trace (4N <= {EXACT_TRACE_LIMIT}): this is a "
+                  f"stochastic-trace estimate from {total} random vectors, standard error {sigma:.3g} "
+                  f"({abs(sigma / np.mean(per_vector)):.1e} relative; seed={seed}).  Pass trace='stochastic' to "
+                  "accept silently, vectors=... for more, or trace='exact'.")
+            mu = per_vector_mu.sum(axis=1) / total
+        else:
+            if chosen_for_the_caller:
+                _warn(f"free_energy() on a {dim}x{dim} matrix is a stochastic-trace estimate from {total} random "
+                      "vectors (4N beyond the exact trace); free_energy_stochastic() reports its standard error")
+            mu = solver.moments_random(scale, moments, count, seed=seed, first_id=first, kind=kind, comm=comm)
+            mu = mu / total
     else:
         raise RuntimeError(f"Trace mode '{trace}' is not supported")
     return cheb.free_energy_series(mu, scale, series_temperature, damping=damping)
+
+
+def _device_mirrors(system, devices):
+    """One device mirror of `system` per entry of `devices` (created here, on the calling thread)."""
+    return [system._solver(("devices", slot), device=d) for slot, d in enumerate(devices)]
+
+
+def _shares(total: int, parts: int):
+    """Contiguous shares [(first, count), ...] of `total` items over `parts` owners, empty ones dropped."""
+    base, extra = divmod(total, parts)
+    out, first = [], 0
+    for k in range(parts):
+        count = base + (1 if k < extra else 0)
+        if count:
+            out.append((k, first, count))
+        first += count
+    return out
+
+
+def dots_random_devices(system, scale: float, steps: int, vectors: int, devices, *, seed: int = 0,
+                        kind: int = VEC_RADEMACHER):
+    """Recurrence dots (d, e), each (steps, vectors), of start vectors 0..vectors-1 computed on
+    several GPUs of this process: vector ids are shared out contiguously, one host thread per GPU
+    (the library is thread safe per handle and ctypes releases the GIL), columns put back in id
+    order.  Start vectors are functions of (seed, id, element) alone, so the columns are
+    bit-identical to those of a single-GPU call."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    mirrors = _device_mirrors(system, devices)
+    jobs = _shares(vectors, len(mirrors))
+    with ThreadPoolExecutor(len(jobs)) as pool:
+        parts = list(pool.map(lambda job: mirrors[job[0]].dots_random(scale, steps, job[2], seed=seed, first_id=job[1], kind=kind), jobs))
+    return np.concatenate([p[0] for p in parts], axis=1), np.concatenate([p[1] for p in parts], axis=1)
+
+
+def _unit_moment_sum_devices(system, scale: float, moments: int, rows: np.ndarray, devices) -> np.ndarray:
+    """Σ over `rows` of the unit-vector moments with the rows shared out over several GPUs."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    mirrors = _device_mirrors(system, devices)
+    jobs = _shares(len(rows), len(mirrors))
+    step = max(64, ((1 << 24) // max(1, moments)) // 64 * 64)  # <= ~128 MB of moments per slice on the host
+
+    def run(job):
+        slot, first, count = job
+        total = np.zeros(moments)
+        for lo in range(first, first + count, step):
+            total += mirrors[slot].moments_unit(scale, moments, rows[lo : min(lo + step, first + count)]).sum(axis=1)
+        return total
+
+    with ThreadPoolExecutor(len(jobs)) as pool:
+        return np.sum(list(pool.map(run, jobs)), axis=0)
 
 
 def free_energy_stochastic(system, temperature: float, *, moments: int | None = None, vectors: int = 64,

@@ -227,6 +227,13 @@ class DeviceSolver:
         )
         return w, z.T
 
+    def hermiticity_defect(self) -> float:
+        """max |H - H^†| over the stored entries of the uploaded matrix (device-side twin of the
+        check at reference hamiltonian.py:121-122)."""
+        out = np.zeros(1)
+        backend.check(self._lib.bdg_hermiticity_defect(self._handle, backend.as_f64p(out)))
+        return float(out[0])
+
     def set_lanes_per_row(self, lanes: int) -> None:
         backend.check(self._lib.bdg_set_lanes_per_row(self._handle, lanes))
 

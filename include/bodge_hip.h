@@ -61,7 +61,8 @@ typedef struct bdg_perf {
     int32_t dict_blocks;   /* >0 = dictionary form: number of distinct blocks in the table   */
     int32_t steps_per_launch; /* 2 = two recurrence steps per sweep of the vectors (lattice stencils), else 1 */
     int32_t rolling;       /* 1 = 3-D stencil kernel with the x-neighbours in registers (cheb_roll3) */
-    int32_t reserved;
+    int32_t dict_skipped;  /* why the matrix has no block dictionary: 0 = it has one, 1 = more than 256
+                              distinct blocks, 2 = more than 2^24 block columns, 3 = BODGE_AMD_DICT=0 */
 } bdg_perf;
 
 const char* bdg_last_error(void);
@@ -172,6 +173,13 @@ int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t v
  * limit 4*nb <= 46000.
  */
 int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out);
+
+/*
+ * max |H - H^†| over the stored entries of the uploaded matrix, computed on the device: the
+ * Hermiticity test the reference makes on the host when a `with` block closes
+ * (hamiltonian.py:121-122, `abs(M - M.getH()).max() > 1e-6` -> RuntimeError).  Whole matrices only.
+ */
+int bdg_hermiticity_defect(bdg_system* sys, double* defect_out);
 
 /*
  * Optional: start reading the rocSOLVER / rocBLAS shared objects into the page cache on a

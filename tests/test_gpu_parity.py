@@ -841,3 +841,98 @@ def test_lanczos_run_is_ended_by_any_other_use_of_the_handle(api, solver_cls):
         dev.lanczos_begin(2, seed=1, max_iter=40)
         again = dev.lanczos_advance(5)
     assert np.array_equal(first[0], again[0]) and np.array_equal(first[1], again[1])
+
+
+def test_hermiticity_check_on_the_device(api, solver_cls, monkeypatch):
+    """f3: the Hermiticity test of a closing `with` block (ref hamiltonian.py:121-122) made on the
+    GPU.  Same criterion, same exception: Hermitian fills pass with the host's defect value,
+    the reference's non-Hermitian cases (ref tests/test_hamiltonian.py:17-57: a hopping term
+    without its partner, a non-Hermitian on-site term) raise RuntimeError, a repaired matrix
+    passes again, and a block whose partner is an all-zero (dropped) block is caught."""
+    from bodge_amd import hamiltonian
+
+    monkeypatch.setattr(hamiltonian, "DEVICE_HERMITICITY_MIN_BLOCKS", 1)  # every `with` goes to the device
+    system = systems.random_periodic(api)  # dense complex terms on sites, bonds and periodic edges
+    host = system._hermiticity_defect()
+    device = system._solver().hermiticity_defect()
+    assert device < 1e-12 and abs(device - host) < 1e-15
+    rng = np.random.default_rng(3)
+    lattice = system.lattice
+    with pytest.raises(RuntimeError, match="not Hermitian"):
+        with system as (H, Δ):
+            H[(0, 1, 2), (0, 1, 3)] = rng.random((2, 2)) + 1j * rng.random((2, 2))  # partner keeps its old value
+    assert system._solver().hermiticity_defect() > 1e-3
+    with pytest.raises(RuntimeError):
+        with system as (H, Δ):
+            H[(2, 2, 2), (2, 2, 2)] = np.array([[1.0, 2.0], [0.5j, 1.0]])  # non-Hermitian on-site term
+    with system as (H, Δ):  # repair both
+        t = 0.3 * api.σ0 + 0.1 * api.σ1
+        H[(0, 1, 2), (0, 1, 3)] = t
+        H[(0, 1, 3), (0, 1, 2)] = t
+        H[(2, 2, 2), (2, 2, 2)] = 0.5 * api.σ3
+    assert system._solver().hermiticity_defect() < 1e-12
+    # a lone block: the open chain has no stored (j, i) partner once that block is all zero
+    chain = api.Hamiltonian(api.CubicLattice((6, 1, 1)))
+    with pytest.raises(RuntimeError):
+        with chain as (H, Δ):
+            for i in chain.lattice.sites():
+                H[i, i] = 1.0 * api.σ0
+            H[(1, 0, 0), (2, 0, 0)] = -1.0 * api.σ0
+            H[(2, 0, 0), (1, 0, 0)] = 0.0 * api.σ0
+
+
+def test_free_energy_over_several_devices_of_one_process(api, golden):
+    """`free_energy(..., devices=[...])`: H replicated per listed GPU, start vectors shared out, one
+    host thread per GPU, moments summed on the host (SURVEY §8b export 1, §5 `devices=`).  On a
+    one-GPU box the list repeats ordinal 0 - two, then three, independent mirrors of the matrix.
+    Per-vector results must be bit-identical to the single-mirror call (start vectors depend on
+    (seed, id, element) only), F equal to round-off, exact traces match the reference's goldens."""
+    from bodge_amd import observables
+
+    system = _build(api, "swave20_zeeman")
+    scale = observables._scale_of(system)
+    single = system._solver().dots_random(scale, 24, 8, seed=11)
+    for devices in ([0, 0], [0, 0, 0], [0]):
+        split = observables.dots_random_devices(system, scale, 24, 8, devices, seed=11)
+        assert np.array_equal(split[0], single[0]) and np.array_equal(split[1], single[1]), devices
+    f_single = system.free_energy(0.5, method="chebyshev", trace="stochastic", vectors=8, moments=128, seed=11)
+    f_split = system.free_energy(0.5, method="chebyshev", trace="stochastic", vectors=8, moments=128, seed=11,
+                                 devices=[0, 0])
+    assert np.isclose(f_split, f_single, rtol=1e-13, atol=0)
+    exact = system.free_energy(0.5, method="chebyshev", trace="exact", devices=[0, 0, 0])
+    assert np.isclose(exact, golden.free_energy("swave20_zeeman", 0.5), rtol=1e-10, atol=0)
+    dense = system.free_energy(0.1, method="dense", devices=[0])
+    assert np.isclose(dense, golden.free_energy("swave20_zeeman", 0.1), rtol=1e-10, atol=0)
+    with pytest.raises(ValueError):
+        system.free_energy(0.5, devices=[])
+    with pytest.raises(ValueError):
+        system.free_energy(0.5, devices=[0], comm=object())
+    with pytest.raises(ValueError):
+        system.free_energy(0.5, method="chebyshev", decomposition="slab")  # slabs need a communicator
+    with pytest.raises((ValueError, RuntimeError)):
+        system.free_energy(0.5, method="chebyshev", devices=[99])  # no such GPU
+
+
+def test_default_call_warns_when_it_is_not_the_reference_computation(api, monkeypatch):
+    """A caller of plain `free_energy(T)` must be told when the answer is not the reference's
+    dense computation: a stochastic-trace estimate (with its standard error) beyond the exact
+    trace, or the surrogate-temperature expansion at T = 0 beyond the dense eigensolver.  Explicit
+    requests for those routes stay silent."""
+    import warnings
+
+    from bodge_amd import observables
+
+    system = _build(api, "swave20_zeeman")
+    monkeypatch.setattr(observables, "EXACT_TRACE_LIMIT", 1000)  # make 4N = 1600 "large"
+    monkeypatch.setattr(observables, "DENSE_AUTO_LIMIT_T0", 1000)
+    with pytest.warns(RuntimeWarning, match="stochastic-trace estimate from 64 random vectors, standard error"):
+        value = system.free_energy(0.5)
+    assert abs(value / system.free_energy(0.5, method="dense") - 1) < 5e-3
+    with warnings.catch_warnings():
+        warnings.simplefilter("error")
+        system.free_energy(0.5, method="chebyshev", trace="stochastic")
+        system.free_energy(0.5, method="dense")
+    monkeypatch.setattr(observables, "DENSE_AUTO_LIMIT", 1000)
+    with pytest.warns(RuntimeWarning, match="surrogate temperature"):
+        zero = system.free_energy(0.0, trace="exact")
+    assert abs(zero / system.free_energy(0.0, method="dense") - 1) < 1e-10
