@@ -525,29 +525,6 @@ def test_diagonalize_matches_reference(api, golden, name):
         system.diagonalize(format="foo")
 
 
-@pytest.mark.parametrize("name", ["complex235", "barrier"])
-def test_rocsolver_route_forced_on_small_systems(api, golden, monkeypatch, name):
-    """The library route taken for 4N > 2048, forced here on small systems: dsyevd when imag(H) = 0
-    (barrier), zheevd otherwise (complex235).  Handing a real matrix to the Hermitian D&C driver
-    (never done by default) shows its NaN-eigenvector defect; the default driver choice then
-    notices on the device and repairs with the Jacobi driver."""
-    monkeypatch.setenv("BODGE_AMD_EIGH", "evd")
-    system = _build(api, name)
-    dense = np.asarray(system.matrix("dense"))
-    vals, vecs = system.diagonalize(format="raw")
-    assert np.allclose(vals, golden.eigenvalues(name), rtol=0, atol=1e-10)
-    assert np.isfinite(vecs).all() and np.allclose(dense @ vecs, vecs * vals, atol=1e-9)
-    if name == "barrier":
-        monkeypatch.setenv("BODGE_AMD_EIGH_REAL", "0")
-        vals1, vecs1 = system.diagonalize(format="raw")
-        assert np.allclose(vals1, golden.eigenvalues(name), rtol=0, atol=1e-10)
-        defect = bool(np.isnan(vecs1).any())  # seen on ROCm 7.2; a fixed library passes too
-        monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")
-        vals2, vecs2 = system.diagonalize(format="raw")
-        assert np.isfinite(vecs2).all() and np.allclose(dense @ vecs2, vecs2 * vals2, atol=1e-9)
-        assert defect or np.allclose(dense @ vecs1, vecs1 * vals1, atol=1e-9)
-
-
 def test_single_site_and_single_line_systems(api):
     """Smallest inputs: a 1x1x1 lattice (one 4x4 block; every axis degenerate, so the self-"edges"
     merge into the diagonal block, ref lattice.py:190-195) and a 1x1xL chain, through every observable."""
