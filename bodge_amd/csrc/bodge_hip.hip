@@ -1654,6 +1654,96 @@ int lanczos_begin(bdg_system* sys, int n_vectors, const StartSpec& start, int ma
     return BDG_OK;
 }
 
+// One iteration j of the process (steps a-c above); W_j is in lz->w_cur on entry, W_{j+1} on exit.
+int lanczos_iterate(bdg_system* sys, LanczosState* lz, bdg::StepArgs& args, int j) {
+    Batch& b = lz->batch;
+    hipStream_t st = sys->stream;
+    args.cur = lz->w_cur;  // a. U = H v_j
+    args.prev = lz->work.ptr;
+    args.col_coef = lz->z.coef_a;
+    args.col_pscale = lz->z.pscale_a;
+    b.plan.kernel<<<b.plan.grid, bdg::kBlockThreads, b.plan.lds_bytes, st>>>(args);
+    args.cur = lz->work.ptr;  // b. R = H U - beta_j v_{j-1}, alpha_j = |U|^2
+    args.prev = lz->w_prev;
+    args.col_coef = lz->z.coef_b;
+    args.col_pscale = lz->z.pscale_b;
+    b.plan.kernel<<<b.plan.grid, bdg::kBlockThreads, b.plan.lds_bytes, st>>>(args);
+    bdg::reduce_partials<<<1, 256, 0, st>>>(sys->partial.ptr, lz->sums.ptr, b.plan.grid, (int)b.width);
+    bdg::lanczos_scalars<<<1, 128, 0, st>>>(lz->z, lz->sums.ptr, lz->cols, j, 1);
+    // c. W_{j+1} = R - alpha_j v_j, beta_{j+1}
+    if (int rc = lanczos_norms(sys, lz, lz->w_prev, lz->w_cur, true)) return rc;
+    bdg::lanczos_scalars<<<1, 128, 0, st>>>(lz->z, lz->sums.ptr, lz->cols, j + 1, 0);
+    std::swap(lz->w_cur, lz->w_prev);
+    return BDG_OK;
+}
+
+// Second pass: repeat the first n_iter iterations of a freshly begun process (same start vectors:
+// the Lanczos vectors are reproduced bit for bit) and accumulate, for every level l and column c,
+//   y_{l,c} = Σ_j coef[j][l][c] v_j^{(c)}
+// i.e. the Ritz vectors whose tridiagonal coordinates the host computed from the first pass.
+// y_out[l][c] is a site-major complex vector of 4*nb entries.
+int lanczos_ritz_vectors(bdg_system* sys, int n_iter, int n_levels, const double* coef, double* y_out) {
+    LanczosState* lz = static_cast<LanczosState*>(sys->lanczos);
+    if (!lz) return fail(BDG_EINVAL, "bdg_lanczos_begin has not been called");
+    if (lz->iter != 0) return fail(BDG_EINVAL, "the Ritz-vector pass starts from a freshly begun process");
+    if (n_iter < 1 || n_iter > lz->max_iter || n_levels < 1 || n_levels > 64)
+        return fail(BDG_EINVAL, "bad iteration or level count");
+    HIP_TRY(hipSetDevice(sys->device));
+    Batch& b = lz->batch;
+    hipStream_t st = sys->stream;
+    const size_t cols = (size_t)lz->cols, count = b.vec_count;
+    DeviceBuffer<double2> y, host_order;
+    DeviceBuffer<double> dev_coef;
+    auto body = [&]() -> int {
+        if (int rc = y.reserve((size_t)n_levels * count)) return rc;
+        if (int rc = host_order.reserve((size_t)4 * sys->nb)) return rc;
+        if (int rc = dev_coef.reserve((size_t)n_iter * n_levels * cols)) return rc;
+        // coefficients padded to the buffer's column count (inactive columns: 0)
+        std::vector<double> padded((size_t)n_iter * n_levels * cols, 0.0);
+        for (int j = 0; j < n_iter; ++j)
+            for (int l = 0; l < n_levels; ++l)
+                for (int c = 0; c < lz->n_active; ++c)
+                    padded[((size_t)j * n_levels + l) * cols + c] = coef[((size_t)j * n_levels + l) * lz->n_active + c];
+        HIP_TRY(hipMemcpyAsync(dev_coef.ptr, padded.data(), sizeof(double) * padded.size(), hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemsetAsync(y.ptr, 0, sizeof(double2) * n_levels * count, st));
+        bdg::StepArgs args = b.args;
+        args.partial = sys->partial.ptr;
+        const int grid = (int)std::min<size_t>(2048, (count + 255) / 256);
+        for (int j = 0; j < n_iter; ++j) {
+            const double* beta_j = lz->z.beta_hist + (size_t)j * cols;
+            const double* coef_j = dev_coef.ptr + (size_t)j * n_levels * cols;
+            if (b.real)
+                bdg::lanczos_accumulate<2><<<grid, 256, 0, st>>>(lz->w_cur, beta_j, coef_j, n_levels, (int)cols, b.rl,
+                                                                 (int64_t)count, y.ptr);
+            else
+                bdg::lanczos_accumulate<1><<<grid, 256, 0, st>>>(lz->w_cur, beta_j, coef_j, n_levels, (int)cols, b.rl,
+                                                                 (int64_t)count, y.ptr);
+            if (int rc = lanczos_iterate(sys, lz, args, j)) return rc;
+        }
+        HIP_TRY(hipGetLastError());
+        lz->iter = n_iter;
+        const size_t n = (size_t)4 * sys->nb;
+        const int cgrid = (int)std::min<size_t>(4096, (n + 255) / 256);
+        for (int l = 0; l < n_levels; ++l)
+            for (int c = 0; c < lz->n_active; ++c) {
+                const double2* src = y.ptr + (size_t)l * count;
+                if (b.real)
+                    bdg::sitemajor_from_planar_real<<<cgrid, 256, 0, st>>>(src, host_order.ptr, sys->nb, b.rl, c);
+                else
+                    bdg::sitemajor_from_planar<<<cgrid, 256, 0, st>>>(src, host_order.ptr, sys->nb, b.rl, c);
+                HIP_TRY(hipMemcpyAsync(y_out + 2 * n * ((size_t)l * lz->n_active + c), host_order.ptr, sizeof(double2) * n,
+                                       hipMemcpyDeviceToHost, st));
+            }
+        HIP_TRY(hipStreamSynchronize(st));
+        return BDG_OK;
+    };
+    const int rc = body();
+    y.release();
+    host_order.release();
+    dev_coef.release();
+    return rc;
+}
+
 int lanczos_advance(bdg_system* sys, int n_iter, double* alpha_out, double* beta_out) {
     LanczosState* lz = static_cast<LanczosState*>(sys->lanczos);
     if (!lz) return fail(BDG_EINVAL, "bdg_lanczos_begin has not been called");
@@ -1665,24 +1755,8 @@ int lanczos_advance(bdg_system* sys, int n_iter, double* alpha_out, double* beta
     bdg::StepArgs args = b.args;
     args.partial = sys->partial.ptr;
     const int first = lz->iter;
-    for (int j = first; j < first + n_iter; ++j) {
-        args.cur = lz->w_cur;  // a. U = H v_j
-        args.prev = lz->work.ptr;
-        args.col_coef = lz->z.coef_a;
-        args.col_pscale = lz->z.pscale_a;
-        b.plan.kernel<<<b.plan.grid, bdg::kBlockThreads, b.plan.lds_bytes, st>>>(args);
-        args.cur = lz->work.ptr;  // b. R = H U - beta_j v_{j-1}, alpha_j = |U|^2
-        args.prev = lz->w_prev;
-        args.col_coef = lz->z.coef_b;
-        args.col_pscale = lz->z.pscale_b;
-        b.plan.kernel<<<b.plan.grid, bdg::kBlockThreads, b.plan.lds_bytes, st>>>(args);
-        bdg::reduce_partials<<<1, 256, 0, st>>>(sys->partial.ptr, lz->sums.ptr, b.plan.grid, (int)b.width);
-        bdg::lanczos_scalars<<<1, 128, 0, st>>>(lz->z, lz->sums.ptr, lz->cols, j, 1);
-        // c. W_{j+1} = R - alpha_j v_j, beta_{j+1}
-        if (int rc = lanczos_norms(sys, lz, lz->w_prev, lz->w_cur, true)) return rc;
-        bdg::lanczos_scalars<<<1, 128, 0, st>>>(lz->z, lz->sums.ptr, lz->cols, j + 1, 0);
-        std::swap(lz->w_cur, lz->w_prev);
-    }
+    for (int j = first; j < first + n_iter; ++j)
+        if (int rc = lanczos_iterate(sys, lz, args, j)) return rc;
     HIP_TRY(hipGetLastError());
     lz->iter += n_iter;
     const size_t cols = (size_t)lz->cols;
@@ -2505,6 +2579,11 @@ int bdg_lanczos_begin(bdg_system* sys, int32_t n_vectors, uint64_t seed, uint64_
 int bdg_lanczos_advance(bdg_system* sys, int32_t n_iter, double* alpha_out, double* beta_out) {
     if (!sys || !alpha_out || !beta_out) return fail(BDG_EINVAL, "null argument");
     return lanczos_advance(sys, n_iter, alpha_out, beta_out);
+}
+
+int bdg_lanczos_ritz_vectors(bdg_system* sys, int32_t n_iter, int32_t n_levels, const double* coef, double* y_out) {
+    if (!sys || !coef || !y_out) return fail(BDG_EINVAL, "null argument");
+    return lanczos_ritz_vectors(sys, n_iter, n_levels, coef, y_out);
 }
 
 int bdg_perf_query(bdg_system* sys, bdg_perf* out) {

@@ -954,6 +954,43 @@ __global__ void lanczos_scalars(LanczosScalars z, const double* __restrict__ sum
     }
 }
 
+// Ritz-vector accumulation (second pass of the Lanczos process): for every level l < n_levels
+//   y_l += (coef[l][col] / beta[col]) * w      (w = beta_j v_j, the unnormalised Lanczos vector)
+// over the whole buffers; y holds n_levels buffers of `count` payloads back to back.
+template <int PER_LANE>
+__global__ __launch_bounds__(256) void lanczos_accumulate(const double2* __restrict__ w,
+                                                          const double* __restrict__ beta,
+                                                          const double* __restrict__ coef, int n_levels,
+                                                          int cols, int rl, int64_t count,
+                                                          double2* __restrict__ y) {
+    const int r = threadIdx.x % rl;  // fixed per thread: 256 and the grid stride are multiples of rl
+    const int c0 = PER_LANE * r, c1 = PER_LANE * r + (PER_LANE - 1);
+    const double b0 = beta[c0], b1 = beta[c1];
+    const double i0 = b0 > 0.0 ? 1.0 / b0 : 0.0, i1 = b1 > 0.0 ? 1.0 / b1 : 0.0;
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < count;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const double2 v = w[idx];
+        for (int l = 0; l < n_levels; ++l) {
+            const double f0 = coef[(size_t)l * cols + c0] * i0, f1 = coef[(size_t)l * cols + c1] * i1;
+            if (f0 == 0.0 && f1 == 0.0) continue;
+            double2 acc = y[(size_t)l * count + idx];
+            acc.x = fma(f0, v.x, acc.x);
+            acc.y = fma(f1, v.y, acc.y);
+            y[(size_t)l * count + idx] = acc;
+        }
+    }
+}
+
+// planar [4][nb][rl] real payloads (vectors 2r, 2r+1) -> site-major complex [nb][4] of vector `col`
+__global__ void sitemajor_from_planar_real(const double2* __restrict__ planar, double2* __restrict__ x,
+                                           int64_t nb, int rl, int col) {
+    for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < 4 * nb;
+         idx += (int64_t)gridDim.x * blockDim.x) {
+        const double2 v = planar[vslot((int)(idx & 3), (size_t)(idx >> 2), col >> 1, (size_t)nb, rl)];
+        x[idx] = make_double2((col & 1) ? v.y : v.x, 0.0);
+    }
+}
+
 // per-column |v|^2 over the owned rows (start of the process): partial[block][column]
 template <int PER_LANE>
 __global__ __launch_bounds__(256) void column_norms(const double2* __restrict__ v, int64_t nb, int64_t ncols,

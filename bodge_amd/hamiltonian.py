@@ -324,6 +324,15 @@ class Hamiltonian:
 
         return lowest_eigenvalues(self, k, **options)
 
+    def lowest_eigenpairs(self, k: int = 1, **options):
+        """The k lowest positive eigenvalues with multiplicities and their eigenvectors (layouts of
+        `diagonalize`), by two passes of the device Lanczos process - `E, v = diagonalize()` cut to
+        its first k states, for lattices where the dense solve does not fit.  Not part of the
+        reference API; see `bodge_amd.observables.lowest_eigenpairs`."""
+        from .observables import lowest_eigenpairs
+
+        return lowest_eigenpairs(self, k, **options)
+
     def ldos(self, site: Coord, energies, **options) -> Matrix:
         """Local density of states at `site` for the given energies (ref :324-387)."""
         from .observables import ldos

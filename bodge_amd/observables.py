@@ -486,6 +486,128 @@ def lowest_eigenvalues(system, k: int = 1, *, tol: float = 1e-6, vectors: int = 
     return np.min(previous, axis=0)
 
 
+def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8, seed: int = 0,
+                      max_iter: int = 20000, check_every: int = 50, format: str = "reshape"):
+    """The k lowest positive eigenvalues of H **with their multiplicities** and orthonormal
+    eigenvectors, for systems where the dense `diagonalize()` is out of reach: what
+    `E, v = system.diagonalize()` followed by `E[:k], v[:k]` gives the reference's callers
+    (e.g. ref tests/test_physics.py:105), same layouts (ref hamiltonian.py:235-248: "raw" ->
+    (E (k,), X (4N, k)), "reshape" -> (E, v[n, site, α])).
+
+    Two passes of the device Lanczos process on H² with `vectors` independent start vectors:
+      1. α, β as in `lowest_eigenvalues`; at every checkpoint the host diagonalises the tridiagonal
+         matrices and records, per start vector and level, the Ritz coordinates at the FIRST
+         checkpoint where the residual estimate β_m |s_m| has dropped below tol·ε (before plain
+         Lanczos starts to produce ghost copies of a converged level);
+      2. the process is repeated (same seed: the Lanczos vectors are reproduced bit for bit) and
+         the Ritz vectors y are accumulated on the device (`bdg_lanczos_ritz_vectors`).
+    y lies in the eigenspace of H² for ε², i.e. in span(eigenvectors of H for +ε and −ε);
+    (H + ε) y projects onto the +ε part.  The `vectors` candidates of a level span its whole
+    eigenspace (up to `vectors` dimensions): their Gram matrix gives the multiplicity, and a
+    Rayleigh-Ritz step with H inside that span the final pairs.  Residuals ‖Hv − εv‖ come out at
+    about `tol`; eigenvalues, being Rayleigh quotients, at about tol².
+    """
+    import warnings
+
+    from scipy.linalg import eigh_tridiagonal
+
+    if k < 1:
+        raise ValueError("k must be at least 1")
+    if format not in ("raw", "reshape"):
+        raise RuntimeError(f"Eigenstate format '{format}' is not yet supported.")
+    solver = system._solver()
+    dim = system.shape[0]
+    levels = k  # k distinct levels hold at least k states
+    solver.lanczos_begin(vectors, seed=seed, max_iter=max_iter)
+    alpha = np.zeros((0, vectors))
+    beta = np.zeros((0, vectors))
+    # per start vector: converged Ritz pairs (θ, m, s) in the order they converged, identified by
+    # VALUE (the position of a Ritz value in the sorted list changes while lower levels are still
+    # emerging); later ghost copies of a recorded value are ignored
+    records: list[list[tuple[float, int, np.ndarray]]] = [[] for _ in range(vectors)]
+    targets = None
+    while alpha.shape[0] < max_iter:
+        a, b = solver.lanczos_advance(min(check_every, max_iter - alpha.shape[0]))
+        alpha, beta = np.vstack([alpha, a]), np.vstack([beta, b])
+        m = alpha.shape[0]
+        scale2 = float(alpha.max())  # ~ |H|^2
+        same = 1e-9 * scale2         # two Ritz values this close are one level (or a ghost of it)
+        want = min(m, 4 * levels + 8)
+        pending = []                 # per start vector: lowest Ritz value that is neither converged nor a ghost
+        for c in range(vectors):
+            theta, s = eigh_tridiagonal(alpha[:, c], beta[: m - 1, c], select="i", select_range=(0, want - 1))
+            residual = beta[m - 1, c] * np.abs(s[-1, :])
+            lowest_open = np.inf
+            for idx in range(want):
+                known = any(abs(theta[idx] - t) <= same for t, _, _ in records[c])
+                eps = np.sqrt(max(theta[idx], 0.0))
+                if not known and residual[idx] <= tol * max(eps, 1e-6 * np.sqrt(scale2)):
+                    records[c].append((float(theta[idx]), m, s[:, idx].copy()))
+                    known = True
+                if not known:
+                    lowest_open = min(lowest_open, theta[idx])
+            pending.append(lowest_open)
+        # distinct converged levels over all start vectors, lowest first
+        merged: list[float] = []
+        for t in sorted(t for rec in records for t, _, _ in rec):
+            if not merged or t - merged[-1] > same:
+                merged.append(t)
+        if len(merged) >= levels:
+            wanted = merged[:levels]
+            complete = all(any(abs(t - w) <= same for t, _, _ in rec) for rec in records for w in wanted)
+            nothing_below = all(p > wanted[-1] + same for p in pending)  # no lower level still emerging anywhere
+            if complete and nothing_below:
+                targets = wanted
+                break
+    if targets is None:
+        merged = []
+        for t in sorted(t for rec in records for t, _, _ in rec):
+            if not merged or t - merged[-1] > 1e-9 * float(alpha.max()):
+                merged.append(t)
+        targets = merged[:levels]
+        if not targets:
+            raise RuntimeError(f"Lanczos converged no level to {tol:g} in {max_iter} iterations")
+        warnings.warn(f"lowest_eigenpairs: only {len(targets)} of {levels} levels converged to {tol:g} in every start "
+                      f"vector after {alpha.shape[0]} iterations; returning what was found", RuntimeWarning)
+    levels = len(targets)
+    same = 1e-9 * float(alpha.max())
+    chosen = [[next(((m, s) for t, m, s in rec if abs(t - w) <= same), None) for w in targets] for rec in records]
+    n_iter = max(entry[0] for row in chosen for entry in row if entry is not None)
+    coef = np.zeros((n_iter, levels, vectors))
+    for c, row in enumerate(chosen):
+        for l, entry in enumerate(row):
+            if entry is not None:
+                coef[: entry[0], l, c] = entry[1]
+    solver.lanczos_begin(vectors, seed=seed, max_iter=max_iter)
+    ritz = solver.lanczos_ritz_vectors(coef)  # (levels, vectors, 4N)
+
+    values, states = [], []
+    for l in range(levels):
+        eps = float(np.sqrt(max(targets[l], 0.0)))
+        # candidates in the +eps eigenspace of H, then an orthonormal basis of what they span
+        have = [c for c in range(vectors) if chosen[c][l] is not None]
+        cand = np.stack([solver.spmv(ritz[l, c]) + eps * ritz[l, c] for c in have])
+        cand /= np.maximum(np.linalg.norm(cand, axis=1, keepdims=True), 1e-300)
+        gram = cand.conj() @ cand.T
+        weight, mix = np.linalg.eigh(gram)
+        keep = weight > 1e-4 * weight[-1]
+        basis = (mix[:, keep] / np.sqrt(weight[keep])).T.conj() @ cand  # rows orthonormal... (rank = multiplicity)
+        basis = np.linalg.qr(basis.T)[0].T  # tidy up round-off
+        h_basis = np.stack([solver.spmv(v) for v in basis])
+        small = basis.conj() @ h_basis.T
+        energy, rot = np.linalg.eigh((small + small.conj().T) / 2)
+        final = rot.T @ basis  # eigenvectors of H restricted to the span (rows)
+        for e, v in zip(energy, final):
+            values.append(float(e))
+            states.append(v / np.linalg.norm(v))
+    order = np.argsort(values)[:k]
+    vals = np.array([values[i] for i in order])
+    vecs = np.stack([states[i] for i in order])  # (k, 4N)
+    if format == "raw":
+        return vals, np.ascontiguousarray(vecs.T)
+    return vals, vecs.reshape(len(order), dim // 4, 4)
+
+
 # ------------------------------------------------------------------------ LDOS
 def ldos(system, site, energies, *, moments: int | None = None, scale: float | None = None,
          digits: float = 12.0) -> np.ndarray:

@@ -213,6 +213,18 @@ class DeviceSolver:
         backend.check(self._lib.bdg_lanczos_advance(self._handle, n_iter, backend.as_f64p(alpha), backend.as_f64p(beta)))
         return alpha, beta
 
+    def lanczos_ritz_vectors(self, coef: np.ndarray) -> np.ndarray:
+        """Second pass of a freshly begun Lanczos process: `coef[j, l, r]` are the coordinates of
+        level l's Ritz vector of start vector r in the Lanczos basis; returns y[l, r, :] (4N complex)."""
+        n_vectors = getattr(self, "_lanczos_vectors", 0)
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        if not n_vectors or coef.ndim != 3 or coef.shape[2] != n_vectors:
+            raise ValueError("bodge_hip: coefficients must be (iterations, levels, start vectors of lanczos_begin)")
+        out = np.empty((coef.shape[1], n_vectors, self.dim), dtype=np.complex128)
+        backend.check(self._lib.bdg_lanczos_ritz_vectors(self._handle, coef.shape[0], coef.shape[1], backend.as_f64p(coef),
+                                                        backend.as_f64p(out.view(np.float64))))
+        return out
+
     def eigh(self, vectors: bool = True):
         """All eigenvalues ascending (and eigenvectors as columns): own Jacobi kernels up to 4N = 2048,
         rocSOLVER above (dsyevd when imag(H) = 0, else zheevd)."""

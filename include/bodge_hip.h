@@ -157,6 +157,16 @@ int bdg_cheb_diag_moments(bdg_system* sys, double scale, int32_t n_moments, int3
 int bdg_lanczos_begin(bdg_system* sys, int32_t n_vectors, uint64_t seed, uint64_t first_vec_id,
                       int32_t vec_kind, int32_t max_iter);
 int bdg_lanczos_advance(bdg_system* sys, int32_t n_iter, double* alpha_out, double* beta_out);
+/*
+ * Ritz vectors by a second pass: on a freshly begun process (same arguments as the first pass:
+ * the Lanczos vectors v_j are reproduced bit for bit) run n_iter iterations and accumulate
+ *   y[l][r] = sum_j coef[(j*n_levels + l)*n_vectors + r] * v_j^{(r)},   l < n_levels,
+ * the eigenvector estimates of H^2 whose coordinates in the Lanczos basis the caller computed
+ * from alpha/beta.  y_out[(l*n_vectors + r)*8*nb ...] receives 4*nb complex entries (site-major)
+ * per (level, start vector).  With eigenvalue eps, (H + eps) y is an eigenvector of H.
+ */
+int bdg_lanczos_ritz_vectors(bdg_system* sys, int32_t n_iter, int32_t n_levels, const double* coef,
+                             double* y_out);
 
 /* Write the counter-based start vector (4*nb complex entries) to a host buffer. */
 int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t vec_kind,

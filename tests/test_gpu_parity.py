@@ -913,3 +913,25 @@ def test_default_call_warns_when_it_is_not_the_reference_computation(api, monkey
     with pytest.warns(RuntimeWarning, match="surrogate temperature"):
         zero = system.free_energy(0.0, trace="exact")
     assert abs(zero / system.free_energy(0.0, method="dense") - 1) < 1e-10
+
+
+@pytest.mark.parametrize("name,k", [("swave20", 6), ("snf", 5), ("complex235", 4), ("swave20_zeeman", 3)])
+def test_lowest_eigenpairs_with_multiplicities_and_vectors(api, golden, name, k):
+    """f4 completed: the k lowest positive eigenvalues WITH multiplicities (swave20's lowest level is
+    four-fold: spin x the k_x <-> k_y symmetry of the square) and orthonormal eigenvectors in the
+    reference's layouts (ref hamiltonian.py:235-248), from two passes of the device Lanczos process.
+    Eigenvalues against the reference's spectrum, residual |Hv - εv| <= 1e-8."""
+    system = _build(api, name)
+    ref = golden.eigenvalues(name)
+    vals, vecs = system.lowest_eigenpairs(k, format="raw")
+    dense = np.asarray(system.matrix("dense"))
+    assert vals.shape == (k,) and vecs.shape == (dense.shape[0], k)
+    assert np.all(np.diff(vals) >= -1e-12) and np.abs(vals - ref[:k]).max() <= 1e-9
+    assert np.abs(dense @ vecs - vecs * vals).max() <= 1e-8
+    assert np.abs(vecs.conj().T @ vecs - np.eye(k)).max() <= 1e-8
+    vals2, shaped = system.lowest_eigenpairs(k)
+    assert shaped.shape == (k, system.lattice.size, 4) and np.allclose(vals2, vals, rtol=0, atol=1e-12)
+    for n in range(k):  # same layout rule as diagonalize(): v[n, site, α] = X[4 site + α, n]
+        assert np.abs(dense @ shaped[n].reshape(-1) - vals2[n] * shaped[n].reshape(-1)).max() <= 1e-8
+    with pytest.raises(Exception):
+        system.lowest_eigenpairs(k, format="foo")
