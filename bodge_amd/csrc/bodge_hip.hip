@@ -146,6 +146,7 @@ struct bdg_system {
     int dict_skipped = 0;  // why there is no dictionary: 0 = there is one, 1 = > 256 distinct blocks,
                            // 2 = more than 2^24 block columns (the packed word holds 24 bits), 3 = switched off
     DeviceBuffer<int> dict_ids;
+    DeviceBuffer<int> dict_diagonal;      // per distinct block: 1 = diagonal as a 4x4 matrix (stencil kernels)
     DeviceBuffer<double2> dict_full;      // n_unique x 16 complex entries
     DeviceBuffer<double2> dict_table[4];  // packed per storage mode, built on first use
     DeviceBuffer<double2> vec_a, vec_b;
@@ -531,13 +532,23 @@ int prepare_tile_order(bdg_system* sys, int rows_per_tile, int n_tiles, double r
 // ------------------------------------------------------- two steps per sweep (sweep.hpp)
 using SweepKernel = void (*)(bdg::SweepArgs);
 
-SweepKernel sweep_kernel(const ModeInfo& mode, bool reverse) {
-    switch (mode.id) {
-        case 1: return reverse ? bdg::cheb_sweep<RealMode, true> : bdg::cheb_sweep<RealMode, false>;
-        case 2: return reverse ? bdg::cheb_sweep<ComplexPHMode, true> : bdg::cheb_sweep<ComplexPHMode, false>;
-        case 3: return reverse ? bdg::cheb_sweep<RealPHMode, true> : bdg::cheb_sweep<RealPHMode, false>;
+template <typename Mode>
+SweepKernel sweep_kernel_for(int lanes, bool reverse) {
+    switch (lanes) {
+        case 1: return reverse ? bdg::cheb_sweep<Mode, 1, true> : bdg::cheb_sweep<Mode, 1, false>;
+        case 2: return reverse ? bdg::cheb_sweep<Mode, 2, true> : bdg::cheb_sweep<Mode, 2, false>;
+        case 4: return reverse ? bdg::cheb_sweep<Mode, 4, true> : bdg::cheb_sweep<Mode, 4, false>;
     }
-    return reverse ? bdg::cheb_sweep<ComplexMode, true> : bdg::cheb_sweep<ComplexMode, false>;
+    return nullptr;
+}
+
+SweepKernel sweep_kernel(const ModeInfo& mode, int lanes, bool reverse) {
+    switch (mode.id) {
+        case 1: return sweep_kernel_for<RealMode>(lanes, reverse);
+        case 2: return sweep_kernel_for<ComplexPHMode>(lanes, reverse);
+        case 3: return sweep_kernel_for<RealPHMode>(lanes, reverse);
+    }
+    return sweep_kernel_for<ComplexMode>(lanes, reverse);
 }
 
 // Segments along x for the marching kernels.  The waves of a launch take the (segment, window)
@@ -560,6 +571,7 @@ int choose_segments(int n_cols, int lx, int waves, int extra_planes, int min_pla
 }
 
 struct SweepPlan {
+    int lanes = bdg::kSweepLanes;
     SweepKernel kernel = nullptr, kernel_reverse = nullptr;
     int grid = 0;
     size_t lds_bytes = 0;
@@ -592,11 +604,13 @@ int ensure_stencil(bdg_system* sys, int* kind) {
                 HIP_TRY(hipMemsetAsync(bad.ptr, 0, sizeof(int), sys->stream));
                 const unsigned grid = (unsigned)std::min<int64_t>(4096, (sys->nb + 255) / 256);
                 if (three_d)
-                    bdg::build_stencil3<<<grid, 256, 0, sys->stream>>>(sys->indptr.ptr, sys->dict_ids.ptr, (int)sys->nb,
-                                                                        (int)plane, sys->shape[2], sys->stencil.ptr, bad.ptr);
+                    bdg::build_stencil3<<<grid, 256, 0, sys->stream>>>(sys->indptr.ptr, sys->dict_ids.ptr,
+                                                                        sys->dict_diagonal.ptr, (int)sys->nb, (int)plane,
+                                                                        sys->shape[2], sys->stencil.ptr, bad.ptr);
                 else
-                    bdg::build_stencil<<<grid, 256, 0, sys->stream>>>(sys->indptr.ptr, sys->dict_ids.ptr, (int)sys->nb,
-                                                                       (int)plane, sys->stencil.ptr, bad.ptr);
+                    bdg::build_stencil<<<grid, 256, 0, sys->stream>>>(sys->indptr.ptr, sys->dict_ids.ptr,
+                                                                       sys->dict_diagonal.ptr, (int)sys->nb, (int)plane,
+                                                                       sys->stencil.ptr, bad.ptr);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(&host_bad, bad.ptr, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
                 HIP_TRY(hipStreamSynchronize(sys->stream));
@@ -625,9 +639,11 @@ int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, int* kind
     return ensure_stencil(sys, kind);
 }
 
-int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, SweepPlan* plan) {
-    plan->kernel = sweep_kernel(mode, false);
-    plan->kernel_reverse = sweep_kernel(mode, true);
+int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, SweepPlan* plan) {
+    plan->lanes = lanes;
+    plan->kernel = sweep_kernel(mode, lanes, false);
+    plan->kernel_reverse = sweep_kernel(mode, lanes, true);
+    if (!plan->kernel) return fail(BDG_EINVAL, "the sweep kernel has 1, 2 or 4 lanes per site, not %d", lanes);
     const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
     if (table > kDictLdsLimit) return fail(BDG_EINVAL, "block table too large for the sweep kernel");
     const size_t rows = (size_t)bdg::kSweepWaves * 2 * bdg::kWave * 4 * sizeof(double2);
@@ -650,7 +666,7 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, SweepPlan* plan) {
     a.nb = (int)sys->nb;
     a.plane = (int)plane;
     a.lx = sys->shape[0];
-    a.n_cols = (int)((plane + bdg::kSweepOwned - 1) / bdg::kSweepOwned);
+    a.n_cols = (int)((plane + bdg::sweep_owned(lanes) - 1) / bdg::sweep_owned(lanes));
     // one unit (segment x window) per resident wave, segments of at least 8 planes
     const int waves = per_cu * sys->num_cus * bdg::kSweepWaves;
     int n_segs = choose_segments(a.n_cols, a.lx, waves, 4, 8);
@@ -667,9 +683,24 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, SweepPlan* plan) {
 // Algorithmic HBM bytes of one two-step sweep: one 8-byte stencil word per site, the block table
 // once, and four passes over 4 x RL 16-byte payloads per site (read t_n, t_{n-1}; write t_{n+1},
 // t_{n+2}).  The halo slots and segment-end planes the waves recompute are NOT counted.
-double sweep_bytes(const bdg_system* sys, const ModeInfo& mode) {
+double sweep_bytes(const bdg_system* sys, const ModeInfo& mode, int lanes) {
     return 8.0 * (double)sys->nb + (mode.block_bytes - 4.0) * sys->n_unique +
-           4.0 * (4.0 * bdg::kSweepLanes * sizeof(double2)) * (double)sys->nb;
+           4.0 * (4.0 * lanes * sizeof(double2)) * (double)sys->nb;
+}
+
+// Lanes per site (vectors per launch) of the sweep kernel.  4 lanes move the fewest redundant
+// bytes per vector-step; with 1 lane (2 real / 1 complex vector per launch) the four buffers of a
+// run are a quarter the size, and when they then fit the 256 MB Infinity Cache together
+// (4 x 64 B x sites + the stencil words <= ~252 MB: up to ~10^6 sites) every launch after the
+// first streams from that cache instead of HBM.  BODGE_AMD_SWEEP_LANES overrides.
+int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane) {
+    if (const char* env = getenv("BODGE_AMD_SWEEP_LANES")) {
+        const int forced = atoi(env);
+        if (forced == 1 || forced == 2 || forced == 4) return forced;
+    }
+    (void)n_active;
+    (void)per_lane;
+    return bdg::kSweepLanes;
 }
 
 // ---- 3-D: one step per launch with the x-neighbours in registers (cheb_roll3)
@@ -977,6 +1008,20 @@ struct Batch {
         if (sys->lanes_override * per_lane >= n_active && sys->lanes_override >= 4 &&
             sys->lanes_override * per_lane <= 64)
             rl = sys->lanes_override;
+        // lattice-stencil kernels (sweep.hpp): K7 runs with 4, 2 or 1 lanes per site, K8 with 4
+        sweep = roll = false;
+        int stencil_kind = 0;
+        if (sys->lanes_override == 0 && rl == 4)
+            if (int rc = sweep_wanted(sys, start.kind == StartKind::Random, col_scalars, &stencil_kind)) return rc;
+        if (stencil_kind == 1) {
+            const int lanes = sweep_lanes_for(sys, n_active, per_lane);
+            if (n_active <= lanes * per_lane) {
+                sweep = true;
+                rl = lanes;
+            }
+        } else if (stencil_kind == 2) {
+            roll = true;
+        }
         rv = rl * per_lane;  // vector columns in the buffers
         if (sys->slab_comm && sys->slab_comm->n_ranks > 1) {
             // the halo messages are 4 * rl payloads per row: a rank with another rl would hang or mis-unpack
@@ -986,16 +1031,19 @@ struct Batch {
                 return fail(BDG_EINVAL, "slab ranks chose different kernel configurations (lanes x mode %d here)",
                             rl * 2 + (real ? 1 : 0));
         }
-        if (int rc = make_plan(sys, rl, mode, &plan, col_scalars)) return rc;
-        if (int rc = matrix_args(sys, plan, &args)) return rc;
-        sweep = roll = false;
-        if (rl == bdg::kSweepLanes && plan.dictionary && sys->lanes_override == 0) {
-            int kind = 0;
-            if (int rc = sweep_wanted(sys, start.kind == StartKind::Random, col_scalars, &kind)) return rc;
-            sweep = kind == 1;
-            roll = kind == 2;
-            if (sweep)
-                if (int rc = make_sweep_plan(sys, mode, &splan)) return rc;
+        if (sweep) {
+            // (no one-step plan: the generic kernels start at 4 lanes per row; the odd last step of a
+            // run goes through the sweep kernel with its second step switched off)
+            plan = StepPlan{};
+            plan.rl = rl;
+            plan.mode = mode;
+            plan.dictionary = true;
+            args = bdg::StepArgs{};
+            if (int rc = make_sweep_plan(sys, mode, rl, &splan)) return rc;
+        } else {
+            if (int rc = make_plan(sys, rl, mode, &plan, col_scalars)) return rc;
+            if (int rc = matrix_args(sys, plan, &args)) return rc;
+            if (roll && !plan.dictionary) roll = false;
             if (roll)
                 if (int rc = make_roll_plan(sys, mode, &rplan)) return rc;
         }
@@ -1079,9 +1127,10 @@ struct Batch {
         HIP_TRY(hipGetLastError());
 
         // bytes of t_n per block row that neighbouring rows re-read: 4 entries per vector
-        if (int rc = prepare_tile_order(sys, plan.rows_per_tile, plan.n_tiles,
-                                        (real ? 32.0 : 64.0) * rv, &args.tile_order, &strip_rows))
-            return rc;
+        if (!sweep)
+            if (int rc = prepare_tile_order(sys, plan.rows_per_tile, plan.n_tiles,
+                                            (real ? 32.0 : 64.0) * rv, &args.tile_order, &strip_rows))
+                return rc;
         if (args.tile_order) band_lo = band_hi = -1;  // the band is a range of naturally ordered tiles
         if (sweep || roll) {
             strip_rows = 0;
@@ -1387,7 +1436,7 @@ struct Batch {
         p.kernel_ms += kernel_ms;
         p.launches += sweep ? n_launches : n_steps;
         p.vector_steps += (int64_t)n_steps * n_active;
-        p.bytes_per_launch = sweep  ? sweep_bytes(sys, mode)
+        p.bytes_per_launch = sweep  ? sweep_bytes(sys, mode, rl)
                              : roll ? roll_bytes(sys, mode)
                                     : algorithmic_bytes(sys, rv, mode, plan.dictionary);
         p.steps_per_launch = sweep ? 2 : 1;
@@ -1436,8 +1485,11 @@ int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors) {
                       !(real_env && real_env[0] == '0');
     int stencil_kind = 0;
     if (sys->lanes_override == 0 && sweep_wanted(sys, start.kind == StartKind::Random, false, &stencil_kind) == BDG_OK &&
-        stencil_kind != 0)
-        return std::min(bdg::kSweepLanes * (real ? 2 : 1), std::max(n_vectors, 1));  // one lane group per launch
+        stencil_kind != 0) {
+        const int per_lane = real ? 2 : 1;
+        const int lanes = stencil_kind == 1 ? sweep_lanes_for(sys, n_vectors, per_lane) : bdg::kSweepLanes;
+        return std::min(lanes * per_lane, std::max(n_vectors, 1));  // one lane group per launch
+    }
     // (slabs: the widest slab of the run decides, so that every rank cuts the same batches)
     const double per_vector = (double)std::max(sys->ncols, sys->slab_max_ncols) * 4 * (real ? 8.0 : 16.0);
     const int granule = 8;  // (the register-pipelined complex kernels start at 8 lanes per row)
@@ -2086,6 +2138,15 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
         sys->n_unique = (int)(distinct.size() / 32);
         if (int rc = sys->dict_ids.reserve(ids.size())) return cleanup(rc);
         if (int rc = sys->dict_full.reserve((size_t)sys->n_unique * 16)) return cleanup(rc);
+        std::vector<int> diagonal((size_t)sys->n_unique, 1);
+        for (int d = 0; d < sys->n_unique; ++d)
+            for (int e = 0; e < 16; ++e)
+                if ((e >> 2) != (e & 3) && (distinct[(size_t)32 * d + 2 * e] != 0.0 || distinct[(size_t)32 * d + 2 * e + 1] != 0.0))
+                    diagonal[(size_t)d] = 0;
+        if (getenv("BODGE_AMD_NO_DIAGONAL_BLOCKS")) std::fill(diagonal.begin(), diagonal.end(), 0);
+        if (int rc = sys->dict_diagonal.reserve((size_t)sys->n_unique)) return cleanup(rc);
+        if (hipMemcpy(sys->dict_diagonal.ptr, diagonal.data(), sizeof(int) * diagonal.size(), hipMemcpyHostToDevice) != hipSuccess)
+            return cleanup(fail(BDG_EDEVICE, "upload of the block dictionary failed"));
         if (hipMemcpy(sys->dict_ids.ptr, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(sys->dict_full.ptr, distinct.data(), sizeof(double) * distinct.size(),
                       hipMemcpyHostToDevice) != hipSuccess)
@@ -2217,6 +2278,7 @@ int bdg_destroy(bdg_system* sys) {
     for (auto& buf : sys->packed) buf.release();
     for (auto& buf : sys->dict_table) buf.release();
     sys->dict_ids.release();
+    sys->dict_diagonal.release();
     sys->dict_full.release();
     sys->vec_a.release();
     sys->vec_b.release();

@@ -270,6 +270,18 @@ struct ComplexMode {
                 acc[al].y = fma(m.y, x[be].x, acc[al].y);
             }
     }
+    // the same for a block that is diagonal as a 4x4 matrix (spin-independent hopping -t σ0 ⊗ τz,
+    // the commonest block of a lattice model): 4 complex MACs instead of 16
+    __device__ static inline void mac_diag(double2 acc[4], const double2* blk, const double2 x[4]) {
+#pragma unroll
+        for (int al = 0; al < 4; ++al) {
+            const double2 m = blk[al * 5];
+            acc[al].x = fma(m.x, x[al].x, acc[al].x);
+            acc[al].x = fma(-m.y, x[al].y, acc[al].x);
+            acc[al].y = fma(m.x, x[al].y, acc[al].y);
+            acc[al].y = fma(m.y, x[al].x, acc[al].y);
+        }
+    }
     // dot[0] = <c|c>, dot[1] = Re<n|c> for the lane's single vector
     __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
         dot[0] = fma(c.x, c.x, dot[0]);
@@ -294,6 +306,17 @@ struct RealMode {
                 acc[al].x = fma(m.y, x[2 * pr + 1].x, acc[al].x);
                 acc[al].y = fma(m.y, x[2 * pr + 1].y, acc[al].y);
             }
+    }
+    __device__ static inline void mac_diag(double2 acc[4], const double2* blk, const double2 x[4]) {
+        // elements (al, al): pair al>>1 of row al, component al&1
+        rfma_(acc[0], blk[0].x, x[0]);
+        rfma_(acc[1], blk[2].y, x[1]);
+        rfma_(acc[2], blk[5].x, x[2]);
+        rfma_(acc[3], blk[7].y, x[3]);
+    }
+    __device__ static inline void rfma_(double2& acc, const double m, const double2 x) {
+        acc.x = fma(m, x.x, acc.x);
+        acc.y = fma(m, x.y, acc.y);
     }
     // dot[0], dot[1] for the first vector (.x), dot[2], dot[3] for the second (.y)
     __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
@@ -342,6 +365,12 @@ struct ComplexPHMode {
             cfms_conj(acc[2 + i], a1, x[3]);
         }
     }
+    __device__ static inline void mac_diag(double2 acc[4], const double2* blk, const double2 x[4]) {
+        cfma(acc[0], blk[0], x[0]);       // A00
+        cfma(acc[1], blk[3], x[1]);       // A11
+        cfms_conj(acc[2], blk[0], x[2]);  // -conj(A00)
+        cfms_conj(acc[3], blk[3], x[3]);  // -conj(A11)
+    }
     __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
         ComplexMode::dots(dot, c, n);
     }
@@ -368,6 +397,12 @@ struct RealPHMode {
             rfma(acc[2 + i], -a.x, x[2]);
             rfma(acc[2 + i], -a.y, x[3]);
         }
+    }
+    __device__ static inline void mac_diag(double2 acc[4], const double2* blk, const double2 x[4]) {
+        rfma(acc[0], blk[0].x, x[0]);   // A00
+        rfma(acc[1], blk[1].y, x[1]);   // A11
+        rfma(acc[2], -blk[0].x, x[2]);  // -A00
+        rfma(acc[3], -blk[1].y, x[3]);  // -A11
     }
     __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
         RealMode::dots(dot, c, n);

@@ -41,9 +41,13 @@
 
 namespace bdg {
 
-constexpr int kSweepLanes = 4;                      // lanes per site (RL)
+constexpr int kSweepLanes = 4;                      // lanes per site (RL) of the default configuration
 constexpr int kSweepSlots = kWave / kSweepLanes;    // 16 site slots per wave
 constexpr int kSweepOwned = kSweepSlots - 4;        // 12 owned positions per wave window
+// K7 also exists with 2 and 1 lanes per site (4 and 2 real vectors per launch, windows of 28 and
+// 60 owned positions): with fewer vectors per launch the four vector buffers of a run get small
+// enough to live in the 256 MB Infinity Cache from one launch to the next.
+constexpr int sweep_owned(int rl) { return kWave / rl - 4; }
 constexpr unsigned kNoBlock = 0xFFu;
 
 struct SweepArgs {
@@ -71,10 +75,15 @@ struct SweepArgs {
 // Stencil table + eligibility test, on the device from the uploaded arrays.  `words` is the
 // dictionary form of the matrix (column | id << 24 per stored block).  bad[0] is raised if any
 // stored block is not one of the five stencil offsets.
-__global__ void build_stencil(const int* __restrict__ indptr, const int* __restrict__ words, int nb, int plane,
+// Byte 5 of the word (K7; byte 7 for K8's seven offsets) is a bit mask: bit o set = the block at
+// offset o is diagonal as a 4x4 matrix (`diagonal[id]`, found on the host when the blocks were
+// deduplicated), so that its product takes 4 multiply-adds per vector instead of 16.
+__global__ void build_stencil(const int* __restrict__ indptr, const int* __restrict__ words,
+                              const int* __restrict__ diagonal, int nb, int plane,
                               uint2* __restrict__ stencil, int* __restrict__ bad) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
         unsigned id[5] = {kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock};
+        unsigned mask = 0;
         const int p = i % plane;
         bool ok = true;
         for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
@@ -87,10 +96,13 @@ __global__ void build_stencil(const int* __restrict__ indptr, const int* __restr
             else if (off == 1 && p <= plane - 2) slot = 3;
             else if (off == plane) slot = 4;
             if (slot < 0 || (w >> 24) == kNoBlock) ok = false;
-            else id[slot] = w >> 24;
+            else {
+                id[slot] = w >> 24;
+                if (diagonal[w >> 24]) mask |= 1u << slot;
+            }
         }
         if (!ok) atomicOr(bad, 1);
-        stencil[i] = make_uint2(id[0] | (id[1] << 8) | (id[2] << 16) | (id[3] << 24), id[4]);
+        stencil[i] = make_uint2(id[0] | (id[1] << 8) | (id[2] << 16) | (id[3] << 24), id[4] | (mask << 8));
     }
 }
 
@@ -131,10 +143,11 @@ __device__ inline void sweep_reduce_dots(double dot[4], double* red, double* par
 constexpr int kSweepWaves = BDG_SWEEP_WAVES;
 constexpr int kSweepThreads = kSweepWaves * kWave;
 
-template <typename Mode, bool REV>
+template <typename Mode, int RL, bool REV>
 __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
     extern __shared__ double2 lds[];
-    constexpr int RL = kSweepLanes;
+    constexpr int SLOTS = kWave / RL;   // site slots per wave: [ghost, halo, owned ..., halo, ghost]
+    constexpr int OWNED = SLOTS - 4;
     constexpr int SPB = Mode::kSlotsPerBlock;
     constexpr int STRIDE = Mode::kBlockStride;
     const int lane = threadIdx.x & (kWave - 1);
@@ -167,10 +180,10 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
         const int seg = u / a.n_cols, col = u - seg * a.n_cols;
         const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
         const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
-        const int p = col * kSweepOwned - 2 + s;
+        const int p = col * OWNED - 2 + s;
         const bool valid = p >= 0 && p < a.plane;
-        const bool does1 = valid && s >= 1 && s <= kSweepSlots - 2;
-        const bool owned = valid && s >= 2 && s <= kSweepSlots - 3;
+        const bool does1 = valid && s >= 1 && s <= SLOTS - 2;
+        const bool owned = valid && s >= 2 && s <= SLOTS - 3;
 
         const bool rev = REV != (bool)(a.zigzag & seg & 1);  // wave-uniform
         auto act = [&](int k) { return rev ? x0 + x1 - 1 - k : k; };  // lattice plane of marching index k
@@ -194,27 +207,29 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
         };
         auto id_of = [](uint2 w, int slot) { return slot < 4 ? (w.x >> (8 * slot)) & 0xFFu : w.y & 0xFFu; };
         // acc += Σ_offsets block * x, in CSR (ascending column) order: -P, -1, 0, +1, +P
+        // one block times one site's entries: 4 MACs if the block is flagged diagonal, else 16
+        auto mac = [&](uint2 w, int slot, const double2 x[4], double2 acc[4]) {
+            const unsigned id = id_of(w, slot);
+            if (id == kNoBlock) return;
+            if ((w.y >> (8 + slot)) & 1u) Mode::mac_diag(acc, lds + id * STRIDE, x);
+            else Mode::mac_row(acc, lds + id * STRIDE, x);
+        };
         auto apply = [&](uint2 w, const double2 lo[4], const double2* row, const double2 mid[4],
                          const double2 hi[4], double2 acc[4]) {
             double2 x[4];
-            unsigned id = id_of(w, 0);
-            if (id != kNoBlock) Mode::mac_row(acc, lds + id * STRIDE, lo);
-            id = id_of(w, 1);
-            if (id != kNoBlock) {
+            mac(w, 0, lo, acc);
+            if (id_of(w, 1) != kNoBlock) {
 #pragma unroll
                 for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane - RL, be)];
-                Mode::mac_row(acc, lds + id * STRIDE, x);
+                mac(w, 1, x, acc);
             }
-            id = id_of(w, 2);
-            if (id != kNoBlock) Mode::mac_row(acc, lds + id * STRIDE, mid);
-            id = id_of(w, 3);
-            if (id != kNoBlock) {
+            mac(w, 2, mid, acc);
+            if (id_of(w, 3) != kNoBlock) {
 #pragma unroll
                 for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane + RL, be)];
-                Mode::mac_row(acc, lds + id * STRIDE, x);
+                mac(w, 3, x, acc);
             }
-            id = id_of(w, 4);
-            if (id != kNoBlock) Mode::mac_row(acc, lds + id * STRIDE, hi);
+            mac(w, 4, hi, acc);
         };
 
         // Step 1 runs on planes k_first..k_last: the segment itself, plus one plane on either side
@@ -357,10 +372,11 @@ struct RollArgs {
     int reverse;             // 1 = march every segment from its far end (launches alternate)
 };
 
-__global__ void build_stencil3(const int* __restrict__ indptr, const int* __restrict__ words, int nb, int plane,
-                               int lz, uint2* __restrict__ stencil, int* __restrict__ bad) {
+__global__ void build_stencil3(const int* __restrict__ indptr, const int* __restrict__ words,
+                               const int* __restrict__ diagonal, int nb, int plane, int lz,
+                               uint2* __restrict__ stencil, int* __restrict__ bad) {
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
-        unsigned id[8] = {kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock};
+        unsigned id[8] = {kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock, 0u};
         const int p = i % plane, z = p % lz, y = p / lz, ly = plane / lz;
         bool ok = true;
         for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
@@ -375,7 +391,10 @@ __global__ void build_stencil3(const int* __restrict__ indptr, const int* __rest
             else if (off == lz && y <= ly - 2) slot = 5;
             else if (off == plane) slot = 6;
             if (slot < 0 || (w >> 24) == kNoBlock) ok = false;
-            else id[slot] = w >> 24;
+            else {
+                id[slot] = w >> 24;
+                if (diagonal[w >> 24]) id[7] |= 1u << slot;  // byte 7: which of the seven blocks are diagonal
+            }
         }
         if (!ok) atomicOr(bad, 1);
         stencil[i] = make_uint2(id[0] | (id[1] << 8) | (id[2] << 16) | (id[3] << 24), id[4] | (id[5] << 8) | (id[6] << 16) | (id[7] << 24));
@@ -471,34 +490,29 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
 #pragma unroll
                 for (int al = 0; al < 4; ++al) acc[al] = zero;
                 // CSR order: -P, -Lz, -1, 0, +1, +Lz, +P  (a reversed march swaps which register is -P)
-                unsigned id = id_of(ids, 0);
-                if (id != kNoBlock) {
-                    if (rev) Mode::mac_row(acc, lds + id * STRIDE, cn_p);
-                    else Mode::mac_row(acc, lds + id * STRIDE, cn_m);
-                }
-                id = id_of(ids, 1);
-                if (id != kNoBlock) Mode::mac_row(acc, lds + id * STRIDE, ym);
-                id = id_of(ids, 2);
-                if (id != kNoBlock) {
+                auto mac = [&](int slot, const double2 v[4]) {
+                    const unsigned id = id_of(ids, slot);
+                    if (id == kNoBlock) return;
+                    if ((ids.y >> (24 + slot)) & 1u) Mode::mac_diag(acc, lds + id * STRIDE, v);
+                    else Mode::mac_row(acc, lds + id * STRIDE, v);
+                };
+                if (rev) mac(0, cn_p);
+                else mac(0, cn_m);
+                mac(1, ym);
+                if (id_of(ids, 2) != kNoBlock) {
 #pragma unroll
                     for (int be = 0; be < 4; ++be) x[be] = row_n[SHARE_SLOT(lane - RL, be)];
-                    Mode::mac_row(acc, lds + id * STRIDE, x);
+                    mac(2, x);
                 }
-                id = id_of(ids, 3);
-                if (id != kNoBlock) Mode::mac_row(acc, lds + id * STRIDE, cn_0);
-                id = id_of(ids, 4);
-                if (id != kNoBlock) {
+                mac(3, cn_0);
+                if (id_of(ids, 4) != kNoBlock) {
 #pragma unroll
                     for (int be = 0; be < 4; ++be) x[be] = row_n[SHARE_SLOT(lane + RL, be)];
-                    Mode::mac_row(acc, lds + id * STRIDE, x);
+                    mac(4, x);
                 }
-                id = id_of(ids, 5);
-                if (id != kNoBlock) Mode::mac_row(acc, lds + id * STRIDE, yp);
-                id = id_of(ids, 6);
-                if (id != kNoBlock) {
-                    if (rev) Mode::mac_row(acc, lds + id * STRIDE, cn_m);
-                    else Mode::mac_row(acc, lds + id * STRIDE, cn_p);
-                }
+                mac(5, yp);
+                if (rev) mac(6, cn_m);
+                else mac(6, cn_p);
                 const size_t site = (size_t)act(k) * a.plane + p;
 #pragma unroll
                 for (int al = 0; al < 4; ++al) {

@@ -47,5 +47,5 @@ with DeviceSolver(indptr, indices, data) as dev:
         t = statistics.median(times[label])
         p = info[label]
         print(f"{label:34s} {t:7.1f} us/launch (min {min(times[label]):6.1f})  {p['bytes_per_launch'] / t / 1e6:5.2f} TB/s alg  "
-              f"{8 * p['steps_per_launch'] / t * 1e3:6.1f} k vector-steps/s  grid={p['grid']} rolling={p['rolling']} "
+              f"{p['vectors_per_launch'] * p['steps_per_launch'] / t * 1e3:6.1f} k vector-steps/s  grid={p['grid']} rolling={p['rolling']} lanes={p['lanes_per_row']} "
               f"steps/launch={p['steps_per_launch']}", flush=True)

@@ -279,7 +279,10 @@ def test_two_steps_per_sweep_kernel_matches_oracle_and_one_step_kernels(api, sol
     per_group = 8 if (vec_kind == cheb_ref.VEC_RADEMACHER and kind != "peierls") else 4
     with solver_cls.from_hamiltonian(system) as dev:
         for steps, vectors, extra in [(8, per_group, {}), (7, 3, {}), (5, per_group + 3, {"BODGE_AMD_SWEEP_ZIGZAG": "0"}),
-                                      (6, 2, {"BODGE_AMD_ALTERNATE": "0", "BODGE_AMD_SWEEP_SEGMENTS": "3"})]:
+                                      (6, 2, {"BODGE_AMD_ALTERNATE": "0", "BODGE_AMD_SWEEP_SEGMENTS": "3"}),
+                                      (6, 5, {"BODGE_AMD_SWEEP_LANES": "1"}),  # 60-position windows, 2 real / 1 complex vector per launch
+                                      (5, 3, {"BODGE_AMD_SWEEP_LANES": "2"}),  # 28-position windows
+                                      (4, 3, {"BODGE_AMD_NO_DIAGONAL_BLOCKS": "1"})]:  # (read at upload: no effect here, see below)
             ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 5, range(vectors), vec_kind))
             monkeypatch.setenv("BODGE_AMD_SWEEP", "0")
             one = dev.dots_random(scale, steps, vectors, seed=5, kind=vec_kind)
@@ -295,7 +298,9 @@ def test_two_steps_per_sweep_kernel_matches_oracle_and_one_step_kernels(api, sol
             stencil = is_stencil and block_storage == "dictionary"  # (the stencil forms read the block dictionary)
             swept, rolled = stencil and not three_d, stencil and three_d
             assert (perf["steps_per_launch"] == 2) == swept and (perf["rolling"] == 1) == rolled, perf
-            batches = -(-vectors // per_group)
+            lanes = int(extra.get("BODGE_AMD_SWEEP_LANES", 4)) if swept else 4
+            batches = -(-vectors // (per_group * lanes // 4))
+            assert not swept or perf["lanes_per_row"] == lanes
             if swept:
                 assert perf["launches"] == batches * ((steps + 1) // 2)
             if rolled:
@@ -303,6 +308,16 @@ def test_two_steps_per_sweep_kernel_matches_oracle_and_one_step_kernels(api, sol
             assert np.array_equal(got[0], again[0]) and np.array_equal(got[1], again[1])  # bit reproducible
             for other in (ref, one):
                 assert np.abs(got[0] - other[0]).max() <= 1e-12 * n and np.abs(got[1] - other[1]).max() <= 1e-12 * n
+    # blocks that are diagonal as 4x4 matrices (plain hopping) take a 4-MAC path in K7/K8; with the
+    # flag withheld at upload every block takes the general 16-MAC path: same numbers
+    monkeypatch.setenv("BODGE_AMD_NO_DIAGONAL_BLOCKS", "1")
+    monkeypatch.setenv("BODGE_AMD_SWEEP", "1")
+    with solver_cls.from_hamiltonian(system) as dev:
+        general = dev.dots_random(scale, 6, per_group, seed=5, kind=vec_kind)
+    monkeypatch.delenv("BODGE_AMD_NO_DIAGONAL_BLOCKS")
+    with solver_cls.from_hamiltonian(system) as dev:
+        flagged = dev.dots_random(scale, 6, per_group, seed=5, kind=vec_kind)
+    assert np.abs(general[0] - flagged[0]).max() <= 1e-13 * n and np.abs(general[1] - flagged[1]).max() <= 1e-13 * n
 
 
 @pytest.mark.parametrize("name,n_vectors,kind", [
