@@ -27,10 +27,11 @@ a result.  `--allow-gloo` (rehearsals on a box with fewer GPUs than ranks) lets 
 three scalar reductions of this script over torch.distributed's gloo backend instead;
 config.collective and config.rccl_ranks always say what actually ran.
 
-The default kernel on this workload is the two-steps-per-sweep form (bodge_amd/csrc/sweep.hpp):
-one launch advances every vector by TWO recurrence steps, so K steps are K/2 launches and
-`roofline` is per launch of that kernel; the one-step kernels are timed beside it
-(`one_step_kernels`, `streamed_blocks_kernels`, `complex128_kernels`).
+The default kernel on this workload is the three-steps-per-sweep form (bodge_amd/csrc/sweep.hpp,
+cheb_sweep3): one launch advances every vector by THREE recurrence steps, so K steps are about
+K/3 launches and `roofline` is per launch of that kernel; the two-step and one-step kernels are
+timed beside it (`two_step_kernels`, `one_step_kernels`, `streamed_blocks_kernels`,
+`complex128_kernels`).
 """
 
 from __future__ import annotations
@@ -299,6 +300,8 @@ def main():
 
     def kernel_label(pf):
         mode = f"{'Real' if pf['real_arithmetic'] else 'Complex'}{'PH' if pf['ph_packed'] else ''}Mode"
+        if pf["steps_per_launch"] == 3:
+            return f"cheb_sweep3<{mode}>"
         if pf["steps_per_launch"] == 2:
             return f"cheb_sweep<{mode}>"
         if pf["rolling"]:
@@ -329,7 +332,8 @@ def main():
             "traffic": measured_traffic(kernel_label(pf), shape, r_local),
         }
 
-    one_step_pass = alternative({"BODGE_AMD_SWEEP": "0"}) if perf["steps_per_launch"] == 2 or perf["rolling"] else None
+    two_step_pass = alternative({"BODGE_AMD_SWEEP_STEPS": "2"}) if perf["steps_per_launch"] == 3 else None
+    one_step_pass = alternative({"BODGE_AMD_SWEEP": "0"}) if perf["steps_per_launch"] >= 2 or perf["rolling"] else None
     streamed_pass = alternative({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0"}) if perf["dict_blocks"] else None
     complex_pass = (alternative({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"})
                     if perf["real_arithmetic"] else None)
@@ -387,7 +391,7 @@ def main():
             "kernel": kernel_name,
             "launch_ms": launch_ms,
             "steps_per_launch": perf["steps_per_launch"],
-            "x_neighbours_in_registers": bool(perf["steps_per_launch"] == 2 or perf["rolling"]),
+            "x_neighbours_in_registers": bool(perf["steps_per_launch"] >= 2 or perf["rolling"]),
             "launches": perf["launches"],
             "bytes_per_launch": perf["bytes_per_launch"],
             "grid": perf["grid"],
@@ -398,6 +402,7 @@ def main():
         "free_energy_wall_s": elapsed,
         "free_energy_estimate": free_energy,
         "host_assembly_s": t_build,
+        "two_step_kernels": two_step_pass,
         "one_step_kernels": one_step_pass,
         "streamed_blocks_kernels": streamed_pass,
         "complex128_kernels": complex_pass,

@@ -570,8 +570,18 @@ int choose_segments(int n_cols, int lx, int waves, int extra_planes, int min_pla
     return best;
 }
 
+SweepKernel sweep3_kernel(const ModeInfo& mode, bool reverse) {
+    switch (mode.id) {
+        case 1: return reverse ? bdg::cheb_sweep3<RealMode, true> : bdg::cheb_sweep3<RealMode, false>;
+        case 2: return reverse ? bdg::cheb_sweep3<ComplexPHMode, true> : bdg::cheb_sweep3<ComplexPHMode, false>;
+        case 3: return reverse ? bdg::cheb_sweep3<RealPHMode, true> : bdg::cheb_sweep3<RealPHMode, false>;
+    }
+    return reverse ? bdg::cheb_sweep3<ComplexMode, true> : bdg::cheb_sweep3<ComplexMode, false>;
+}
+
 struct SweepPlan {
     int lanes = bdg::kSweepLanes;
+    int depth = 2;  // recurrence steps per sweep: 2 (cheb_sweep) or 3 (cheb_sweep3)
     SweepKernel kernel = nullptr, kernel_reverse = nullptr;
     int grid = 0;
     size_t lds_bytes = 0;
@@ -639,14 +649,15 @@ int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, int* kind
     return ensure_stencil(sys, kind);
 }
 
-int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, SweepPlan* plan) {
+int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth, SweepPlan* plan) {
     plan->lanes = lanes;
-    plan->kernel = sweep_kernel(mode, lanes, false);
-    plan->kernel_reverse = sweep_kernel(mode, lanes, true);
+    plan->depth = depth;
+    plan->kernel = depth == 3 ? sweep3_kernel(mode, false) : sweep_kernel(mode, lanes, false);
+    plan->kernel_reverse = depth == 3 ? sweep3_kernel(mode, true) : sweep_kernel(mode, lanes, true);
     if (!plan->kernel) return fail(BDG_EINVAL, "the sweep kernel has 1, 2 or 4 lanes per site, not %d", lanes);
     const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
     if (table > kDictLdsLimit) return fail(BDG_EINVAL, "block table too large for the sweep kernel");
-    const size_t rows = (size_t)bdg::kSweepWaves * 2 * bdg::kWave * 4 * sizeof(double2);
+    const size_t rows = (size_t)bdg::kSweepWaves * depth * bdg::kWave * 4 * sizeof(double2);
     plan->lds_bytes = table + rows;
     if (plan->lds_bytes > 64 * 1024)
         for (SweepKernel k : {plan->kernel, plan->kernel_reverse})
@@ -666,10 +677,11 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, SweepPlan*
     a.nb = (int)sys->nb;
     a.plane = (int)plane;
     a.lx = sys->shape[0];
-    a.n_cols = (int)((plane + bdg::sweep_owned(lanes) - 1) / bdg::sweep_owned(lanes));
+    const int owned = depth == 3 ? bdg::kSweep3Owned : bdg::sweep_owned(lanes);
+    a.n_cols = (int)((plane + owned - 1) / owned);
     // one unit (segment x window) per resident wave, segments of at least 8 planes
     const int waves = per_cu * sys->num_cus * bdg::kSweepWaves;
-    int n_segs = choose_segments(a.n_cols, a.lx, waves, 4, 8);
+    int n_segs = choose_segments(a.n_cols, a.lx, waves, 2 * depth, 8);
     if (const char* env = getenv("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
     a.n_segs = std::max(1, std::min(n_segs, a.lx / 8));
     a.zigzag = 1;
@@ -693,6 +705,17 @@ double sweep_bytes(const bdg_system* sys, const ModeInfo& mode, int lanes) {
 // run are a quarter the size, and when they then fit the 256 MB Infinity Cache together
 // (4 x 64 B x sites + the stencil words <= ~252 MB: up to ~10^6 sites) every launch after the
 // first streams from that cache instead of HBM.  BODGE_AMD_SWEEP_LANES overrides.
+// Steps per sweep: 3 (cheb_sweep3, 4 lanes per site only) moves 4/9 of the one-step kernels'
+// bytes against 2/3 for 2.  BODGE_AMD_SWEEP_STEPS=2|3 overrides.
+int sweep_depth_for(int lanes) {
+    int depth = lanes == bdg::kSweepLanes ? 3 : 2;
+    if (const char* env = getenv("BODGE_AMD_SWEEP_STEPS")) {
+        const int forced = atoi(env);
+        if (forced == 2 || (forced == 3 && lanes == bdg::kSweepLanes)) depth = forced;
+    }
+    return depth;
+}
+
 int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane) {
     if (const char* env = getenv("BODGE_AMD_SWEEP_LANES")) {
         const int forced = atoi(env);
@@ -1039,7 +1062,7 @@ struct Batch {
             plan.mode = mode;
             plan.dictionary = true;
             args = bdg::StepArgs{};
-            if (int rc = make_sweep_plan(sys, mode, rl, &splan)) return rc;
+            if (int rc = make_sweep_plan(sys, mode, rl, sweep_depth_for(rl), &splan)) return rc;
         } else {
             if (int rc = make_plan(sys, rl, mode, &plan, col_scalars)) return rc;
             if (int rc = matrix_args(sys, plan, &args)) return rc;
@@ -1075,7 +1098,7 @@ struct Batch {
         // n_steps (up to 1024), so a short warm-up call leaves nothing to allocate later.
         per_step = (size_t)(overlapped ? grid_interior + grid_boundary : launch_grid) * width;
         constexpr int kChunk = 64;
-        chunk = std::min(n_steps, kChunk);
+        chunk = std::min(n_steps, sweep && splan.depth == 3 ? 63 : kChunk);  // a sweep must not straddle two chunks
         if (int rc = sys->partial.reserve((size_t)kChunk * per_step)) return rc;
         const size_t dots_count = (size_t)std::max(n_steps, 1024) * width;
         if (int rc = sys->dots.reserve(dots_count)) return rc;
@@ -1358,14 +1381,16 @@ struct Batch {
         return BDG_OK;
     }
 
-    // Steps n and n + 1 in one sweep (sweep.hpp); the last step of an odd run alone.  Buffers
-    // rotate: (t_n, t_{n-1}, spare, spare) -> (t_{n+2}, t_{n+1}, spare, spare).
-    int step_sweep(int n) {
+    // Steps n .. n + depth - 1 in one sweep (sweep.hpp); what is left at the end of a run in a
+    // shorter one.  Returns the number of steps made.  Buffers rotate:
+    // (t_n, t_{n-1}, spare, spare) -> (t_{n+k}, t_{n+k-1}, spare, spare).
+    int step_sweep(int n, int* made) {
         HIP_TRY(hipSetDevice(sys->device));
         hipStream_t st = sys->stream;
-        const bool two = n + 1 < n_steps;
         const int in_chunk = n % chunk;
         const int chunk_id = n / chunk;
+        const int now = std::min({splan.depth, n_steps - n, chunk - in_chunk});
+        *made = now;
         while ((int)sys->ev_pool.size() < 2 * (chunk_id + 1)) {
             hipEvent_t ev = nullptr;
             HIP_TRY(hipEventCreate(&ev));
@@ -1379,25 +1404,31 @@ struct Batch {
         a.out2 = spare2;
         a.coef1 = (n == 0 ? 1.0 : 2.0) / scale;
         a.coef2 = 2.0 / scale;
-        a.two = two ? 1 : 0;
+        a.two = now >= 2 ? 1 : 0;
+        a.steps = now;
         a.partial1 = sys->partial.ptr + (size_t)in_chunk * per_step;
-        a.partial2 = a.partial1 + per_step;  // chunk lengths are even (or the whole run): same chunk
+        a.partial2 = a.partial1 + per_step;
+        a.partial3 = a.partial2 + per_step;
         (alternate && (n_launches & 1) ? splan.kernel_reverse : splan.kernel)<<<splan.grid, bdg::kSweepThreads,
                                                                                   splan.lds_bytes, st>>>(a);
         ++n_launches;
         double2* old_cur = cur;
         double2* old_prev = prev;
-        if (two) {
+        if (splan.depth == 2 && now == 1) {  // cheb_sweep writes a lone step to out1
+            cur = spare1;
+            prev = old_cur;
+            spare1 = old_prev;
+        } else if (now == 1) {               // cheb_sweep3 writes the last level to out2, the one before to out1
+            cur = spare2;
+            prev = old_cur;
+            spare2 = old_prev;
+        } else {
             cur = spare2;
             prev = spare1;
             spare1 = old_prev;
             spare2 = old_cur;
-        } else {
-            cur = spare1;
-            prev = old_cur;
-            spare1 = old_prev;
         }
-        const int last = n + (two ? 1 : 0);
+        const int last = n + now - 1;
         const int last_in_chunk = last % chunk;
         if (last_in_chunk == chunk - 1 || last == n_steps - 1) {
             const int s0 = last - last_in_chunk;
@@ -1439,7 +1470,7 @@ struct Batch {
         p.bytes_per_launch = sweep  ? sweep_bytes(sys, mode, rl)
                              : roll ? roll_bytes(sys, mode)
                                     : algorithmic_bytes(sys, rv, mode, plan.dictionary);
-        p.steps_per_launch = sweep ? 2 : 1;
+        p.steps_per_launch = sweep ? splan.depth : 1;
         p.rolling = roll ? 1 : 0;
         p.dict_skipped = sys->dict_skipped;
         p.lanes_per_row = rl;
@@ -1517,8 +1548,9 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
         const auto t1 = now();
         for (int n = 0; n < n_steps; ++n) {
             if (batch.sweep) {
-                if (int rc = batch.step_sweep(n)) return rc;
-                ++n;  // (a lone last step leaves the loop through its bound)
+                int made = 1;
+                if (int rc = batch.step_sweep(n, &made)) return rc;
+                n += made - 1;
                 continue;
             }
             if (batch.overlapped) {

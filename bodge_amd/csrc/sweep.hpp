@@ -67,7 +67,9 @@ struct SweepArgs {
     int lx;
     int n_cols;              // windows per plane = ceil(P / 12)
     int n_segs;              // segments along x
-    int two;                 // 1 = both steps, 0 = step 1 only (odd tail of a run)
+    int two;                 // cheb_sweep: 1 = both steps, 0 = step 1 only (odd tail of a run)
+    int steps;               // cheb_sweep3: steps this launch makes, 1..3 (out1 = t_{n+steps-1}, out2 = t_{n+steps})
+    double* partial3;        // cheb_sweep3: dots of step 3
     int stream;              // non-temporal hints: bit 0 t_{n-1} loads, bit 1 stores, bit 2 t_n loads
     int zigzag;              // 1 = odd segments march against the even ones
 };
@@ -337,6 +339,256 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
     }
 }
 
+
+// =====================================================================================
+// K7b  cheb_sweep3 - THREE recurrence steps per sweep of the vectors.
+//
+// A sweep that makes k steps still reads only t_n and t_{n-1} and writes only the last two
+// levels t_{n+k-1}, t_{n+k}: four array passes per k steps.  k = 2 (cheb_sweep) moves 2/3 of the
+// one-step kernels' bytes, k = 3 moves 4/9: the intermediate level t_{n+1} is never stored at
+// all.  The price is one more plane pair of rolling state per level, a halo slot more on either
+// side of the window (16 slots = [3 halo, 10 owned, 3 halo]: step j is valid on slots j..15-j),
+// and one more recomputed plane at either end of a segment.  To stay within two waves per SIMD
+// the current plane of every level lives in its LDS hand-over row (the lane's own slot) instead
+// of a register; only the planes before and after it are registers.
+//
+// Iteration k of a wave (plane indices along its march):
+//     step 1 on plane k     from t_n[k-1,k,k+1]                  -> level 1
+//     step 2 on plane k-1   from level 1 [k-2, k-1, k]           -> level 2   (k was just made)
+//     step 3 on plane k-2   from level 2 [k-3, k-2, k-1]         -> level 3
+// a launch may make fewer (steps = 1 or 2: the tail of a run whose length is not a multiple of 3).
+constexpr int kSweep3Owned = kSweepSlots - 6;  // 10 owned positions per wave window
+
+template <typename Mode, bool REV>
+__global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
+    extern __shared__ double2 lds[];
+    constexpr int RL = kSweepLanes;
+    constexpr int SLOTS = kSweepSlots;
+    constexpr int SPB = Mode::kSlotsPerBlock;
+    constexpr int STRIDE = Mode::kBlockStride;
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const int s = lane / RL;
+    const int r = lane % RL;
+
+    // LDS: [table][per wave: three rows of 64 lanes x 4 entries: level 0 plane k, level 1 plane k-1, level 2 plane k-2]
+    const double2* table = static_cast<const double2*>(a.dict_table);
+    for (int e = threadIdx.x; e < a.n_unique * SPB; e += kBlockThreads)
+        lds[(e / SPB) * STRIDE + (e % SPB)] = table[e];
+    double2* row_0 = lds + a.n_unique * STRIDE + wave * (3 * kWave * 4);
+    double2* row_1 = row_0 + kWave * 4;
+    double2* row_2 = row_1 + kWave * 4;
+    __syncthreads();
+
+    const int n_units = a.n_cols * a.n_segs;
+    const int xcd = blockIdx.x & 7;
+    const int u_lo = (int)(((int64_t)n_units * xcd) >> 3);
+    const int u_hi = (int)(((int64_t)n_units * (xcd + 1)) >> 3);
+    const int waves_per_xcd = (gridDim.x >> 3) * kWavesPerBlock;
+
+    double dot1[4] = {0.0, 0.0, 0.0, 0.0}, dot2[4] = {0.0, 0.0, 0.0, 0.0}, dot3[4] = {0.0, 0.0, 0.0, 0.0};
+    const double2 zero = make_double2(0.0, 0.0);
+    const size_t nb = (size_t)a.nb;
+    const int steps = a.steps;  // uniform
+    const bool nt_prev = a.stream & 1, nt_store = a.stream & 2, nt_cur = a.stream & 4;
+
+    for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
+        const int seg = u / a.n_cols, col = u - seg * a.n_cols;
+        const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
+        const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
+        const int p = col * kSweep3Owned - 3 + s;
+        const bool valid = p >= 0 && p < a.plane;
+        const bool ok1 = valid && s >= 1 && s <= SLOTS - 2;
+        const bool ok2 = valid && s >= 2 && s <= SLOTS - 3;
+        const bool owned = valid && s >= 3 && s <= SLOTS - 4;
+
+        const bool rev = REV != (bool)(a.zigzag & seg & 1);  // wave-uniform
+        auto act = [&](int k) { return rev ? x0 + x1 - 1 - k : k; };
+        auto in_lattice = [&](int k) { return act(k) >= 0 && act(k) < a.lx; };
+        auto load_plane = [&](const double2* buf, bool nt, int k, bool wanted, double2 out[4]) {
+            k = act(k);
+            if (wanted && k >= 0 && k < a.lx) {
+                const size_t site = (size_t)k * a.plane + p;
+#pragma unroll
+                for (int al = 0; al < 4; ++al)
+                    out[al] = nt ? load_stream(buf + vslot(al, site, r, nb, RL)) : buf[vslot(al, site, r, nb, RL)];
+            } else {
+#pragma unroll
+                for (int al = 0; al < 4; ++al) out[al] = zero;
+            }
+        };
+        auto store_plane = [&](double2* buf, int k, const double2 v[4]) {
+            const size_t site = (size_t)act(k) * a.plane + p;
+#pragma unroll
+            for (int al = 0; al < 4; ++al) {
+                if (nt_store) store_stream(buf + vslot(al, site, r, nb, RL), v[al]);
+                else buf[vslot(al, site, r, nb, RL)] = v[al];
+            }
+        };
+        auto load_ids = [&](int k) {
+            uint2 w = make_uint2(0xFFFFFFFFu, 0xFFu);
+            k = act(k);
+            if (ok1 && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + p];
+            return w;
+        };
+        auto id_of = [](uint2 w, int slot) { return slot < 4 ? (w.x >> (8 * slot)) & 0xFFu : w.y & 0xFFu; };
+        auto mac = [&](uint2 w, int slot, const double2 x[4], double2 acc[4]) {
+            const unsigned id = id_of(w, slot);
+            if (id == kNoBlock) return;
+            if ((w.y >> (8 + slot)) & 1u) Mode::mac_diag(acc, lds + id * STRIDE, x);
+            else Mode::mac_row(acc, lds + id * STRIDE, x);
+        };
+        auto own_of = [&](const double2* row, double2 out[4]) {
+#pragma unroll
+            for (int be = 0; be < 4; ++be) out[be] = row[SHARE_SLOT(lane, be)];
+        };
+        auto put_own = [&](double2* row, const double2 v[4]) {
+#pragma unroll
+            for (int be = 0; be < 4; ++be) row[SHARE_SLOT(lane, be)] = v[be];
+        };
+        auto wave_sync = [&]() {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        };
+        // acc = Σ_offsets block * x in CSR order (-P, -1, 0, +1, +P); `before` / `after` are the planes
+        // behind / ahead of the march, `mid` the lane's own entries, `row` the hand-over row of the level
+        auto apply = [&](uint2 w, const double2 before[4], const double2* row, const double2 mid[4],
+                         const double2 after[4], double2 acc[4]) {
+            double2 x[4];
+            if (rev) mac(w, 0, after, acc);
+            else mac(w, 0, before, acc);
+            if (id_of(w, 1) != kNoBlock) {
+#pragma unroll
+                for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane - RL, be)];
+                mac(w, 1, x, acc);
+            }
+            mac(w, 2, mid, acc);
+            if (id_of(w, 3) != kNoBlock) {
+#pragma unroll
+                for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane + RL, be)];
+                mac(w, 3, x, acc);
+            }
+            if (rev) mac(w, 4, before, acc);
+            else mac(w, 4, after, acc);
+        };
+
+        // step j (1-based) runs on plane k-j+1 and is needed on planes [x0-(steps-j), x1+(steps-j))
+        const int k_first = x0 - (steps - 1), k_last = x1 + steps - 2;
+
+        // ---- prologue
+        double2 cn_m[4], cn_0[4], cn_p[4], pv[4], c1_m[4], c2_m[4];
+        load_plane(a.cur, nt_cur, k_first - 1, valid, cn_m);
+        load_plane(a.cur, nt_cur, k_first, valid, cn_0);
+        load_plane(a.cur, nt_cur, k_first + 1, valid, cn_p);
+        load_plane(a.prev, nt_prev, k_first, ok1, pv);
+        uint2 ids_0 = load_ids(k_first), ids_1 = make_uint2(0xFFFFFFFFu, 0xFFu), ids_2 = ids_1;
+#pragma unroll
+        for (int al = 0; al < 4; ++al) c1_m[al] = c2_m[al] = zero;
+        put_own(row_1, c1_m);  // the rows still hold the previous unit's planes
+        put_own(row_2, c1_m);
+
+        for (int k = k_first; k <= k_last; ++k) {
+            // ---- prefetch what the next iteration consumes
+            double2 nx_cn[4], nx_pv[4];
+            const bool more = k < k_last;
+            load_plane(a.cur, nt_cur, k + 2, valid && more, nx_cn);
+            load_plane(a.prev, nt_prev, k + 1, ok1 && more, nx_pv);
+            const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFu);
+
+            put_own(row_0, cn_0);
+            wave_sync();
+
+            // ---- step 1 on plane k: level 1 = c1 H t_n - t_{n-1}
+            double2 new1[4], new2[4];
+#pragma unroll
+            for (int al = 0; al < 4; ++al) new1[al] = new2[al] = zero;
+            if (ok1 && in_lattice(k)) {
+                double2 acc[4], mid[4];
+#pragma unroll
+                for (int al = 0; al < 4; ++al) acc[al] = zero;
+                own_of(row_0, mid);
+                apply(ids_0, cn_m, row_0, mid, cn_p, acc);
+#pragma unroll
+                for (int al = 0; al < 4; ++al) {
+                    new1[al].x = fma(a.coef1, acc[al].x, -pv[al].x);
+                    new1[al].y = fma(a.coef1, acc[al].y, -pv[al].y);
+                }
+                if (owned && k >= x0 && k < x1) {
+#pragma unroll
+                    for (int al = 0; al < 4; ++al) Mode::dots(dot1, mid[al], new1[al]);
+                    if (steps == 1) store_plane(a.out2, k, new1);
+                    if (steps == 2) store_plane(a.out1, k, new1);
+                }
+            }
+
+            // ---- step 2 on plane k-1: level 2 = c2 H level1 - t_n        (row_1 = level 1, plane k-1)
+            if (steps >= 2 && ok2 && in_lattice(k - 1) && k - 1 >= x0 - (steps - 2) && k - 1 < x1 + (steps - 2)) {
+                double2 acc[4], mid[4];
+#pragma unroll
+                for (int al = 0; al < 4; ++al) acc[al] = zero;
+                own_of(row_1, mid);
+                apply(ids_1, c1_m, row_1, mid, new1, acc);
+#pragma unroll
+                for (int al = 0; al < 4; ++al) {
+                    new2[al].x = fma(a.coef2, acc[al].x, -cn_m[al].x);
+                    new2[al].y = fma(a.coef2, acc[al].y, -cn_m[al].y);
+                }
+                if (owned && k - 1 >= x0 && k - 1 < x1) {
+#pragma unroll
+                    for (int al = 0; al < 4; ++al) Mode::dots(dot2, mid[al], new2[al]);
+                    if (steps == 2) store_plane(a.out2, k - 1, new2);
+                    if (steps == 3) store_plane(a.out1, k - 1, new2);
+                }
+            }
+
+            // ---- step 3 on plane k-2: level 3 = c2 H level2 - level1       (row_2 = level 2, plane k-2)
+            if (steps >= 3 && owned && k - 2 >= x0 && k - 2 < x1) {
+                double2 acc[4], mid[4], new3[4];
+#pragma unroll
+                for (int al = 0; al < 4; ++al) acc[al] = zero;
+                own_of(row_2, mid);
+                apply(ids_2, c2_m, row_2, mid, new2, acc);
+#pragma unroll
+                for (int al = 0; al < 4; ++al) {
+                    new3[al].x = fma(a.coef2, acc[al].x, -c1_m[al].x);
+                    new3[al].y = fma(a.coef2, acc[al].y, -c1_m[al].y);
+                    Mode::dots(dot3, mid[al], new3[al]);
+                }
+                store_plane(a.out2, k - 2, new3);
+            }
+
+            // ---- roll: every level moves one plane on
+            wave_sync();
+            own_of(row_0, cn_m);   // level 0, plane k
+            own_of(row_1, c1_m);   // level 1, plane k-1
+            own_of(row_2, c2_m);   // level 2, plane k-2
+            wave_sync();
+            put_own(row_1, new1);  // level 1, plane k
+            put_own(row_2, new2);  // level 2, plane k-1
+#pragma unroll
+            for (int al = 0; al < 4; ++al) {
+                cn_0[al] = cn_p[al];
+                cn_p[al] = nx_cn[al];
+                pv[al] = nx_pv[al];
+            }
+            ids_2 = ids_1;
+            ids_1 = ids_0;
+            ids_0 = nx_ids;
+        }
+    }
+
+    __syncthreads();
+    sweep_reduce_dots<Mode, RL, kWavesPerBlock>(dot1, reinterpret_cast<double*>(lds), a.partial1, lane, wave);
+    if (steps >= 2) {
+        __syncthreads();
+        sweep_reduce_dots<Mode, RL, kWavesPerBlock>(dot2, reinterpret_cast<double*>(lds), a.partial2, lane, wave);
+    }
+    if (steps >= 3) {
+        __syncthreads();
+        sweep_reduce_dots<Mode, RL, kWavesPerBlock>(dot3, reinterpret_cast<double*>(lds), a.partial3, lane, wave);
+    }
+}
 
 // =====================================================================================
 // K8  cheb_roll3 - one recurrence step on a 3-D lattice stencil with the x-neighbours in registers.

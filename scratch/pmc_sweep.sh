@@ -18,7 +18,7 @@ for f in glob.glob(out + "/g*/*/*counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         name = r["Kernel_Name"]
         if "cheb_s" not in name and "cheb_roll" not in name: continue
-        key = re.sub(r", (true|false)>$", ">", name.split("(")[0].replace("void bdg::", "")) if "cheb_sweep" in name else name.split("(")[0].replace("void bdg::", "")
+        key = re.sub(r"(, \d)?, (true|false)>$", ">", name.split("(")[0].replace("void bdg::", "")) if "cheb_sweep" in name else name.split("(")[0].replace("void bdg::", "")
         acc[key][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in acc.items():
     print(k)

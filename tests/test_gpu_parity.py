@@ -263,7 +263,7 @@ def _sweep_system(api, shape, kind):
     ((10, 6, 8), "peierls", cheb_ref.VEC_Z4),            # 3-D complex
     ((8, 5, 6), "periodic", cheb_ref.VEC_RADEMACHER),    # 3-D with wrap blocks: falls back
 ])
-def test_two_steps_per_sweep_kernel_matches_oracle_and_one_step_kernels(api, solver_cls, monkeypatch, block_storage,
+def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_cls, monkeypatch, block_storage,
                                                                         shape, kind, vec_kind):
     """K7 / K8 (sweep.hpp) forced on small lattices: every d_n, e_n against the CPU oracle and against
     the one-step kernels on the same vectors, for even and odd step counts (the odd tail of a
@@ -280,6 +280,8 @@ def test_two_steps_per_sweep_kernel_matches_oracle_and_one_step_kernels(api, sol
     with solver_cls.from_hamiltonian(system) as dev:
         for steps, vectors, extra in [(8, per_group, {}), (7, 3, {}), (5, per_group + 3, {"BODGE_AMD_SWEEP_ZIGZAG": "0"}),
                                       (6, 2, {"BODGE_AMD_ALTERNATE": "0", "BODGE_AMD_SWEEP_SEGMENTS": "3"}),
+                                      (8, per_group, {"BODGE_AMD_SWEEP_STEPS": "2"}),  # cheb_sweep (two steps) instead of cheb_sweep3
+                                      (7, 3, {"BODGE_AMD_SWEEP_STEPS": "2", "BODGE_AMD_SWEEP_ZIGZAG": "0"}),
                                       (6, 5, {"BODGE_AMD_SWEEP_LANES": "1"}),  # 60-position windows, 2 real / 1 complex vector per launch
                                       (5, 3, {"BODGE_AMD_SWEEP_LANES": "2"}),  # 28-position windows
                                       (4, 3, {"BODGE_AMD_NO_DIAGONAL_BLOCKS": "1"})]:  # (read at upload: no effect here, see below)
@@ -297,12 +299,13 @@ def test_two_steps_per_sweep_kernel_matches_oracle_and_one_step_kernels(api, sol
                 monkeypatch.delenv(key)
             stencil = is_stencil and block_storage == "dictionary"  # (the stencil forms read the block dictionary)
             swept, rolled = stencil and not three_d, stencil and three_d
-            assert (perf["steps_per_launch"] == 2) == swept and (perf["rolling"] == 1) == rolled, perf
             lanes = int(extra.get("BODGE_AMD_SWEEP_LANES", 4)) if swept else 4
+            depth = int(extra.get("BODGE_AMD_SWEEP_STEPS", 3 if lanes == 4 else 2))  # steps per sweep
+            assert perf["steps_per_launch"] == (depth if swept else 1) and (perf["rolling"] == 1) == rolled, perf
             batches = -(-vectors // (per_group * lanes // 4))
             assert not swept or perf["lanes_per_row"] == lanes
             if swept:
-                assert perf["launches"] == batches * ((steps + 1) // 2)
+                assert perf["launches"] == batches * -(-steps // depth)
             if rolled:
                 assert perf["launches"] == batches * steps
             assert np.array_equal(got[0], again[0]) and np.array_equal(got[1], again[1])  # bit reproducible
