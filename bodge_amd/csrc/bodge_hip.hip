@@ -1146,7 +1146,8 @@ struct Batch {
                 bdg::set_unit<<<1, 64, 0, st>>>(sys->vec_a.ptr, sys->nb, sys->ncols, rv, n_active,
                                                 sys->rows.ptr, sys->row_offset);
         }
-        bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)vec_count);
+        if (!sweep)  // (the sweep kernels are told that t_{-1} = 0 instead of reading 256 MB of zeros)
+            bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)vec_count);
         HIP_TRY(hipGetLastError());
 
         // bytes of t_n per block row that neighbouring rows re-read: 4 entries per vector
@@ -1399,7 +1400,7 @@ struct Batch {
         if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id], st));
         bdg::SweepArgs& a = splan.args;
         a.cur = cur;
-        a.prev = prev;
+        a.prev = n == 0 ? nullptr : prev;
         a.out1 = spare1;
         a.out2 = spare2;
         a.coef1 = (n == 0 ? 1.0 : 2.0) / scale;

@@ -125,20 +125,26 @@ __global__ void fill_random(double2* __restrict__ vec, int64_t nb, int64_t ncols
     }
 }
 
-// RealMode layout: double[α][site][rv]; only the Rademacher kind is real.
+// RealMode layout: double[α][site][rv]; only the Rademacher kind is real.  One thread writes one
+// 16-byte lane payload (vectors 2q, 2q+1 of one (site, component)).
 __global__ void fill_random_real(double* __restrict__ vec, int64_t nb, int64_t ncols, int rv,
                                  int n_active, uint64_t seed, uint64_t first_id, int64_t row_offset) {
-    const int64_t total = 4 * ncols * rv;
+    const int rl = rv / 2;  // payloads per (site, component)
+    const int64_t total = 4 * ncols * rl;
+    double2* out = reinterpret_cast<double2*>(vec);
     for (int64_t idx = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; idx < total;
          idx += (int64_t)gridDim.x * blockDim.x) {
-        const int r = (int)(idx % rv);
+        const int q = (int)(idx % rl);
         int alpha;
         int64_t site;
-        vpair(idx / rv, ncols, alpha, site);
-        double v = 0.0;
-        if (r < n_active && site < nb)
-            v = start_entry(vector_key(seed, first_id + r), 4 * (row_offset + site) + alpha, 0).x;
-        vec[idx] = v;
+        vpair(idx / rl, ncols, alpha, site);
+        double2 v = make_double2(0.0, 0.0);
+        if (site < nb) {
+            const uint64_t element = 4 * (row_offset + site) + alpha;
+            if (2 * q < n_active) v.x = start_entry(vector_key(seed, first_id + 2 * q), element, 0).x;
+            if (2 * q + 1 < n_active) v.y = start_entry(vector_key(seed, first_id + 2 * q + 1), element, 0).x;
+        }
+        out[idx] = v;
     }
 }
 

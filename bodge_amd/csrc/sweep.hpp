@@ -56,7 +56,7 @@ struct SweepArgs {
     const void* dict_table;  // the distinct blocks, packed for the mode
     int n_unique;
     const double2* cur;      // t_n
-    const double2* prev;     // t_{n-1}
+    const double2* prev;     // t_{n-1}; nullptr = zero (first sweep of a run: t_{-1} = 0 is not read)
     double2* out1;           // t_{n+1}
     double2* out2;           // t_{n+2}
     double* partial1;        // [gridDim.x][RL * kVec][2]  dots of step 1: <t_n|t_n>, <t_{n+1}|t_n>
@@ -243,7 +243,7 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
         load_plane(a.cur, nt_cur, k_first - 1, valid, cn_m);
         load_plane(a.cur, nt_cur, k_first, valid, cn_0);
         load_plane(a.cur, nt_cur, k_first + 1, valid, cn_p);
-        load_plane(a.prev, nt_prev, k_first, does1, pv);
+        load_plane(a.prev, nt_prev, k_first, does1 && a.prev != nullptr, pv);
         uint2 ids_0 = load_ids(k_first), ids_m = make_uint2(0xFFFFFFFFu, 0xFFu);
 #pragma unroll
         for (int al = 0; al < 4; ++al) c1_m[al] = c1_0[al] = zero;
@@ -253,7 +253,7 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
             double2 nx_cn[4], nx_pv[4];
             const bool more = k < k_last;
             load_plane(a.cur, nt_cur, k + 2, valid && more, nx_cn);
-            load_plane(a.prev, nt_prev, k + 1, does1 && more, nx_pv);
+            load_plane(a.prev, nt_prev, k + 1, does1 && more && a.prev != nullptr, nx_pv);
             const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFu);
 
             // ---- step 1 on plane k: t_{n+1} = c1 H t_n - t_{n-1}
@@ -481,7 +481,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
         load_plane(a.cur, nt_cur, k_first - 1, valid, cn_m);
         load_plane(a.cur, nt_cur, k_first, valid, cn_0);
         load_plane(a.cur, nt_cur, k_first + 1, valid, cn_p);
-        load_plane(a.prev, nt_prev, k_first, ok1, pv);
+        load_plane(a.prev, nt_prev, k_first, ok1 && a.prev != nullptr, pv);
         uint2 ids_0 = load_ids(k_first), ids_1 = make_uint2(0xFFFFFFFFu, 0xFFu), ids_2 = ids_1;
 #pragma unroll
         for (int al = 0; al < 4; ++al) c1_m[al] = c2_m[al] = zero;
@@ -493,7 +493,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
             double2 nx_cn[4], nx_pv[4];
             const bool more = k < k_last;
             load_plane(a.cur, nt_cur, k + 2, valid && more, nx_cn);
-            load_plane(a.prev, nt_prev, k + 1, ok1 && more, nx_pv);
+            load_plane(a.prev, nt_prev, k + 1, ok1 && more && a.prev != nullptr, nx_pv);
             const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFu);
 
             put_own(row_0, cn_0);
