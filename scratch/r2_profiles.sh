@@ -10,8 +10,8 @@ cd /tmp && export TMPDIR=/tmp
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats -- python3 $GRAFT_REPO_ROOT/bench.py --cpu-seconds 0 > $OUT/bench_n1_under_rocprof.json 2> $OUT/stats.err || echo "stats run failed"
 timeout -k 10 300 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/stats_dwave -- python3 $GRAFT_REPO_ROOT/bench.py --model dwave --lattice 100,100,100 --cpu-seconds 0 > $OUT/bench_dwave100_under_rocprof.json 2> $OUT/stats_dwave.err || echo "stats dwave run failed"
 for c in FETCH_SIZE WRITE_SIZE; do
-  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --cpu-seconds 0 > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err || echo "pmc $c failed"
-  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_dwave_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --cpu-seconds 0 --model dwave --lattice 100,100,100 > $OUT/pmc_dwave_$c.json 2> $OUT/pmc_dwave_$c.err || echo "pmc dwave $c failed"
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 63 --warmup 3 --cpu-seconds 0 > $OUT/pmc_$c.json 2> $OUT/pmc_$c.err || echo "pmc $c failed"
+  timeout -k 10 300 rocprofv3 --pmc $c --kernel-trace --output-format csv -d $OUT/pmc_dwave_$c -- python3 $GRAFT_REPO_ROOT/bench.py --steps 32 --warmup 2 --cpu-seconds 0 --model dwave --lattice 100,100,100 > $OUT/pmc_dwave_$c.json 2> $OUT/pmc_dwave_$c.err || echo "pmc dwave $c failed"
 done
 cd $GRAFT_REPO_ROOT
 cp profiles/traffic.json $OUT/traffic.json

@@ -58,7 +58,10 @@ def main():
     for d in args.dirs:
         for kernel, counters in collect(d).items():
             for counter, values in counters.items():
-                merged[kernel][counter] = (sum(values) / len(values), len(values))
+                # median, not mean: the first launch of a run of the multi-step sweep kernels does not read
+                # t_{-1} and the last may make fewer steps; the typical (full) launch is what is reported
+                ordered = sorted(values)
+                merged[kernel][counter] = (ordered[len(ordered) // 2], len(values))
     table = {}
     if os.path.exists(args.out):
         with open(args.out) as fh:
@@ -76,7 +79,7 @@ def main():
             "write_bytes": write_bytes,
             "FETCH_SIZE_KiB_raw": fetch_kib,
             "WRITE_SIZE_KiB_raw": write_kib,
-            "launches_averaged": [n_f, n_w],
+            "launches_sampled_median": [n_f, n_w],
             "correction": "read = 2 x FETCH_SIZE (gfx950 counts 128-B streaming requests as 64 B)",
         }
     with open(args.out, "w") as fh:
