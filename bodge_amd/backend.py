@@ -86,6 +86,8 @@ SIGNATURES = {
     "bdg_hermiticity_defect": (C.c_int, [_handle, _f64p]),
     "bdg_dense_prefetch": (C.c_int, []),
     "bdg_dense_prefetch_wait": (C.c_int, [C.c_double, C.POINTER(C.c_int32)]),
+    "bdg_rccl_prefetch": (C.c_int, []),
+    "bdg_rccl_prefetch_wait": (C.c_int, [C.c_double, C.POINTER(C.c_int32)]),
     "bdg_perf_query": (C.c_int, [_handle, C.POINTER(Perf)]),
     "bdg_set_lattice_shape": (C.c_int, [_handle, C.c_int32, C.c_int32, C.c_int32]),
     "bdg_set_lanes_per_row": (C.c_int, [_handle, C.c_int32]),

@@ -836,11 +836,14 @@ void warm_page_cache(const char* path) {
     close(fd);
 }
 
-struct SolverPrefetch {
+struct FilePrefetch {
+    std::vector<const char*> paths;
+    FilePrefetch* after = nullptr;  // read only once that one is done (the disk serves one stream best)
     std::mutex lock;
     std::condition_variable changed;
     bool started = false, done = false, reported = false;
     double seconds = 0.0;
+    FilePrefetch(std::vector<const char*> files, FilePrefetch* first) : paths(std::move(files)), after(first) {}
     void start() {
         std::lock_guard<std::mutex> guard(lock);
         if (started) return;
@@ -850,16 +853,20 @@ struct SolverPrefetch {
             return;
         }
         // detached: a process that ends before the read has finished must not wait for it
-        // (the object itself is never destroyed, see g_solver_prefetch)
+        // (the objects themselves are never destroyed, see below)
         std::thread([this] {
+            if (after && after->is_started()) (void)after->wait(-1.0);
             const auto t0 = std::chrono::steady_clock::now();
-            warm_page_cache("/opt/rocm/lib/librocblas.so");
-            warm_page_cache("/opt/rocm/lib/librocsolver.so");
+            for (const char* path : paths) warm_page_cache(path);
             std::lock_guard<std::mutex> inner(lock);
             seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
             done = true;
             changed.notify_all();
         }).detach();
+    }
+    bool is_started() {
+        std::lock_guard<std::mutex> guard(lock);
+        return started;
     }
     // true once the files have been read; waits at most `timeout_s` (negative: no limit)
     bool wait(double timeout_s) {
@@ -869,12 +876,15 @@ struct SolverPrefetch {
         else changed.wait_for(guard, std::chrono::duration<double>(timeout_s), [this] { return done; });
         if (done && !reported && getenv("BODGE_AMD_TRACE")) {
             reported = true;
-            fprintf(stderr, "[bdg] rocBLAS/rocSOLVER files read in %.1f s\n", seconds);
+            fprintf(stderr, "[bdg] %s%s read in %.1f s\n", paths[0], paths.size() > 1 ? " ..." : "", seconds);
         }
         return done;
     }
 };
-SolverPrefetch& g_solver_prefetch = *new SolverPrefetch();  // deliberately immortal: outlives every exit path
+// deliberately immortal: they outlive every exit path
+FilePrefetch& g_rccl_prefetch = *new FilePrefetch({"/opt/rocm/lib/librccl.so"}, nullptr);
+FilePrefetch& g_solver_prefetch =
+    *new FilePrefetch({"/opt/rocm/lib/librocblas.so", "/opt/rocm/lib/librocsolver.so"}, &g_rccl_prefetch);
 
 int load_solver(SolverApi** out) {
     static SolverApi api;
@@ -926,6 +936,7 @@ int load_rccl(RcclApi** out) {
     static bool tried = false, ok = false;
     if (!tried) {
         tried = true;
+        (void)g_rccl_prefetch.wait(-1.0);  // 573 MB: streamed in before dlopen faults it in piecemeal
         api.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
         if (!api.lib) api.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
         if (!api.lib) api.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
@@ -2656,6 +2667,17 @@ int bdg_dense_prefetch(void) {
 int bdg_dense_prefetch_wait(double timeout_seconds, int32_t* ready) {
     if (!ready) return fail(BDG_EINVAL, "null ready pointer");
     *ready = g_solver_prefetch.wait(timeout_seconds) ? 1 : 0;
+    return BDG_OK;
+}
+
+int bdg_rccl_prefetch(void) {
+    g_rccl_prefetch.start();
+    return BDG_OK;
+}
+
+int bdg_rccl_prefetch_wait(double timeout_seconds, int32_t* ready) {
+    if (!ready) return fail(BDG_EINVAL, "null ready pointer");
+    *ready = g_rccl_prefetch.wait(timeout_seconds) ? 1 : 0;
     return BDG_OK;
 }
 

@@ -32,6 +32,17 @@ def prefetch_dense_library() -> None:
     backend.check(backend.load().bdg_dense_prefetch())
 
 
+def prefetch_rccl_library() -> None:
+    """The same for the RCCL shared object (573 MB) that the first `Communicator` loads."""
+    backend.check(backend.load().bdg_rccl_prefetch())
+
+
+def rccl_library_ready(timeout: float = 0.0) -> bool:
+    ready = C.c_int32(0)
+    backend.check(backend.load().bdg_rccl_prefetch_wait(float(timeout), C.byref(ready)))
+    return bool(ready.value)
+
+
 def dense_library_ready(timeout: float = 0.0) -> bool:
     """True once the background read started by `prefetch_dense_library` has finished; waits up
     to `timeout` seconds for it."""

@@ -72,6 +72,36 @@ def _dense_library_prefetch(request):
         from bodge_amd import backend, solver
 
         if backend.device_count() > 0:
+            solver.prefetch_rccl_library()   # (read first: the communicator tests come earlier in the suite)
             solver.prefetch_dense_library()
     except Exception:  # library not built yet: the tests that need it say so themselves
         pass
+
+
+def wait_for_library(request, ready, name: str, budget_s: float = 780.0) -> None:
+    """Wait for a background library read with a progress line every 30 s (a long silent wait looks
+    like a hang to whoever runs the suite); skip, loudly, if it has not arrived `budget_s` into the
+    session rather than let the run's limit kill every other result with it."""
+    import time
+
+    start = float(os.environ.get("BODGE_AMD_TEST_SESSION_START", time.time()))
+    capture = request.config.pluginmanager.getplugin("capturemanager")
+    waited = time.time()
+    while not ready(0.0):
+        elapsed = time.time() - start
+        if elapsed > budget_s:
+            pytest.skip(f"{name} not read from cold storage after {elapsed:.0f} s of this session")
+        if ready(min(30.0, budget_s - elapsed)):
+            break
+        with capture.global_and_fixture_disabled():
+            print(f"\n[{name}] waiting for the shared object to arrive from cold storage: "
+                  f"{time.time() - waited:.0f} s so far, session at {time.time() - start:.0f} s", flush=True)
+
+
+@pytest.fixture(scope="session")
+def rccl_library(request):
+    """RCCL's 573 MB object in the page cache (tests that create a communicator)."""
+    from bodge_amd import solver
+
+    solver.prefetch_rccl_library()
+    wait_for_library(request, solver.rccl_library_ready, "librccl.so")

@@ -735,7 +735,7 @@ def test_slab_group_matches_whole_matrix(api, solver_cls, name, n_slabs, n_vecto
     assert np.allclose(unit_split[1], unit_ref[1], rtol=0, atol=1e-13)
 
 
-def test_slab_with_rccl_self_exchange(api, solver_cls):
+def test_slab_with_rccl_self_exchange(api, solver_cls, rccl_library):
     """The RCCL send/recv halo path on one GPU: a one-rank plan whose periodic wrap blocks are
     routed through the halo region, exchanged with itself through ncclSend/ncclRecv."""
     from bodge_amd import slab
@@ -763,7 +763,7 @@ def test_slab_with_rccl_self_exchange(api, solver_cls):
     comm.close()
 
 
-def test_free_energy_with_communicator_both_decompositions(api, golden, hip_library):
+def test_free_energy_with_communicator_both_decompositions(api, golden, hip_library, rccl_library):
     """free_energy(comm=...) with a one-rank RCCL communicator: vector-sharded and slab routes."""
     from bodge_amd.solver import Communicator
 

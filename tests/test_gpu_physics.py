@@ -173,7 +173,7 @@ def test_josephson_minigap():
     assert np.allclose(g[0], g[4]) and np.allclose(g[1], g[3])
 
 
-def test_rccl_single_rank_communicator(hip_library):
+def test_rccl_single_rank_communicator(hip_library, rccl_library):
     """The RCCL binding (dlopen, unique id, init, all-reduce) with a world of one rank."""
     from bodge_amd.solver import Communicator
 

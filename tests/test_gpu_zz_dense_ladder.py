@@ -22,24 +22,12 @@ SESSION_BUDGET_S = 780.0
 
 @pytest.fixture(scope="module")
 def dense_library(request):
-    import os
-    import time
+    from conftest import wait_for_library
 
     from bodge_amd import solver
 
-    start = float(os.environ.get("BODGE_AMD_TEST_SESSION_START", time.time()))
-    capture = request.config.pluginmanager.getplugin("capturemanager")
     solver.prefetch_dense_library()
-    waited = time.time()
-    while not solver.dense_library_ready(0.0):
-        elapsed = time.time() - start
-        if elapsed > SESSION_BUDGET_S:
-            pytest.skip(f"rocSOLVER shared object (931 MB) not read from cold storage after {elapsed:.0f} s of this session")
-        if solver.dense_library_ready(min(30.0, SESSION_BUDGET_S - elapsed)):
-            break
-        with capture.global_and_fixture_disabled():  # a long silent wait looks like a hang to whoever runs the suite
-            print(f"\n[dense ladder] waiting for librocsolver.so to arrive from cold storage: "
-                  f"{time.time() - waited:.0f} s so far, session at {time.time() - start:.0f} s", flush=True)
+    wait_for_library(request, solver.dense_library_ready, "librocsolver.so", SESSION_BUDGET_S)
 
 
 def _build(api, name):

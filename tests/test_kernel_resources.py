@@ -44,9 +44,15 @@ def test_headline_kernels_do_not_spill_and_keep_their_occupancy(resources):
 
 @pytest.mark.timeout(600)
 def test_sweep_kernels_fit_two_waves_per_simd_without_spilling(resources):
-    """K7 keeps five site arrays and a plane of prefetch in registers: it must stay within the
-    256-VGPR step (two waves per SIMD) and must not spill, in every arithmetic mode and direction."""
+    """K7 / K7b / K8 keep five to seven site arrays and a plane of prefetch in registers: they must stay
+    within the 256-VGPR step (two waves per SIMD) and must not spill, in every arithmetic mode, lane
+    count and marching direction."""
     for mode in ("RealPHMode", "ComplexPHMode", "RealMode", "ComplexMode"):
         for reverse in ("false", "true"):
-            row = _row(resources, f"cheb_sweep<bdg::{mode}, {reverse}>")
+            for lanes in (1, 2, 4):
+                row = _row(resources, f"cheb_sweep<bdg::{mode}, {lanes}, {reverse}>")
+                assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, reverse, row)
+            row = _row(resources, f"cheb_sweep3<bdg::{mode}, {reverse}>")
             assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, reverse, row)
+        row = _row(resources, f"cheb_roll3<bdg::{mode}>")
+        assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, row)
