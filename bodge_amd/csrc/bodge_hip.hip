@@ -570,13 +570,22 @@ int choose_segments(int n_cols, int lx, int waves, int extra_planes, int min_pla
     return best;
 }
 
-SweepKernel sweep3_kernel(const ModeInfo& mode, bool reverse) {
-    switch (mode.id) {
-        case 1: return reverse ? bdg::cheb_sweep3<RealMode, true> : bdg::cheb_sweep3<RealMode, false>;
-        case 2: return reverse ? bdg::cheb_sweep3<ComplexPHMode, true> : bdg::cheb_sweep3<ComplexPHMode, false>;
-        case 3: return reverse ? bdg::cheb_sweep3<RealPHMode, true> : bdg::cheb_sweep3<RealPHMode, false>;
+template <typename Mode>
+SweepKernel sweep3_kernel_for(int lanes, bool reverse) {
+    switch (lanes) {
+        case 2: return reverse ? bdg::cheb_sweep3<Mode, 2, true> : bdg::cheb_sweep3<Mode, 2, false>;
+        case 4: return reverse ? bdg::cheb_sweep3<Mode, 4, true> : bdg::cheb_sweep3<Mode, 4, false>;
     }
-    return reverse ? bdg::cheb_sweep3<ComplexMode, true> : bdg::cheb_sweep3<ComplexMode, false>;
+    return nullptr;
+}
+
+SweepKernel sweep3_kernel(const ModeInfo& mode, int lanes, bool reverse) {
+    switch (mode.id) {
+        case 1: return sweep3_kernel_for<RealMode>(lanes, reverse);
+        case 2: return sweep3_kernel_for<ComplexPHMode>(lanes, reverse);
+        case 3: return sweep3_kernel_for<RealPHMode>(lanes, reverse);
+    }
+    return sweep3_kernel_for<ComplexMode>(lanes, reverse);
 }
 
 struct SweepPlan {
@@ -652,8 +661,8 @@ int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, int* kind
 int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth, SweepPlan* plan) {
     plan->lanes = lanes;
     plan->depth = depth;
-    plan->kernel = depth == 3 ? sweep3_kernel(mode, false) : sweep_kernel(mode, lanes, false);
-    plan->kernel_reverse = depth == 3 ? sweep3_kernel(mode, true) : sweep_kernel(mode, lanes, true);
+    plan->kernel = depth == 3 ? sweep3_kernel(mode, lanes, false) : sweep_kernel(mode, lanes, false);
+    plan->kernel_reverse = depth == 3 ? sweep3_kernel(mode, lanes, true) : sweep_kernel(mode, lanes, true);
     if (!plan->kernel) return fail(BDG_EINVAL, "the sweep kernel has 1, 2 or 4 lanes per site, not %d", lanes);
     const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
     if (table > kDictLdsLimit) return fail(BDG_EINVAL, "block table too large for the sweep kernel");
@@ -677,7 +686,7 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     a.nb = (int)sys->nb;
     a.plane = (int)plane;
     a.lx = sys->shape[0];
-    const int owned = depth == 3 ? bdg::kSweep3Owned : bdg::sweep_owned(lanes);
+    const int owned = depth == 3 ? bdg::sweep3_owned(lanes) : bdg::sweep_owned(lanes);
     a.n_cols = (int)((plane + owned - 1) / owned);
     // one unit (segment x window) per resident wave, segments of at least 8 planes
     const int waves = per_cu * sys->num_cus * bdg::kSweepWaves;
@@ -708,22 +717,27 @@ double sweep_bytes(const bdg_system* sys, const ModeInfo& mode, int lanes) {
 // Steps per sweep: 3 (cheb_sweep3, 4 lanes per site only) moves 4/9 of the one-step kernels'
 // bytes against 2/3 for 2.  BODGE_AMD_SWEEP_STEPS=2|3 overrides.
 int sweep_depth_for(int lanes) {
-    int depth = lanes == bdg::kSweepLanes ? 3 : 2;
+    int depth = lanes >= 2 ? 3 : 2;
     if (const char* env = getenv("BODGE_AMD_SWEEP_STEPS")) {
         const int forced = atoi(env);
-        if (forced == 2 || (forced == 3 && lanes == bdg::kSweepLanes)) depth = forced;
+        if (forced == 2 || (forced == 3 && lanes >= 2)) depth = forced;
     }
     return depth;
 }
 
+// Default lanes per site: 2.  Fewer lanes mean wider windows (the 3-step kernel owns 26 of 32
+// slots with 2 lanes, 10 of 16 with 4: less recomputed halo per useful site) at the price of
+// shorter x-segments.  Measured on 1000x1000, 8 real vectors: 2 lanes 106.6 k vector-steps/s,
+// 4 lanes 99.9 k (profiles/r02_sweep_experiments.log).
 int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane) {
     if (const char* env = getenv("BODGE_AMD_SWEEP_LANES")) {
         const int forced = atoi(env);
         if (forced == 1 || forced == 2 || forced == 4) return forced;
     }
+    (void)sys;
     (void)n_active;
     (void)per_lane;
-    return bdg::kSweepLanes;
+    return 2;
 }
 
 // ---- 3-D: one step per launch with the x-neighbours in registers (cheb_roll3)

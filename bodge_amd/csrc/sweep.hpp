@@ -357,13 +357,14 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
 //     step 2 on plane k-1   from level 1 [k-2, k-1, k]           -> level 2   (k was just made)
 //     step 3 on plane k-2   from level 2 [k-3, k-2, k-1]         -> level 3
 // a launch may make fewer (steps = 1 or 2: the tail of a run whose length is not a multiple of 3).
-constexpr int kSweep3Owned = kSweepSlots - 6;  // 10 owned positions per wave window
+constexpr int kSweep3Owned = kSweepSlots - 6;  // 10 owned positions per wave window (4 lanes per site)
+constexpr int sweep3_owned(int rl) { return kWave / rl - 6; }
 
-template <typename Mode, bool REV>
+template <typename Mode, int RL, bool REV>
 __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
     extern __shared__ double2 lds[];
-    constexpr int RL = kSweepLanes;
-    constexpr int SLOTS = kSweepSlots;
+    constexpr int SLOTS = kWave / RL;
+    constexpr int OWNED3 = SLOTS - 6;
     constexpr int SPB = Mode::kSlotsPerBlock;
     constexpr int STRIDE = Mode::kBlockStride;
     const int lane = threadIdx.x & (kWave - 1);
@@ -396,7 +397,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
         const int seg = u / a.n_cols, col = u - seg * a.n_cols;
         const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
         const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
-        const int p = col * kSweep3Owned - 3 + s;
+        const int p = col * OWNED3 - 3 + s;
         const bool valid = p >= 0 && p < a.plane;
         const bool ok1 = valid && s >= 1 && s <= SLOTS - 2;
         const bool ok2 = valid && s >= 2 && s <= SLOTS - 3;

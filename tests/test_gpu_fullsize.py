@@ -81,7 +81,9 @@ def test_size_independent_properties(big):
         ({"BODGE_AMD_ALTERNATE": "0", "BODGE_AMD_SWEEP_ZIGZAG": "0"}, lambda p: p["steps_per_launch"] == 3),
         ({"BODGE_AMD_SWEEP_SEGMENTS": "7"}, lambda p: p["steps_per_launch"] == 3),
         ({"BODGE_AMD_SWEEP_STEPS": "2"}, lambda p: p["steps_per_launch"] == 2),
-        ({"BODGE_AMD_SWEEP_STEPS": "2", "BODGE_AMD_SWEEP_LANES": "2"}, lambda p: p["steps_per_launch"] == 2 and p["lanes_per_row"] == 2),
+        ({"BODGE_AMD_SWEEP_STEPS": "2", "BODGE_AMD_SWEEP_LANES": "4"}, lambda p: p["steps_per_launch"] == 2 and p["lanes_per_row"] == 4),
+        ({"BODGE_AMD_SWEEP_LANES": "4"}, lambda p: p["steps_per_launch"] == 3 and p["lanes_per_row"] == 4),
+        ({"BODGE_AMD_SWEEP_STEPS": "2", "BODGE_AMD_SWEEP_LANES": "1"}, lambda p: p["steps_per_launch"] == 2 and p["lanes_per_row"] == 1),
         ({"BODGE_AMD_DICT": "0"}, lambda p: p["dict_blocks"] == 0 and p["pipelined"] == 1),
         ({"BODGE_AMD_DICT": "0", "BODGE_AMD_PH": "0"}, lambda p: p["ph_packed"] == 0),
         ({"BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"}, lambda p: p["real_arithmetic"] == 0),
@@ -113,10 +115,11 @@ def test_config3_1000x1000_512_moments_full_length_against_cpu_on_the_same_vecto
     assert np.allclose(d_ref[:8, :2], d2, rtol=0, atol=1e-12 * n) and np.allclose(e_ref[:8, :2], e2, rtol=0, atol=1e-12 * n)
     # default route at this size: two recurrence steps per sweep (sweep.hpp) ...
     (d, e), perf = _with_env(solver, {}, scale, moments // 2, vectors, seed=0)
-    assert perf["steps_per_launch"] == 3 and perf["launches"] == 4 * 21 + 2  # chunks of 63 steps + the 64th; 256 = 4 x 64
+    # (two batches of 4 vectors; per batch 4 chunks of 63 steps = 21 sweeps each, and 3 + 1 steps at the end)
+    assert perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == 2 and perf["launches"] == 2 * (4 * 21 + 2)
     # ... its two-step sibling ...
     (d2s, e2s), perf2 = _with_env(solver, {"BODGE_AMD_SWEEP_STEPS": "2"}, scale, moments // 2, vectors, seed=0)
-    assert perf2["steps_per_launch"] == 2 and perf2["launches"] == moments // 4
+    assert perf2["steps_per_launch"] == 2 and perf2["launches"] == 2 * (moments // 4)
     assert np.abs(d2s - d_ref).max() <= 1e-12 * n and np.abs(e2s - e_ref).max() <= 1e-12 * n
     assert np.abs(d - d_ref).max() <= 1e-12 * n and np.abs(e - e_ref).max() <= 1e-12 * n
     # ... and the one-step dictionary kernel, same vectors, full length as well

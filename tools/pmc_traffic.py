@@ -24,7 +24,7 @@ import re
 
 
 def kernel_key(name: str) -> str:
-    m = re.search(r"cheb_sweep3<bdg::(\w+), (?:true|false)>", name)  # both marching directions count as one kernel
+    m = re.search(r"cheb_sweep3<bdg::(\w+), \d, (?:true|false)>", name)  # both marching directions count as one kernel
     if m:
         return f"cheb_sweep3<{m.group(1)}>"
     m = re.search(r"cheb_sweep<bdg::(\w+), \d, (?:true|false)>", name)
