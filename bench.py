@@ -298,9 +298,9 @@ def main():
     def kernel_label(pf):
         mode = f"{'Real' if pf['real_arithmetic'] else 'Complex'}{'PH' if pf['ph_packed'] else ''}Mode"
         if pf["steps_per_launch"] == 3:
-            return f"cheb_sweep3<{mode}>"
+            return f"cheb_sweep3<{mode},{pf['lanes_per_row']}>"
         if pf["steps_per_launch"] == 2:
-            return f"cheb_sweep<{mode}>"
+            return f"cheb_sweep<{mode},{pf['lanes_per_row']}>"
         if pf["rolling"]:
             return f"cheb_roll3<{mode}>"
         family = "cheb_step_dict" if pf["dict_blocks"] else "cheb_step_pipelined" if pf["pipelined"] else "cheb_step"
@@ -399,6 +399,7 @@ def main():
             "kernel": kernel_name,
             "launch_ms": launch_ms,
             "steps_per_launch": perf["steps_per_launch"],
+            "vectors_per_launch": perf["vectors_per_launch"],
             "x_neighbours_in_registers": bool(perf["steps_per_launch"] >= 2 or perf["rolling"]),
             "launches": perf["launches"],
             "bytes_per_launch": perf["bytes_per_launch"],

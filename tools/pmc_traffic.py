@@ -24,12 +24,9 @@ import re
 
 
 def kernel_key(name: str) -> str:
-    m = re.search(r"cheb_sweep3<bdg::(\w+), \d, (?:true|false)>", name)  # both marching directions count as one kernel
+    m = re.search(r"(cheb_sweep3?)<bdg::(\w+), (\d), (?:true|false)>", name)  # both marching directions count as one kernel
     if m:
-        return f"cheb_sweep3<{m.group(1)}>"
-    m = re.search(r"cheb_sweep<bdg::(\w+), \d, (?:true|false)>", name)
-    if m:
-        return f"cheb_sweep<{m.group(1)}>"
+        return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
     m = re.search(r"cheb_roll3<bdg::(\w+)>", name)
     if m:
         return f"cheb_roll3<{m.group(1)}>"
