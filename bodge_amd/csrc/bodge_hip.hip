@@ -597,10 +597,15 @@ struct SweepPlan {
     bdg::SweepArgs args{};
 };
 
-// Smallest lattice the sweep form is chosen for by default: below this the x-segments get so short
-// that the two extra planes each wave recomputes at either end eat the saving, and the vectors
-// are Infinity-Cache resident anyway.  BODGE_AMD_SWEEP=0 never, =1 whenever the matrix qualifies.
-constexpr int64_t kSweepMinSites = 600000;
+// Smallest lattices the stencil kernels are chosen for by default.  Below, the x-segments get so
+// short that the planes each wave recomputes at their ends eat the saving, and the one-step
+// kernels work from the Infinity Cache with wide batches.  Measured with 64-vector calls
+// (profiles/r02_sweep_experiments.log): 300x300 one-step 725 k vector-steps/s vs 504 k, 400x400 407 k
+// vs 458 k, 500x500 252 k vs 326 k, 700x700 130 k vs 193 k, 1000x1000 57 k vs 104 k.
+// BODGE_AMD_SWEEP=0 never, =1 whenever the matrix qualifies.
+constexpr int64_t kSweepMinSites = 150000;   // 2-D: multi-step sweeps (K7, K7b)
+constexpr int64_t kRollMinSites = 600000;    // 3-D: rolling one-step kernel (K8)
+constexpr int64_t kSweepTwoLaneSites = 450000;  // from here on 2 lanes per site beat 4
 
 // Stencil table of the matrix (built once per lattice shape).  *kind = 1: 5-point stencil whose
 // planes are lines (2-D lattice: the two-steps-per-sweep kernel applies), 2: 7-point stencil of a
@@ -652,10 +657,13 @@ int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, int* kind
     *kind = 0;
     const char* env = getenv("BODGE_AMD_SWEEP");
     if ((env && env[0] == '0') || !random_start || col_scalars || !sys->peers.empty()) return BDG_OK;
-    if (!(env && env[0] == '1') && sys->nb < kSweepMinSites) return BDG_OK;
+    const bool forced = env && env[0] == '1';
+    if (!forced && sys->nb < std::min(kSweepMinSites, kRollMinSites)) return BDG_OK;
     const char* dict_env = getenv("BODGE_AMD_DICT");
     if (dict_env && dict_env[0] == '0') return BDG_OK;
-    return ensure_stencil(sys, kind);
+    if (int rc = ensure_stencil(sys, kind)) return rc;
+    if (!forced && sys->nb < (*kind == 2 ? kRollMinSites : kSweepMinSites)) *kind = 0;
+    return BDG_OK;
 }
 
 int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth, SweepPlan* plan) {
@@ -734,10 +742,9 @@ int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane) {
         const int forced = atoi(env);
         if (forced == 1 || forced == 2 || forced == 4) return forced;
     }
-    (void)sys;
     (void)n_active;
     (void)per_lane;
-    return 2;
+    return sys->nb >= kSweepTwoLaneSites ? 2 : 4;  // small lattices: more work per launch matters more
 }
 
 // ---- 3-D: one step per launch with the x-neighbours in registers (cheb_roll3)

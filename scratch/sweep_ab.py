@@ -21,6 +21,7 @@ with sysm as (H, D):
         H.set_sites(3.0 * ba.σ0 - 0.05 * ba.σ3); D.set_sites(-0.1 * ba.jσ2); H.set_bonds(-1.0 * ba.σ0)
 indptr, indices, data = sysm.bsr_arrays()
 scale = chebyshev.spectral_bound(indptr, data)
+NV = int(os.environ.get("AB_VECTORS", "8"))
 variants = []
 for spec in sys.argv[1:]:
     label, _, envs = spec.partition(":")
@@ -33,7 +34,7 @@ with DeviceSolver(indptr, indices, data) as dev:
     for rep in range(5):
         for label, env in variants:
             os.environ.update(env)
-            d, e = dev.dots_random(scale, 256, 8, seed=0)
+            d, e = dev.dots_random(scale, 256, NV, seed=0)
             p = dev.perf()
             for k in env:
                 del os.environ[k]
@@ -46,6 +47,7 @@ with DeviceSolver(indptr, indices, data) as dev:
     for label, _ in variants:
         t = statistics.median(times[label])
         p = info[label]
-        print(f"{label:34s} {t:7.1f} us/launch (min {min(times[label]):6.1f})  {p['bytes_per_launch'] / t / 1e6:5.2f} TB/s alg  "
+        total_us = p["kernel_ms"] * 1e3
+        print(f"{label:34s} [{NV * 256 / total_us * 1e3:7.1f} k vector-steps/s over the whole call] {t:7.1f} us/launch (min {min(times[label]):6.1f})  {p['bytes_per_launch'] / t / 1e6:5.2f} TB/s alg  "
               f"{p['vectors_per_launch'] * p['steps_per_launch'] / t * 1e3:6.1f} k vector-steps/s  grid={p['grid']} rolling={p['rolling']} lanes={p['lanes_per_row']} "
               f"steps/launch={p['steps_per_launch']}", flush=True)

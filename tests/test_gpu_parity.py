@@ -283,8 +283,9 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
                                       (8, per_group, {"BODGE_AMD_SWEEP_STEPS": "2"}),  # cheb_sweep (two steps) instead of cheb_sweep3
                                       (7, 3, {"BODGE_AMD_SWEEP_STEPS": "2", "BODGE_AMD_SWEEP_ZIGZAG": "0"}),
                                       (6, 5, {"BODGE_AMD_SWEEP_LANES": "1"}),  # 60-position windows, 2 real / 1 complex vector per launch
-                                      (5, 3, {"BODGE_AMD_SWEEP_LANES": "4"}),  # 10-position windows (3 steps), 12 (2 steps)
-                                      (5, 5, {"BODGE_AMD_SWEEP_LANES": "4", "BODGE_AMD_SWEEP_STEPS": "2"}),
+                                      (5, 3, {"BODGE_AMD_SWEEP_LANES": "2"}),  # 26-position windows (3 steps), the default from 4.5e5 sites
+                                      (7, 5, {"BODGE_AMD_SWEEP_LANES": "2", "BODGE_AMD_SWEEP_SEGMENTS": "2"}),
+                                      (5, 5, {"BODGE_AMD_SWEEP_LANES": "2", "BODGE_AMD_SWEEP_STEPS": "2"}),  # 28-position windows
                                       (4, 3, {"BODGE_AMD_NO_DIAGONAL_BLOCKS": "1"})]:  # (read at upload: no effect here, see below)
             ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 5, range(vectors), vec_kind))
             monkeypatch.setenv("BODGE_AMD_SWEEP", "0")
@@ -300,7 +301,7 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
                 monkeypatch.delenv(key)
             stencil = is_stencil and block_storage == "dictionary"  # (the stencil forms read the block dictionary)
             swept, rolled = stencil and not three_d, stencil and three_d
-            lanes = int(extra.get("BODGE_AMD_SWEEP_LANES", 2)) if swept else 4  # (default: 2 lanes per site)
+            lanes = int(extra.get("BODGE_AMD_SWEEP_LANES", 4)) if swept else 4  # (default below 4.5e5 sites: 4 lanes per site)
             depth = int(extra.get("BODGE_AMD_SWEEP_STEPS", 3 if lanes >= 2 else 2))  # steps per sweep
             assert perf["steps_per_launch"] == (depth if swept else 1) and (perf["rolling"] == 1) == rolled, perf
             batches = -(-vectors // (per_group * lanes // 4))
