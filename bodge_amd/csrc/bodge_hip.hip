@@ -1895,6 +1895,9 @@ int lanczos_advance(bdg_system* sys, int n_iter, double* alpha_out, double* beta
 // One-sided Jacobi on the GPU for matrices up to kJacobiLimit (no external library: the first
 // use of rocSOLVER on a fresh machine pages in ~1 GB and was measured at 1.5-7.5 minutes).
 constexpr int64_t kJacobiLimit = 256 * bdg::kJacobiElems;  // 2048: a column pair fits the registers of a workgroup
+// With 16 elements per thread the same kernels reach 4096 (n = 3600: ~3 s against rocSOLVER's 0.13 s):
+// used while the rocSOLVER object has not arrived from cold storage yet, which takes minutes.
+constexpr int64_t kJacobiWideLimit = 256 * bdg::kJacobiElemsWide;
 
 inline void scatter_for_jacobi(bdg_system* sys, double2* G, hipStream_t st) {
     bdg::scatter_dense<<<(unsigned)sys->nb, 128, 0, st>>>(sys->indptr.ptr, sys->indices.ptr, sys->blocks.ptr, G,
@@ -1909,8 +1912,9 @@ inline void scatter_for_jacobi(bdg_system* sys, double* G, hipStream_t st) {
 template <typename T>
 int eigh_jacobi_typed(bdg_system* sys, double* w_out, double* z_out) {
     const int64_t n = 4 * sys->nb;
-    if (n > 256 * bdg::kJacobiElems)
-        return fail(BDG_EINVAL, "the Jacobi kernels hold a column pair in registers: 4*nb <= %d", 256 * bdg::kJacobiElems);
+    if (n > kJacobiWideLimit)
+        return fail(BDG_EINVAL, "the Jacobi kernels hold a column pair in registers: 4*nb <= %d", (int)kJacobiWideLimit);
+    const bool wide = n > kJacobiLimit;
     hipStream_t st = sys->stream;
     DeviceBuffer<T> G, V;
     DeviceBuffer<double> eig;
@@ -1931,9 +1935,14 @@ int eigh_jacobi_typed(bdg_system* sys, double* w_out, double* z_out) {
         int sweep = 0;
         for (; sweep < max_sweeps; ++sweep) {
             HIP_TRY(hipMemsetAsync(counter.ptr, 0, sizeof(int), st));
-            for (int round = 0; round < n - 1; ++round)
-                bdg::jacobi_round<T><<<(unsigned)(n / 2), 256, 0, st>>>(G.ptr, z_out ? V.ptr : nullptr, (int)n,
-                                                                         round, 1e-15, counter.ptr);
+            for (int round = 0; round < n - 1; ++round) {
+                if (wide)
+                    bdg::jacobi_round<T, bdg::kJacobiElemsWide><<<(unsigned)(n / 2), 256, 0, st>>>(
+                        G.ptr, z_out ? V.ptr : nullptr, (int)n, round, 1e-15, counter.ptr);
+                else
+                    bdg::jacobi_round<T, bdg::kJacobiElems><<<(unsigned)(n / 2), 256, 0, st>>>(
+                        G.ptr, z_out ? V.ptr : nullptr, (int)n, round, 1e-15, counter.ptr);
+            }
             int rotations = 0;
             HIP_TRY(hipMemcpyAsync(&rotations, counter.ptr, sizeof(int), hipMemcpyDeviceToHost, st));
             HIP_TRY(hipStreamSynchronize(st));
@@ -2523,7 +2532,13 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     const int64_t n = 4 * sys->nb;
     {
         const char* forced = getenv("BODGE_AMD_EIGH");
-        const bool own = forced ? std::string(forced) == "jacobi" : n <= kJacobiLimit;
+        bool own = forced ? std::string(forced) == "jacobi" : n <= kJacobiLimit;
+        if (!forced && n > kJacobiLimit && n <= kJacobiWideLimit) {
+            // the library solves this size in 0.1-0.2 s once loaded, but from cold storage its 931 MB take
+            // minutes to arrive: until they have (read on in the background), the own kernels serve
+            g_solver_prefetch.start();
+            own = !g_solver_prefetch.wait(0.0);
+        }
         if (own) return eigh_jacobi(sys, w_out, z_out);
     }
     SolverApi* api = nullptr;

@@ -1170,11 +1170,13 @@ __device__ inline void jrotate(double& x, double& y, double cs, double sn, doubl
 
 // One round.  The two columns of G stay in registers between the dot products and the rotation
 // (n <= 256 * kJacobiElems), so G is read once and written once per round; V is read and written.
-constexpr int kJacobiElems = 8;
+constexpr int kJacobiElems = 8;       // n <= 2048
+constexpr int kJacobiElemsWide = 16;  // n <= 4096 (twice the registers per thread)
 
-template <typename T>
+template <typename T, int ELEMS>
 __global__ __launch_bounds__(256) void jacobi_round(T* __restrict__ G, T* __restrict__ V, int n, int round,
                                                     double tol, int* __restrict__ rotations) {
+    constexpr int kJacobiElems = ELEMS;
     __shared__ double red[4][256];
     __shared__ double rot[4];  // cs, sn, cos φ, sin φ  (sn = 0: skip)
     int p, q;

@@ -955,3 +955,21 @@ def test_lowest_eigenpairs_with_multiplicities_and_vectors(api, golden, name, k)
         assert np.abs(dense @ shaped[n].reshape(-1) - vals2[n] * shaped[n].reshape(-1)).max() <= 1e-8
     with pytest.raises(Exception):
         system.lowest_eigenpairs(k, format="foo")
+
+
+@pytest.mark.parametrize("name", ["swave30_zeeman", "peierls30"])
+def test_own_jacobi_kernels_reach_4096_rows(api, golden, monkeypatch, name):
+    """Between 4N = 2048 and 4096 the own one-sided Jacobi kernels (16 elements per thread) serve
+    for as long as the rocSOLVER object has not arrived from cold storage; forced here.  n = 3600,
+    real and complex, against the reference's own spectra: eigenvalues 1e-10, residual 1e-9."""
+    monkeypatch.setenv("BODGE_AMD_EIGH", "jacobi")
+    system = _build(api, name)
+    vals, vecs = system.diagonalize(format="raw")
+    ref = golden.eigenvalues(name)
+    assert vals.shape == ref.shape and np.abs(vals - ref).max() <= 1e-10
+    bsr = system.matrix("bsr")
+    assert np.isfinite(vecs).all() and np.abs(bsr @ vecs - vecs * vals).max() <= 1e-9
+    idx = np.arange(0, vals.size, 97)
+    gram = vecs[:, idx].conj().T @ vecs
+    gram[np.arange(idx.size), idx] -= 1.0
+    assert np.abs(gram).max() <= 1e-9

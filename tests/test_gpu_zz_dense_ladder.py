@@ -43,8 +43,9 @@ def test_dense_ladder_above_the_jacobi_limit_matches_reference(api, golden, monk
     literal "300" chain (n = 1200, sent to rocSOLVER here as well): eigenvalues within 1e-10 of the
     reference's, eigen-equation residual <= 1e-9, orthonormal finite vectors, reference shapes,
     and F(T) from the same spectrum within 1e-10 relative."""
-    if name == "chain300":
-        monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")  # 4N = 1200 would use the own Jacobi kernels
+    # pin the library route: 4N = 1200 would use the own Jacobi kernels, and so would 4N = 3600 while the
+    # library is still cold (tests/test_gpu_parity.py::test_own_jacobi_kernels_reach_4096_rows covers those)
+    monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")
     system = _build(api, name)
     dim = system.shape[0]
     data = system._data
