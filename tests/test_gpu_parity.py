@@ -737,53 +737,6 @@ def test_slab_group_matches_whole_matrix(api, solver_cls, name, n_slabs, n_vecto
     assert np.allclose(unit_split[1], unit_ref[1], rtol=0, atol=1e-13)
 
 
-def test_slab_with_rccl_self_exchange(api, solver_cls, rccl_library):
-    """The RCCL send/recv halo path on one GPU: a one-rank plan whose periodic wrap blocks are
-    routed through the halo region, exchanged with itself through ncclSend/ncclRecv."""
-    from bodge_amd import slab
-    from bodge_amd.solver import Communicator
-
-    system = systems.random_periodic(api, shape=(40, 4, 3), seed=5)  # 480 rows: interior and boundary tiles
-    indptr, indices, data = system.bsr_arrays()
-    plan = slab.build_plan(indptr, indices, data, np.array([0, system.lattice.size]), 0, self_exchange=True)
-    assert plan.halo_rows == 24
-    bsr = system.matrix("bsr")
-    scale = cheb_ref.spectral_bound(bsr)
-    comm = Communicator(0, 1, 0, Communicator.new_unique_id())
-    ref = cheb_ref.recurrence_dots(bsr, scale, 32, cheb_ref.random_block(bsr.shape[0], 8, range(5), cheb_ref.VEC_Z4))
-    import os
-
-    for overlap in ("1", "0"):  # exchange hidden behind the interior rows / exchange then compute
-        os.environ["BODGE_AMD_OVERLAP"] = overlap
-        try:
-            with solver_cls.from_slab_plan(plan, comm=comm) as dev:
-                got = dev.dots_random(scale, 16, 5, seed=8, kind=cheb_ref.VEC_Z4)
-        finally:
-            del os.environ["BODGE_AMD_OVERLAP"]
-        assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * bsr.shape[0])
-        assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * bsr.shape[0])
-    comm.close()
-
-
-def test_free_energy_with_communicator_both_decompositions(api, golden, hip_library, rccl_library):
-    """free_energy(comm=...) with a one-rank RCCL communicator: vector-sharded and slab routes."""
-    from bodge_amd.solver import Communicator
-
-    comm = Communicator(0, 1, 0, Communicator.new_unique_id())
-    system = _build(api, "snf")
-    for decomposition in ("vectors", "slab"):
-        exact = system.free_energy(1.0, method="chebyshev", trace="exact", moments=64, comm=comm,
-                                   decomposition=decomposition)
-        assert np.isclose(exact, golden.free_energy("snf", 1.0), rtol=1e-10, atol=0)
-    a = system.free_energy(1.0, method="chebyshev", trace="stochastic", moments=64, vectors=16, comm=comm)
-    b = system.free_energy(1.0, method="chebyshev", trace="stochastic", moments=64, vectors=16, comm=comm,
-                           decomposition="slab")
-    assert np.isclose(a, b, rtol=1e-12)
-    with pytest.raises(RuntimeError):
-        system.free_energy(1.0, method="chebyshev", comm=comm, decomposition="rows")
-    comm.close()
-
-
 # ------------------------------------------------------------------ Lanczos / gap
 @pytest.mark.parametrize("name,k", [("swave20", 3), ("complex235", 2), ("snf", 2), ("chain128", 3), ("dwave8", 2)])
 def test_lowest_eigenvalues_match_dense_spectrum(api, golden, name, k):

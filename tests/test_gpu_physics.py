@@ -171,15 +171,3 @@ def test_josephson_minigap():
     g = [minigap(x * π) for x in (0.0, 0.5, 1.0, 1.5, 2.0)]
     assert g[0] > g[1] > g[2]
     assert np.allclose(g[0], g[4]) and np.allclose(g[1], g[3])
-
-
-def test_rccl_single_rank_communicator(hip_library, rccl_library):
-    """The RCCL binding (dlopen, unique id, init, all-reduce) with a world of one rank."""
-    from bodge_amd.solver import Communicator
-
-    comm = Communicator(0, 1, 0, Communicator.new_unique_id())
-    values = np.array([1.5, -2.0, 3.25])
-    assert np.array_equal(comm.allreduce_sum(values), values)
-    assert np.array_equal(comm.allreduce_max(values), values)
-    comm.barrier()
-    comm.close()

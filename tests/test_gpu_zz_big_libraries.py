@@ -1,16 +1,28 @@
-"""Dense route above the own Jacobi kernels' limit (4N > 2048): rocSOLVER dsyevd / zheevd.
+"""Tests that need one of the big ROCm shared objects: RCCL (573 MB; the one-rank communicator
+tests) and rocSOLVER (931 MB; the dense route above the own Jacobi kernels' limit, dsyevd / zheevd).
 
-Kept in a file of its own that sorts last: the first use of rocSOLVER on a fresh machine has to
-bring a 931 MB shared object in (the library streams the file through the page cache first,
-`warm_page_cache` in bodge_hip.hip), so everything else has already been reported by then.
+Kept in a file of its own that sorts last: on a fresh machine those objects take minutes to come
+off cold storage (the library streams them through the page cache on background threads started
+at session start, tests/conftest.py), so everything else has already been reported by then.  The
+RCCL tests come first - the smaller file arrives first.
 """
+
+import os
 
 import numpy as np
 import pytest
 
 import systems
+from oracle import cheb_ref
 
 pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def solver_cls(hip_library):
+    from bodge_amd.solver import DeviceSolver
+
+    return DeviceSolver
 
 
 # The driver gives the whole `-m gpu` run 900 s.  From cold storage the rocSOLVER object takes
@@ -33,6 +45,65 @@ def dense_library(request):
 def _build(api, name):
     spec = systems.CATALOG[name]
     return spec["build"](api, **spec["kwargs"])
+
+
+def test_slab_with_rccl_self_exchange(api, solver_cls, rccl_library):
+    """The RCCL send/recv halo path on one GPU: a one-rank plan whose periodic wrap blocks are
+    routed through the halo region, exchanged with itself through ncclSend/ncclRecv."""
+    from bodge_amd import slab
+    from bodge_amd.solver import Communicator
+
+    system = systems.random_periodic(api, shape=(40, 4, 3), seed=5)  # 480 rows: interior and boundary tiles
+    indptr, indices, data = system.bsr_arrays()
+    plan = slab.build_plan(indptr, indices, data, np.array([0, system.lattice.size]), 0, self_exchange=True)
+    assert plan.halo_rows == 24
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    comm = Communicator(0, 1, 0, Communicator.new_unique_id())
+    ref = cheb_ref.recurrence_dots(bsr, scale, 32, cheb_ref.random_block(bsr.shape[0], 8, range(5), cheb_ref.VEC_Z4))
+    import os
+
+    for overlap in ("1", "0"):  # exchange hidden behind the interior rows / exchange then compute
+        os.environ["BODGE_AMD_OVERLAP"] = overlap
+        try:
+            with solver_cls.from_slab_plan(plan, comm=comm) as dev:
+                got = dev.dots_random(scale, 16, 5, seed=8, kind=cheb_ref.VEC_Z4)
+        finally:
+            del os.environ["BODGE_AMD_OVERLAP"]
+        assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * bsr.shape[0])
+        assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * bsr.shape[0])
+    comm.close()
+
+
+def test_free_energy_with_communicator_both_decompositions(api, golden, hip_library, rccl_library):
+    """free_energy(comm=...) with a one-rank RCCL communicator: vector-sharded and slab routes."""
+    from bodge_amd.solver import Communicator
+
+    comm = Communicator(0, 1, 0, Communicator.new_unique_id())
+    system = _build(api, "snf")
+    for decomposition in ("vectors", "slab"):
+        exact = system.free_energy(1.0, method="chebyshev", trace="exact", moments=64, comm=comm,
+                                   decomposition=decomposition)
+        assert np.isclose(exact, golden.free_energy("snf", 1.0), rtol=1e-10, atol=0)
+    a = system.free_energy(1.0, method="chebyshev", trace="stochastic", moments=64, vectors=16, comm=comm)
+    b = system.free_energy(1.0, method="chebyshev", trace="stochastic", moments=64, vectors=16, comm=comm,
+                           decomposition="slab")
+    assert np.isclose(a, b, rtol=1e-12)
+    with pytest.raises(RuntimeError):
+        system.free_energy(1.0, method="chebyshev", comm=comm, decomposition="rows")
+    comm.close()
+
+
+def test_rccl_single_rank_communicator(hip_library, rccl_library):
+    """The RCCL binding (dlopen, unique id, init, all-reduce) with a world of one rank."""
+    from bodge_amd.solver import Communicator
+
+    comm = Communicator(0, 1, 0, Communicator.new_unique_id())
+    values = np.array([1.5, -2.0, 3.25])
+    assert np.array_equal(comm.allreduce_sum(values), values)
+    assert np.array_equal(comm.allreduce_max(values), values)
+    comm.barrier()
+    comm.close()
 
 
 # BASELINE config 5's feasible ladder (SURVEY §8d item 5): goldens are the reference's own
