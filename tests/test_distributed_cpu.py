@@ -102,7 +102,7 @@ def test_rccl_rendezvous_under_torchrun(tmp_path):
         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
         os.path.join(ROOT, "tests", "_rdzv_worker.py"), str(tmp_path),
     ]
-    env = dict(os.environ, BODGE_AMD_RDZV_DIR=str(tmp_path))
+    env = dict(os.environ)
     proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
     assert proc.returncode == 0, proc.stderr[-2000:]
     ranks = [json.loads((tmp_path / f"rank{r}.json").read_text()) for r in range(4)]
@@ -123,7 +123,7 @@ def test_bench_host_fallback_when_rccl_is_unavailable_and_allowed(tmp_path):
         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
         os.path.join(ROOT, "tests", "_fallback_worker.py"), str(tmp_path),
     ]
-    env = dict(os.environ, BODGE_AMD_RDZV_DIR=str(tmp_path))
+    env = dict(os.environ)
     proc = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=540)
     assert proc.returncode == 0, proc.stderr[-2000:]
     for r in range(2):
