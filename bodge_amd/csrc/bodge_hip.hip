@@ -155,6 +155,7 @@ struct bdg_system {
     // are lines), 2 = 7-point table built (3-D), -1 = not a stencil
     DeviceBuffer<uint2> stencil;
     int stencil_state = 0;
+    bool stencil_wrap_p = false, stencil_wrap_x = false;  // periodic edge blocks: planes / stack of planes are rings
     DeviceBuffer<double> partial, dots;
     double* host_dots = nullptr;  // pinned staging for the dot products (sized like `dots`)
     size_t host_dots_count = 0;
@@ -622,10 +623,10 @@ int ensure_stencil(bdg_system* sys, int* kind) {
             sys->max_row_blocks <= (three_d ? 7 : 5) && sys->nnzb > 0) {
             if (int rc = sys->stencil.reserve((size_t)sys->nb)) return rc;
             DeviceBuffer<int> bad;
-            if (int rc = bad.reserve(1)) return rc;
-            int host_bad = 1;
+            if (int rc = bad.reserve(3)) return rc;
+            int host_bad[3] = {1, 0, 0};  // {not a stencil, periodic inside the planes, periodic across the planes}
             auto body = [&]() -> int {
-                HIP_TRY(hipMemsetAsync(bad.ptr, 0, sizeof(int), sys->stream));
+                HIP_TRY(hipMemsetAsync(bad.ptr, 0, 3 * sizeof(int), sys->stream));
                 const unsigned grid = (unsigned)std::min<int64_t>(4096, (sys->nb + 255) / 256);
                 if (three_d)
                     bdg::build_stencil3<<<grid, 256, 0, sys->stream>>>(sys->indptr.ptr, sys->dict_ids.ptr,
@@ -636,15 +637,20 @@ int ensure_stencil(bdg_system* sys, int* kind) {
                                                                        sys->dict_diagonal.ptr, (int)sys->nb, (int)plane,
                                                                        sys->stencil.ptr, bad.ptr);
                 HIP_TRY(hipGetLastError());
-                HIP_TRY(hipMemcpyAsync(&host_bad, bad.ptr, sizeof(int), hipMemcpyDeviceToHost, sys->stream));
+                HIP_TRY(hipMemcpyAsync(host_bad, bad.ptr, 3 * sizeof(int), hipMemcpyDeviceToHost, sys->stream));
                 HIP_TRY(hipStreamSynchronize(sys->stream));
                 return BDG_OK;
             };
             const int rc = body();
             bad.release();
             if (rc) return rc;
-            if (host_bad == 0) sys->stencil_state = three_d ? 2 : 1;
-            else sys->stencil.release();
+            if (host_bad[0] == 0) {
+                sys->stencil_state = three_d ? 2 : 1;
+                sys->stencil_wrap_p = host_bad[1] != 0;
+                sys->stencil_wrap_x = host_bad[2] != 0;
+            } else {
+                sys->stencil.release();
+            }
         }
     }
     *kind = std::max(0, sys->stencil_state);
@@ -703,6 +709,8 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     a.n_segs = std::max(1, std::min(n_segs, a.lx / 8));
     a.zigzag = 1;
     if (const char* env = getenv("BODGE_AMD_SWEEP_ZIGZAG")) a.zigzag = atoi(env) != 0;
+    a.wrap_p = sys->stencil_wrap_p ? 1 : 0;
+    a.wrap_x = sys->stencil_wrap_x ? 1 : 0;
     const int64_t units = (int64_t)a.n_cols * a.n_segs;
     const int grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus, (units + bdg::kSweepWaves - 1) / bdg::kSweepWaves);
     plan->grid = std::max(8, (grid + 7) / 8 * 8);

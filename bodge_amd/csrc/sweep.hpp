@@ -72,6 +72,8 @@ struct SweepArgs {
     double* partial3;        // cheb_sweep3: dots of step 3
     int stream;              // non-temporal hints: bit 0 t_{n-1} loads, bit 1 stores, bit 2 t_n loads
     int zigzag;              // 1 = odd segments march against the even ones
+    int wrap_p;              // 1 = the plane is a ring: position P-1 neighbours position 0 (periodic edge blocks)
+    int wrap_x;              // 1 = the planes form a ring: plane lx-1 neighbours plane 0
 };
 
 // Stencil table + eligibility test, on the device from the uploaded arrays.  `words` is the
@@ -80,13 +82,18 @@ struct SweepArgs {
 // Byte 5 of the word (K7; byte 7 for K8's seven offsets) is a bit mask: bit o set = the block at
 // offset o is diagonal as a 4x4 matrix (`diagonal[id]`, found on the host when the blocks were
 // deduplicated), so that its product takes 4 multiply-adds per vector instead of 16.
+// Periodic lattices: the wrap-around blocks of the reference's `lattice.edges()` (position P-1 <->
+// position 0 inside a plane, plane lx-1 <-> plane 0) are the same neighbours seen across the
+// seam; they take the slots of the -1 / +1 / -P / +P neighbours they are, and bad[1] / bad[2]
+// tell the kernels to close the plane / the stack of planes into rings.
 __global__ void build_stencil(const int* __restrict__ indptr, const int* __restrict__ words,
                               const int* __restrict__ diagonal, int nb, int plane,
                               uint2* __restrict__ stencil, int* __restrict__ bad) {
+    const int lx = nb / plane;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
         unsigned id[5] = {kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock};
         unsigned mask = 0;
-        const int p = i % plane;
+        const int p = i % plane, x = i / plane;
         bool ok = true;
         for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
             const unsigned w = (unsigned)words[k];
@@ -97,6 +104,19 @@ __global__ void build_stencil(const int* __restrict__ indptr, const int* __restr
             else if (off == 0) slot = 2;
             else if (off == 1 && p <= plane - 2) slot = 3;
             else if (off == plane) slot = 4;
+            else if (off == plane - 1 && p == 0) {
+                slot = 1;
+                atomicOr(bad + 1, 1);
+            } else if (off == -(plane - 1) && p == plane - 1) {
+                slot = 3;
+                atomicOr(bad + 1, 1);
+            } else if (off == (lx - 1) * plane && x == 0) {
+                slot = 0;
+                atomicOr(bad + 2, 1);
+            } else if (off == -(lx - 1) * plane && x == lx - 1) {
+                slot = 4;
+                atomicOr(bad + 2, 1);
+            }
             if (slot < 0 || (w >> 24) == kNoBlock) ok = false;
             else {
                 id[slot] = w >> 24;
@@ -183,16 +203,20 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
         const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
         const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
         const int p = col * OWNED - 2 + s;
-        const bool valid = p >= 0 && p < a.plane;
+        const bool inside = p >= 0 && p < a.plane;
+        const bool valid = inside || a.wrap_p;  // a ring has no edge: halo slots beyond it hold the far side
+        const int pw = inside ? p : ((p % a.plane) + a.plane) % a.plane;
         const bool does1 = valid && s >= 1 && s <= SLOTS - 2;
-        const bool owned = valid && s >= 2 && s <= SLOTS - 3;
+        const bool owned = inside && s >= 2 && s <= SLOTS - 3;
 
         const bool rev = REV != (bool)(a.zigzag & seg & 1);  // wave-uniform
         auto act = [&](int k) { return rev ? x0 + x1 - 1 - k : k; };  // lattice plane of marching index k
+        // (with periodic planes the ones recomputed beyond either end of the stack are those of the far end)
+        auto ring = [&](int k) { return a.wrap_x ? (k < 0 ? k + a.lx : (k >= a.lx ? k - a.lx : k)) : k; };
         auto load_plane = [&](const double2* buf, bool nt, int k, bool wanted, double2 out[4]) {
-            k = act(k);
+            k = ring(act(k));
             if (wanted && k >= 0 && k < a.lx) {
-                const size_t site = (size_t)k * a.plane + p;
+                const size_t site = (size_t)k * a.plane + pw;
 #pragma unroll
                 for (int al = 0; al < 4; ++al)
                     out[al] = nt ? load_stream(buf + vslot(al, site, r, nb, RL)) : buf[vslot(al, site, r, nb, RL)];
@@ -203,8 +227,8 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
         };
         auto load_ids = [&](int k) {
             uint2 w = make_uint2(0xFFFFFFFFu, 0xFFu);
-            k = act(k);
-            if (does1 && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + p];
+            k = ring(act(k));
+            if (does1 && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + pw];
             return w;
         };
         auto id_of = [](uint2 w, int slot) { return slot < 4 ? (w.x >> (8 * slot)) & 0xFFu : w.y & 0xFFu; };
@@ -265,7 +289,7 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
             double2 new1[4];
 #pragma unroll
             for (int al = 0; al < 4; ++al) new1[al] = zero;
-            const bool plane_ok = act(k) >= 0 && act(k) < a.lx;
+            const bool plane_ok = a.wrap_x || (act(k) >= 0 && act(k) < a.lx);
             if (does1 && plane_ok) {
                 double2 acc[4];
 #pragma unroll
@@ -398,18 +422,21 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
         const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
         const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
         const int p = col * OWNED3 - 3 + s;
-        const bool valid = p >= 0 && p < a.plane;
+        const bool inside = p >= 0 && p < a.plane;
+        const bool valid = inside || a.wrap_p;  // a ring has no edge: halo slots beyond it hold the far side
+        const int pw = inside ? p : ((p % a.plane) + a.plane) % a.plane;
         const bool ok1 = valid && s >= 1 && s <= SLOTS - 2;
         const bool ok2 = valid && s >= 2 && s <= SLOTS - 3;
-        const bool owned = valid && s >= 3 && s <= SLOTS - 4;
+        const bool owned = inside && s >= 3 && s <= SLOTS - 4;
 
         const bool rev = REV != (bool)(a.zigzag & seg & 1);  // wave-uniform
         auto act = [&](int k) { return rev ? x0 + x1 - 1 - k : k; };
-        auto in_lattice = [&](int k) { return act(k) >= 0 && act(k) < a.lx; };
+        auto ring = [&](int k) { return a.wrap_x ? (k < 0 ? k + a.lx : (k >= a.lx ? k - a.lx : k)) : k; };
+        auto in_lattice = [&](int k) { return a.wrap_x || (act(k) >= 0 && act(k) < a.lx); };
         auto load_plane = [&](const double2* buf, bool nt, int k, bool wanted, double2 out[4]) {
-            k = act(k);
+            k = ring(act(k));
             if (wanted && k >= 0 && k < a.lx) {
-                const size_t site = (size_t)k * a.plane + p;
+                const size_t site = (size_t)k * a.plane + pw;
 #pragma unroll
                 for (int al = 0; al < 4; ++al)
                     out[al] = nt ? load_stream(buf + vslot(al, site, r, nb, RL)) : buf[vslot(al, site, r, nb, RL)];
@@ -428,8 +455,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
         };
         auto load_ids = [&](int k) {
             uint2 w = make_uint2(0xFFFFFFFFu, 0xFFu);
-            k = act(k);
-            if (ok1 && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + p];
+            k = ring(act(k));
+            if (ok1 && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + pw];
             return w;
         };
         auto id_of = [](uint2 w, int slot) { return slot < 4 ? (w.x >> (8 * slot)) & 0xFFu : w.y & 0xFFu; };

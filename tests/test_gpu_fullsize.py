@@ -309,3 +309,34 @@ def test_complex_hamiltonian_at_full_size(api, hip_library):
     for out in (got, streamed):
         assert np.allclose(out[0], ref[0], rtol=0, atol=1e-12 * n) and np.allclose(out[1], ref[1], rtol=0, atol=1e-12 * n)
     assert np.allclose(got[0][0], n, rtol=1e-15)  # |v|^2 = 4N exactly for Z4 vectors
+
+
+def test_periodic_lattice_at_full_size_sweeps_match_one_step_kernels(api, hip_library):
+    """A 10^6-site torus (the reference's `lattice.edges()` terms set on both axes): the wrap-around
+    blocks close the planes and their stack into rings for the multi-step sweep kernels; 10 steps
+    (three sweeps and a lone step) against the one-step kernels on the same vectors, which take
+    the wrap blocks as ordinary BSR blocks, and the first steps against the CPU oracle."""
+    from bodge_amd import chebyshev
+    from bodge_amd.solver import DeviceSolver
+
+    lattice = api.CubicLattice((1000, 1000, 1))
+    system = api.Hamiltonian(lattice)
+    with system as (H, Δ):
+        H.set_sites(3.0 * api.σ0 - 0.05 * api.σ3)
+        Δ.set_sites(-0.1 * api.jσ2)
+        H.set_bonds(-1.0 * api.σ0)
+        H.set_edges(-1.0 * api.σ0)
+    indptr, indices, data = system.bsr_arrays()
+    assert indices.size == 5_000_000  # every row has its five blocks
+    scale = chebyshev.spectral_bound(indptr, data)
+    n = 4 * lattice.size
+    with DeviceSolver(indptr, indices, data) as solver:
+        solver.set_lattice_shape(lattice.shape)
+        (d, e), perf = _with_env(solver, {}, scale, 10, 8, seed=2)
+        assert perf["steps_per_launch"] == 3
+        (d1, e1), perf1 = _with_env(solver, {"BODGE_AMD_SWEEP": "0"}, scale, 10, 8, seed=2)
+        assert perf1["steps_per_launch"] == 1
+    assert np.abs(d - d1).max() <= 1e-12 * n and np.abs(e - e1).max() <= 1e-12 * n
+    bsr = system.matrix("bsr")
+    ref = cheb_ref.recurrence_dots(bsr, scale, 4, cheb_ref.random_block(bsr.shape[0], 2, range(2)))
+    assert np.allclose(d[:2, :2], ref[0], rtol=0, atol=1e-12 * n) and np.allclose(e[:2, :2], ref[1], rtol=0, atol=1e-12 * n)

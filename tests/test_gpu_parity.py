@@ -211,8 +211,8 @@ def test_strip_ordered_tiles_do_not_change_results(api, solver_cls, monkeypatch,
 
 
 def _sweep_system(api, shape, kind):
-    """2-D lattice models for the two-steps-per-sweep kernel: uniform, position dependent, complex,
-    d-wave bonds, and one with periodic wrap blocks (not a stencil: must fall back)."""
+    """Lattice models for the stencil kernels: uniform, position dependent, complex, d-wave bonds,
+    and periodic ones (wrap-around blocks in one or both directions)."""
     lattice = api.CubicLattice(shape)
     system = api.Hamiltonian(lattice)
     with system as (H, Δ):
@@ -240,11 +240,14 @@ def _sweep_system(api, shape, kind):
             H.set_sites(np.where(middle, 0.5 * api.σ0 + 1.5 * api.σ3, -0.5 * api.σ0))
             Δ.set_sites(np.where(middle, 0 * api.jσ2, -1.0 * api.jσ2))
             H.set_bonds(-1.0 * api.σ0)
-        elif kind == "periodic":
-            H.set_sites(3.0 * api.σ0)
+        elif kind in ("periodic", "periodic_x", "periodic_y"):
+            H.set_sites(3.0 * api.σ0 - 0.05 * api.σ3)
             Δ.set_sites(-0.1 * api.jσ2)
             H.set_bonds(-1.0 * api.σ0)
-            H.set_edges(-1.0 * api.σ0)
+            if kind == "periodic":
+                H.set_edges(-1.0 * api.σ0)
+            else:  # a ring in one direction only, with a different hopping across the seam
+                H.set_edges(-0.8 * api.σ0 + 0.1 * api.σ3, axis=0 if kind == "periodic_x" else (1 if shape[1] > 1 else 2))
         else:
             raise ValueError(kind)
     return system
@@ -257,7 +260,10 @@ def _sweep_system(api, shape, kind):
     ((48, 50, 1), "junction", cheb_ref.VEC_RADEMACHER),  # position-dependent blocks
     ((16, 1, 40), "swave", cheb_ref.VEC_RADEMACHER),     # (Lx, 1, Lz): the plane is a z-line
     ((9, 25, 1), "swave", cheb_ref.VEC_Z4),              # complex vectors on a real matrix, one short segment
-    ((30, 30, 1), "periodic", cheb_ref.VEC_RADEMACHER),  # wrap blocks: not a stencil, one-step kernels must run
+    ((30, 30, 1), "periodic", cheb_ref.VEC_RADEMACHER),  # torus: wrap blocks close planes and their stack into rings
+    ((9, 61, 1), "periodic_y", cheb_ref.VEC_RADEMACHER),  # rings inside the planes only, ragged last window
+    ((37, 30, 1), "periodic_x", cheb_ref.VEC_Z4),        # ring of planes only
+    ((16, 1, 40), "periodic", cheb_ref.VEC_RADEMACHER),  # (Lx, 1, Lz) torus
     ((12, 30, 4), "swave", cheb_ref.VEC_RADEMACHER),     # 3-D: one step per launch, x-neighbours in registers (K8)
     ((9, 7, 13), "dwave", cheb_ref.VEC_RADEMACHER),      # 3-D d-wave (zero z-bond pairing blocks), odd sizes
     ((10, 6, 8), "peierls", cheb_ref.VEC_Z4),            # 3-D complex
@@ -275,7 +281,7 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
     scale = cheb_ref.spectral_bound(bsr)
     n = bsr.shape[0]
     three_d = shape[1] > 1 and shape[2] > 1
-    is_stencil = kind != "periodic"
+    is_stencil = not (kind == "periodic" and three_d)  # (the 3-D kernel K8 has no rings: periodic 3-D falls back)
     per_group = 8 if (vec_kind == cheb_ref.VEC_RADEMACHER and kind != "peierls") else 4
     with solver_cls.from_hamiltonian(system) as dev:
         for steps, vectors, extra in [(8, per_group, {}), (7, 3, {}), (5, per_group + 3, {"BODGE_AMD_SWEEP_ZIGZAG": "0"}),
