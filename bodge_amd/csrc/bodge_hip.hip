@@ -910,12 +910,12 @@ struct FilePrefetch {
         return done;
     }
 };
-// deliberately immortal: they outlive every exit path
-FilePrefetch& g_rccl_prefetch = *new FilePrefetch({"/opt/rocm/lib/librccl.so"}, nullptr);
-// (each file on a thread of its own: measured on fresh boxes, two files read side by side arrive
-// in ~400 s, one after the other in ~600 s - the cold storage serves about 2.5 MB/s per stream)
+// deliberately immortal: they outlive every exit path.  One stream at a time - side by side the two
+// reads take as long as one after the other (the cold storage delivers ~2.5 MB/s in total) - and the
+// dense-solver objects first when both are wanted: a diagonalize() call is waiting for those.
 FilePrefetch& g_solver_prefetch =
     *new FilePrefetch({"/opt/rocm/lib/librocblas.so", "/opt/rocm/lib/librocsolver.so"}, nullptr);
+FilePrefetch& g_rccl_prefetch = *new FilePrefetch({"/opt/rocm/lib/librccl.so"}, &g_solver_prefetch);
 
 int load_solver(SolverApi** out) {
     static SolverApi api;

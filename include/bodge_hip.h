@@ -203,8 +203,8 @@ int bdg_hermiticity_defect(bdg_system* sys, double* defect_out);
 int bdg_dense_prefetch(void);
 /* Wait up to timeout_seconds (negative: until done) for that read; *ready = 1 once it has finished. */
 int bdg_dense_prefetch_wait(double timeout_seconds, int32_t* ready);
-/* The same for the RCCL shared object (573 MB), which the first bdg_comm_* call loads (a thread
- * of its own: the two reads proceed side by side). */
+/* The same for the RCCL shared object (573 MB), which the first bdg_comm_* call loads.  If the
+ * dense-solver read has been started too, this one follows it (one stream at a time). */
 int bdg_rccl_prefetch(void);
 int bdg_rccl_prefetch_wait(double timeout_seconds, int32_t* ready);
 

@@ -4,7 +4,7 @@ tests) and rocSOLVER (931 MB; the dense route above the own Jacobi kernels' limi
 Kept in a file of its own that sorts last: on a fresh machine those objects take minutes to come
 off cold storage (the library streams them through the page cache on background threads started
 at session start, tests/conftest.py), so everything else has already been reported by then.  The
-RCCL tests come first - the smaller file arrives first.
+dense-ladder tests come first (their objects are read first), the RCCL tests last.
 """
 
 import os
@@ -47,6 +47,63 @@ def _build(api, name):
     return spec["build"](api, **spec["kwargs"])
 
 
+# BASELINE config 5's feasible ladder (SURVEY §8d item 5): goldens are the reference's own
+# diagonalize() / free_energy() on these systems (tests/golden/make_golden.py)
+@pytest.mark.parametrize("name,driver", [("swave30_zeeman", "dsyevd"), ("peierls30", "zheevd"), ("chain300", "dsyevd")])
+def test_dense_ladder_above_the_jacobi_limit_matches_reference(api, golden, monkeypatch, dense_library, name, driver):
+    """n = 3600 real (dsyevd, the driver BASELINE config 5 names), n = 3600 complex (zheevd), and the
+    literal "300" chain (n = 1200, sent to rocSOLVER here as well): eigenvalues within 1e-10 of the
+    reference's, eigen-equation residual <= 1e-9, orthonormal finite vectors, reference shapes,
+    and F(T) from the same spectrum within 1e-10 relative."""
+    # pin the library route: 4N = 1200 would use the own Jacobi kernels, and so would 4N = 3600 while the
+    # library is still cold (tests/test_gpu_parity.py::test_own_jacobi_kernels_reach_4096_rows covers those)
+    monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")
+    system = _build(api, name)
+    dim = system.shape[0]
+    data = system._data
+    assert (np.abs(data.imag).max() > 0) == (driver == "zheevd")
+    vals, vecs = system.diagonalize(format="raw")
+    ref = golden.eigenvalues(name)
+    assert vals.shape == ref.shape == (dim // 2,) and vecs.shape == (dim, dim // 2)
+    assert np.all(np.diff(vals) >= 0) and np.abs(vals - ref).max() <= 1e-10
+    assert np.isfinite(vecs).all()
+    bsr = system.matrix("bsr")
+    assert np.abs(bsr @ vecs - vecs * vals).max() <= 1e-9
+    idx = np.arange(0, vals.size, max(1, vals.size // 64))  # a sample of columns against all of them
+    gram = vecs[:, idx].conj().T @ vecs
+    gram[np.arange(idx.size), idx] -= 1.0
+    assert np.abs(gram).max() <= 1e-9
+    _, shaped = system.diagonalize()
+    assert shaped.shape == (dim // 2, dim // 4, 4) and np.array_equal(shaped[3, 7, :], vecs[28:32, 3])
+    for temperature in (0.0, 0.1, 0.5):
+        value = system.free_energy(temperature, method="dense")
+        assert abs(value - golden.free_energy(name, temperature)) <= 1e-10 * abs(value)
+
+
+@pytest.mark.parametrize("name", ["complex235", "barrier"])
+def test_rocsolver_route_forced_on_small_systems(api, golden, monkeypatch, dense_library, name):
+    """The library route taken for 4N > 2048, forced here on small systems: dsyevd when imag(H) = 0
+    (barrier), zheevd otherwise (complex235).  Handing a real matrix to the Hermitian D&C driver
+    (never done by default) shows its NaN-eigenvector defect; the default driver choice then
+    notices on the device and repairs with the Jacobi driver."""
+    monkeypatch.setenv("BODGE_AMD_EIGH", "evd")
+    system = _build(api, name)
+    dense = np.asarray(system.matrix("dense"))
+    vals, vecs = system.diagonalize(format="raw")
+    assert np.allclose(vals, golden.eigenvalues(name), rtol=0, atol=1e-10)
+    assert np.isfinite(vecs).all() and np.allclose(dense @ vecs, vecs * vals, atol=1e-9)
+    if name == "barrier":
+        monkeypatch.setenv("BODGE_AMD_EIGH_REAL", "0")
+        vals1, vecs1 = system.diagonalize(format="raw")
+        assert np.allclose(vals1, golden.eigenvalues(name), rtol=0, atol=1e-10)
+        defect = bool(np.isnan(vecs1).any())  # seen on ROCm 7.2; a fixed library passes too
+        monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")
+        vals2, vecs2 = system.diagonalize(format="raw")
+        assert np.isfinite(vecs2).all() and np.allclose(dense @ vecs2, vecs2 * vals2, atol=1e-9)
+        assert defect or np.allclose(dense @ vecs1, vecs1 * vals1, atol=1e-9)
+
+
+# ---- one-rank RCCL communicator tests: they need librccl.so (573 MB), read after the solver objects
 def test_slab_with_rccl_self_exchange(api, solver_cls, rccl_library):
     """The RCCL send/recv halo path on one GPU: a one-rank plan whose periodic wrap blocks are
     routed through the halo region, exchanged with itself through ncclSend/ncclRecv."""
@@ -104,59 +161,3 @@ def test_rccl_single_rank_communicator(hip_library, rccl_library):
     assert np.array_equal(comm.allreduce_max(values), values)
     comm.barrier()
     comm.close()
-
-
-# BASELINE config 5's feasible ladder (SURVEY §8d item 5): goldens are the reference's own
-# diagonalize() / free_energy() on these systems (tests/golden/make_golden.py)
-@pytest.mark.parametrize("name,driver", [("swave30_zeeman", "dsyevd"), ("peierls30", "zheevd"), ("chain300", "dsyevd")])
-def test_dense_ladder_above_the_jacobi_limit_matches_reference(api, golden, monkeypatch, dense_library, name, driver):
-    """n = 3600 real (dsyevd, the driver BASELINE config 5 names), n = 3600 complex (zheevd), and the
-    literal "300" chain (n = 1200, sent to rocSOLVER here as well): eigenvalues within 1e-10 of the
-    reference's, eigen-equation residual <= 1e-9, orthonormal finite vectors, reference shapes,
-    and F(T) from the same spectrum within 1e-10 relative."""
-    # pin the library route: 4N = 1200 would use the own Jacobi kernels, and so would 4N = 3600 while the
-    # library is still cold (tests/test_gpu_parity.py::test_own_jacobi_kernels_reach_4096_rows covers those)
-    monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")
-    system = _build(api, name)
-    dim = system.shape[0]
-    data = system._data
-    assert (np.abs(data.imag).max() > 0) == (driver == "zheevd")
-    vals, vecs = system.diagonalize(format="raw")
-    ref = golden.eigenvalues(name)
-    assert vals.shape == ref.shape == (dim // 2,) and vecs.shape == (dim, dim // 2)
-    assert np.all(np.diff(vals) >= 0) and np.abs(vals - ref).max() <= 1e-10
-    assert np.isfinite(vecs).all()
-    bsr = system.matrix("bsr")
-    assert np.abs(bsr @ vecs - vecs * vals).max() <= 1e-9
-    idx = np.arange(0, vals.size, max(1, vals.size // 64))  # a sample of columns against all of them
-    gram = vecs[:, idx].conj().T @ vecs
-    gram[np.arange(idx.size), idx] -= 1.0
-    assert np.abs(gram).max() <= 1e-9
-    _, shaped = system.diagonalize()
-    assert shaped.shape == (dim // 2, dim // 4, 4) and np.array_equal(shaped[3, 7, :], vecs[28:32, 3])
-    for temperature in (0.0, 0.1, 0.5):
-        value = system.free_energy(temperature, method="dense")
-        assert abs(value - golden.free_energy(name, temperature)) <= 1e-10 * abs(value)
-
-
-@pytest.mark.parametrize("name", ["complex235", "barrier"])
-def test_rocsolver_route_forced_on_small_systems(api, golden, monkeypatch, dense_library, name):
-    """The library route taken for 4N > 2048, forced here on small systems: dsyevd when imag(H) = 0
-    (barrier), zheevd otherwise (complex235).  Handing a real matrix to the Hermitian D&C driver
-    (never done by default) shows its NaN-eigenvector defect; the default driver choice then
-    notices on the device and repairs with the Jacobi driver."""
-    monkeypatch.setenv("BODGE_AMD_EIGH", "evd")
-    system = _build(api, name)
-    dense = np.asarray(system.matrix("dense"))
-    vals, vecs = system.diagonalize(format="raw")
-    assert np.allclose(vals, golden.eigenvalues(name), rtol=0, atol=1e-10)
-    assert np.isfinite(vecs).all() and np.allclose(dense @ vecs, vecs * vals, atol=1e-9)
-    if name == "barrier":
-        monkeypatch.setenv("BODGE_AMD_EIGH_REAL", "0")
-        vals1, vecs1 = system.diagonalize(format="raw")
-        assert np.allclose(vals1, golden.eigenvalues(name), rtol=0, atol=1e-10)
-        defect = bool(np.isnan(vecs1).any())  # seen on ROCm 7.2; a fixed library passes too
-        monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")
-        vals2, vecs2 = system.diagonalize(format="raw")
-        assert np.isfinite(vecs2).all() and np.allclose(dense @ vecs2, vecs2 * vals2, atol=1e-9)
-        assert defect or np.allclose(dense @ vecs1, vecs1 * vals1, atol=1e-9)
