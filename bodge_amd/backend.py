@@ -92,6 +92,10 @@ SIGNATURES = {
     "bdg_set_lattice_shape": (C.c_int, [_handle, C.c_int32, C.c_int32, C.c_int32]),
     "bdg_set_lanes_per_row": (C.c_int, [_handle, C.c_int32]),
     "bdg_comm_unique_id": (C.c_int, [_u8p]),
+    "bdg_host_fill_terms": (C.c_int, [_f64p, C.c_int64, _i64p, C.c_int64, _f64p, C.c_int, C.c_int, _u8p]),
+    "bdg_host_scan_blocks": (C.c_int, [_f64p, _i32p, C.c_int64, _u8p, C.POINTER(C.c_int64), C.POINTER(C.c_double),
+                                      C.POINTER(C.c_double), C.POINTER(C.c_int32)]),
+    "bdg_host_compact_blocks": (C.c_int, [_f64p, _i32p, _i32p, C.c_int64, _u8p, _f64p, _i32p, _i32p]),
     "bdg_comm_init": (C.c_int, [C.c_int, _u8p, C.c_int32, C.c_int32, C.POINTER(_handle)]),
     "bdg_comm_info": (C.c_int, [_handle, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_char_p]),
     "bdg_comm_allreduce_sum": (C.c_int, [_handle, _f64p, C.c_int64]),
@@ -155,3 +159,7 @@ def as_i32p(array: np.ndarray):
 
 def as_i64p(array: np.ndarray):
     return array.ctypes.data_as(_i64p)
+
+
+def as_u8p(array: np.ndarray):
+    return array.ctypes.data_as(_u8p)

@@ -34,6 +34,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "host_assembly.hpp"
 #include "kernels.hpp"
 #include "sweep.hpp"
 
@@ -2702,6 +2703,50 @@ int bdg_hermiticity_defect(bdg_system* sys, double* defect_out) {
     double worst = 0.0;
     for (double v : host) worst = std::isnan(v) ? v : std::max(worst, v);
     *defect_out = worst;
+    return BDG_OK;
+}
+
+// ---- host-side assembly helpers (CPU threads only; host_assembly.hpp)
+int bdg_host_fill_terms(double* data, int64_t nnzb, const int64_t* ids, int64_t count, const double* values,
+                        int per_term, int kind, uint8_t* touched) {
+    if (count < 0 || nnzb < 0 || kind < 0 || kind > 2) return fail(BDG_EINVAL, "bad fill arguments (count=%lld kind=%d)", (long long)count, kind);
+    if (count == 0) return BDG_OK;
+    if (!data || !ids || !values) return fail(BDG_EINVAL, "null argument");
+    for (int64_t n = 0; n < count; ++n)
+        if (ids[n] < 0 || ids[n] >= nnzb) return fail(BDG_EINVAL, "term %lld names block %lld of %lld", (long long)n, (long long)ids[n], (long long)nnzb);
+    bdg_host::fill_terms(data, nnzb, ids, count, values, per_term != 0, kind, touched);
+    return BDG_OK;
+}
+
+static int check_indptr(const int32_t* indptr, int64_t nb) {
+    if (!indptr || nb < 0) return fail(BDG_EINVAL, "null argument");
+    if (indptr[0] != 0) return fail(BDG_EINVAL, "indptr does not start at 0");
+    for (int64_t i = 0; i < nb; ++i)
+        if (indptr[i + 1] < indptr[i]) return fail(BDG_EINVAL, "indptr is not monotone at row %lld", (long long)i);
+    return BDG_OK;
+}
+
+int bdg_host_scan_blocks(const double* data, const int32_t* indptr, int64_t nb, uint8_t* nonzero, int64_t* n_nonzero,
+                         double* ph_defect, double* row_sum_max, int32_t* all_real) {
+    if (int rc = check_indptr(indptr, nb)) return rc;
+    if (indptr[nb] > 0 && !data) return fail(BDG_EINVAL, "null argument");
+    const bdg_host::BlockScan scan = bdg_host::scan_blocks(data, indptr, nb, nonzero);
+    const double nan = std::nan("");
+    if (n_nonzero) *n_nonzero = scan.n_nonzero;
+    if (ph_defect) *ph_defect = scan.has_nan ? nan : scan.ph_defect;
+    if (row_sum_max) *row_sum_max = scan.has_nan ? nan : scan.row_sum_max;
+    if (all_real) *all_real = scan.all_real ? 1 : 0;
+    return BDG_OK;
+}
+
+int bdg_host_compact_blocks(const double* data, const int32_t* indices, const int32_t* indptr, int64_t nb,
+                            const uint8_t* keep, double* data_out, int32_t* indices_out, int32_t* indptr_out) {
+    if (int rc = check_indptr(indptr, nb)) return rc;
+    if (!indptr_out || (indptr[nb] > 0 && (!data || !indices || !keep))) return fail(BDG_EINVAL, "null argument");
+    int64_t kept = 0;
+    for (int64_t k = 0; k < indptr[nb]; ++k) kept += keep[k] ? 1 : 0;
+    if (kept > 0 && (!data_out || !indices_out)) return fail(BDG_EINVAL, "null output");
+    bdg_host::compact_blocks(data, indices, indptr, nb, keep, data_out, indices_out, indptr_out);
     return BDG_OK;
 }
 

@@ -45,6 +45,87 @@ def _gpu_present() -> bool:
         return False
 
 
+def _host_library():
+    """The shared library for its CPU-thread assembly helpers (bdg_host_*), or None: without it
+    (not built, or BODGE_AMD_HOST_NATIVE=0) the same passes are made with numpy.  This concerns the
+    host-side assembly only - the observables have no such alternative."""
+    import os
+
+    if os.environ.get("BODGE_AMD_HOST_NATIVE", "1") == "0":
+        return None
+    try:
+        from . import backend
+
+        return backend.load()
+    except (RuntimeError, OSError):
+        return None
+
+
+def _fill_terms(data: np.ndarray, ids: np.ndarray, values: np.ndarray, kind: int, touched: np.ndarray | None) -> None:
+    """Scatter 2x2 spin matrices into the 4x4 Nambu blocks `ids` (ref :102-118).
+
+    kind 0: hopping  blk[0:2,0:2] = v, blk[2:4,2:4] = -v*;  kind 1: pairing  blk[0:2,2:4] = v;
+    kind 2: pairing term seen from the transposed block  blk[2:4,0:2] = v^†.
+    `values` is (len(ids), 2, 2) or one (2, 2) matrix for every id."""
+    lib = _host_library()
+    if lib is None:
+        if touched is not None:
+            touched[ids] = 1
+        if kind == 0:
+            data[ids, 0:2, 0:2] = values
+            data[ids, 2:4, 2:4] = -values.conj()
+        elif kind == 1:
+            data[ids, 0:2, 2:4] = values
+        else:
+            data[ids, 2:4, 0:2] = np.swapaxes(values.conj(), -1, -2)
+        return
+    from . import backend
+
+    ids = np.ascontiguousarray(ids, dtype=np.int64)
+    values = np.ascontiguousarray(values, dtype=np.complex128)
+    backend.check(lib.bdg_host_fill_terms(
+        backend.as_f64p(data), len(data), backend.as_i64p(ids), len(ids), backend.as_f64p(values),
+        1 if values.ndim == 3 else 0, kind, None if touched is None else backend.as_u8p(touched)))
+
+
+def _cubic_skeleton(shape) -> tuple[np.ndarray, np.ndarray, np.ndarray]:
+    """(indptr, indices, block_rows) of the block skeleton of a cubic lattice: the diagonal, every
+    bond and every opposite-face "edge" pair, zero or not (ref :37-67) - written down directly
+    instead of sorting the pair list.  Relative to site i = z + Lz (y + Ly x) the partners sit at
+    fixed offsets, which in ascending order are
+        -(Lx-1)Sx, -Sx, -(Ly-1)Sy, -Sy, -(Lz-1), -1, 0, +1, +(Lz-1), +Sy, +(Ly-1)Sy, +Sx, +(Lx-1)Sx
+    (Sx = Ly Lz, Sy = Lz), each present where the site has that partner.  An axis of extent 2 has
+    its edge pair coincide with its bond, an axis of extent 1 has it coincide with the diagonal."""
+    Lx, Ly, Lz = (int(v) for v in shape)
+    n = Lx * Ly * Lz
+    extent, stride = (Lx, Ly, Lz), (Ly * Lz, Lz, 1)
+    i = np.arange(n, dtype=np.int64)
+    coord = (i // stride[0], (i // Lz) % Ly, i % Lz)
+    offsets, present = [], []
+    for a in (0, 1, 2):
+        if extent[a] >= 3:
+            offsets.append(-(extent[a] - 1) * stride[a])
+            present.append(coord[a] == extent[a] - 1)
+        if extent[a] >= 2:
+            offsets.append(-stride[a])
+            present.append(coord[a] >= 1)
+    offsets.append(0)
+    present.append(np.ones(n, dtype=bool))
+    for a in (2, 1, 0):
+        if extent[a] >= 2:
+            offsets.append(stride[a])
+            present.append(coord[a] <= extent[a] - 2)
+        if extent[a] >= 3:
+            offsets.append((extent[a] - 1) * stride[a])
+            present.append(coord[a] == 0)
+    mask = np.stack(present, axis=1)
+    columns = i[:, None] + np.array(offsets, dtype=np.int64)[None, :]
+    indptr = np.zeros(n + 1, dtype=np.int32)
+    np.cumsum(mask.sum(axis=1), out=indptr[1:])
+    block_rows = np.broadcast_to(i[:, None], mask.shape)[mask]
+    return indptr, columns[mask].astype(np.int32), block_rows
+
+
 # ---------------------------------------------------------------------------
 class TermTable(dict):
     """Mapping {(coord_i, coord_j): 2x2 matrix} handed out by `with system as ...`.
@@ -64,8 +145,8 @@ class TermTable(dict):
         if values.shape[-2:] != (2, 2):
             raise ValueError("Expected 2x2 spin matrices (or an array of them)")
         if values.ndim == 2:
-            values = np.broadcast_to(values, (len(rows), 2, 2))
-        elif values.shape[0] != len(rows):
+            values = values.copy()  # one matrix for every term of the batch
+        elif values.ndim != 3 or values.shape[0] != len(rows):
             raise ValueError(f"Expected {len(rows)} matrices, got {values.shape[0]}")
         self._bulk.append((np.asarray(rows, np.int64), np.asarray(cols, np.int64), values))
 
@@ -96,22 +177,24 @@ class Hamiltonian:
         n = lattice.size
         self.shape: Indices = (4 * n, 4 * n)
 
-        rows, cols = self._skeleton_pairs()
-        keys = np.unique(np.concatenate([rows * n + cols, cols * n + rows]))
-        block_rows = keys // n
-        indices = (keys - block_rows * n).astype(np.int32)
-        indptr = np.zeros(n + 1, dtype=np.int32)
-        np.cumsum(np.bincount(block_rows, minlength=n), out=indptr[1:])
+        if type(lattice) is CubicLattice:
+            indptr, indices, block_rows = _cubic_skeleton(lattice.shape)
+            keys = block_rows * n + indices
+        else:
+            rows, cols = self._skeleton_pairs()
+            keys = np.unique(np.concatenate([rows * n + cols, cols * n + rows]))
+            block_rows = keys // n
+            indices = (keys - block_rows * n).astype(np.int32)
+            indptr = np.zeros(n + 1, dtype=np.int32)
+            np.cumsum(np.bincount(block_rows, minlength=n), out=indptr[1:])
 
         data = np.zeros((len(keys), 4, 4), dtype=np.complex128)
         self._matrix = sp.bsr_matrix((data, indices, indptr), shape=self.shape, blocksize=(4, 4))
         self._data: Matrix = self._matrix.data
 
-        # Sorted (row, col) keys: block lookup is a binary search.  `_mirror[k]`
-        # is the position of the transposed block, used for the Hermitian fill
-        # and for the Hermiticity check.
+        # Sorted (row, col) keys: block lookup is a binary search.
         self._keys = keys
-        self._mirror = np.searchsorted(keys, indices.astype(np.int64) * n + block_rows)
+        self._mirror_ids: np.ndarray | None = None
 
         # Device-side state (created lazily; invalidated whenever terms change).
         self._revision = 0
@@ -120,6 +203,15 @@ class Hamiltonian:
         self._memo: dict = {}
         self._recheck_all = False  # set when a Hermiticity check failed: the next one covers everything
         self._memo_revision = -1
+
+    @property
+    def _mirror(self) -> np.ndarray:
+        """`_mirror[k]` = position of the transposed block of block k (host Hermiticity check)."""
+        if self._mirror_ids is None:
+            n = self.lattice.size
+            block_rows = self._keys // n
+            self._mirror_ids = np.searchsorted(self._keys, (self._keys - block_rows * n) * n + block_rows)
+        return self._mirror_ids
 
     def _skeleton_pairs(self) -> tuple[np.ndarray, np.ndarray]:
         lattice = self.lattice
@@ -158,7 +250,7 @@ class Hamiltonian:
 
     def __exit__(self, exc_type, exc_val, exc_tb):
         data = self._data
-        touched = np.zeros(len(data), dtype=bool)
+        touched = np.zeros(len(data), dtype=np.uint8)
         for table, is_pairing in ((self._hopp, False), (self._pair, True)):
             batches = list(table._bulk)
             keyed = self._dict_to_arrays(table)
@@ -166,21 +258,21 @@ class Hamiltonian:
                 batches.append(keyed)
             for rows, cols, vals in batches:
                 k = self._block_ids(rows, cols)
-                touched[k] = True
                 if is_pairing:
-                    data[k, 0:2, 2:4] = vals
-                    data[self._mirror[k], 2:4, 0:2] = vals.conj().transpose(0, 2, 1)
+                    twin = k if rows is cols else self._block_ids(cols, rows)
+                    _fill_terms(data, k, vals, 1, touched)
+                    _fill_terms(data, twin, vals, 2, None)
                 else:
-                    data[k, 0:2, 0:2] = vals
-                    data[k, 2:4, 2:4] = -vals.conj()
+                    _fill_terms(data, k, vals, 0, touched)
         del self._hopp
         del self._pair
         self._revision += 1
 
         # Blocks this `with` did not write were checked when they were written (and start out zero),
         # unless that earlier check failed and left the matrix in a non-Hermitian state.
+        touched = touched.view(bool)
         everything = self._recheck_all or bool(touched.all())
-        if int(touched.sum()) >= DEVICE_HERMITICITY_MIN_BLOCKS and _gpu_present():
+        if int(np.count_nonzero(touched)) >= DEVICE_HERMITICITY_MIN_BLOCKS and _gpu_present():
             # large fills: the matrix goes to the GPU now (the observables need it there anyway)
             # and is compared with its conjugate transpose on the device, block against block
             defect = self._solver().hermiticity_defect()
@@ -217,13 +309,41 @@ class Hamiltonian:
         off-diagonal part holds when the pairing obeys fermionic antisymmetry Δ_ij = -Δ_ji^T
         (singlet on-site terms, odd-parity triplet bond terms).  The Chebyshev free energy
         relies on it; the dense path and the LDOS do not."""
-        def defect() -> float:
-            data = self._data
-            a = np.abs(data[:, 2:4, 2:4] + data[:, 0:2, 0:2].conj()).max(initial=0.0)
-            b = np.abs(data[:, 2:4, 0:2] + data[:, 0:2, 2:4].conj()).max(initial=0.0)
-            return float(max(a, b))
+        return bool(self._block_scan()["ph_defect"] <= tol)
 
-        return bool(self._memoized("ph_defect", defect) <= tol)
+    def gershgorin_bound(self) -> float:
+        """max over scalar rows of Σ|H_rc| ≥ ‖H‖ (1.0 for an all-zero matrix): the number
+        `chebyshev.spectral_bound(indptr, data, pad=1.0)` returns for the stored blocks."""
+        bound = self._block_scan()["row_sum_max"]
+        return bound if bound > 0 or np.isnan(bound) else 1.0
+
+    def _block_scan(self) -> dict:
+        """One pass over the stored blocks, cached until the next `with`: which blocks are all-zero,
+        the particle-hole defect, the Gershgorin bound (bdg_host_scan_blocks; numpy without the library)."""
+        def scan() -> dict:
+            data, indptr = self._data, self._matrix.indptr
+            lib = _host_library()
+            if lib is None:
+                from .chebyshev import spectral_bound
+
+                nonzero = np.any(data.reshape(len(data), 16) != 0, axis=1)
+                a = np.abs(data[:, 2:4, 2:4] + data[:, 0:2, 0:2].conj()).max(initial=0.0)
+                b = np.abs(data[:, 2:4, 0:2] + data[:, 0:2, 2:4].conj()).max(initial=0.0)
+                bound = spectral_bound(indptr, data, pad=1.0) if np.any(nonzero) else 0.0
+                return {"nonzero": nonzero, "n_nonzero": int(np.count_nonzero(nonzero)), "ph_defect": float(max(a, b)),
+                        "row_sum_max": float(bound)}
+            from . import backend
+            import ctypes as C
+
+            nonzero = np.empty(len(data), dtype=np.uint8)
+            count, defect, bound, real = C.c_int64(0), C.c_double(0.0), C.c_double(0.0), C.c_int32(0)
+            backend.check(lib.bdg_host_scan_blocks(
+                backend.as_f64p(data), backend.as_i32p(indptr), len(indptr) - 1, backend.as_u8p(nonzero),
+                C.byref(count), C.byref(defect), C.byref(bound), C.byref(real)))
+            return {"nonzero": nonzero.view(bool), "n_nonzero": int(count.value), "ph_defect": float(defect.value),
+                    "row_sum_max": float(bound.value)}
+
+        return self._memoized("block_scan", scan)
 
     # ------------------------------------------------------------------ export
     def matrix(self, format: str = "dense"):
@@ -258,12 +378,23 @@ class Hamiltonian:
         indptr, indices, data = self._matrix.indptr, self._matrix.indices, self._data
         if not drop_zero_blocks:
             return indptr.copy(), indices.copy(), data.copy()
-        keep = np.any(data.reshape(len(data), 16) != 0, axis=1)
-        n = self.lattice.size
-        block_rows = (self._keys // n)[keep]
-        new_ptr = np.zeros(n + 1, dtype=np.int32)
-        np.cumsum(np.bincount(block_rows, minlength=n), out=new_ptr[1:])
-        return new_ptr, indices[keep].copy(), np.ascontiguousarray(data[keep])
+        scan = self._block_scan()
+        keep, n = scan["nonzero"], self.lattice.size
+        lib = _host_library()
+        if lib is None:
+            block_rows = (self._keys // n)[keep]
+            new_ptr = np.zeros(n + 1, dtype=np.int32)
+            np.cumsum(np.bincount(block_rows, minlength=n), out=new_ptr[1:])
+            return new_ptr, indices[keep].copy(), np.ascontiguousarray(data[keep])
+        from . import backend
+
+        new_ptr = np.empty(n + 1, dtype=np.int32)
+        new_indices = np.empty(scan["n_nonzero"], dtype=np.int32)
+        new_data = np.empty((scan["n_nonzero"], 4, 4), dtype=np.complex128)
+        backend.check(lib.bdg_host_compact_blocks(
+            backend.as_f64p(data), backend.as_i32p(indices), backend.as_i32p(indptr), n, backend.as_u8p(keep.view(np.uint8)),
+            backend.as_f64p(new_data), backend.as_i32p(new_indices), backend.as_i32p(new_ptr)))
+        return new_ptr, new_indices, new_data
 
     def _memoized(self, name: str, compute):
         """Value of `compute()` cached until the next `with` block rewrites the matrix."""

@@ -125,6 +125,26 @@ class CubicLattice(Lattice):
             chunks.append(both)
         return np.concatenate(chunks, axis=0)
 
+    def _directed_indices(self, axis, wrap: bool) -> np.ndarray:
+        """(2P, 2) site indices of `_directed(axis, wrap)`, by index arithmetic (no coordinate tables)."""
+        _check_axis(axis)
+        Lx, Ly, Lz = self.shape
+        stride = (Ly * Lz, Lz, 1)
+        chunks = []
+        for ax in (2, 1, 0) if axis is None else (axis,):
+            extents = list(self.shape)
+            extents[ax] = 1 if wrap else self.shape[ax] - 1
+            if min(extents) <= 0:
+                continue
+            x, y, z = (np.arange(e, dtype=np.int64) for e in extents)
+            first = ((x[:, None, None] * Ly + y[None, :, None]) * Lz + z[None, None, :]).reshape(-1)
+            second = first + ((self.shape[ax] - 1) if wrap else 1) * stride[ax]
+            both = np.empty((2 * len(first), 2), dtype=np.int64)
+            both[0::2, 0], both[0::2, 1] = first, second
+            both[1::2, 0], both[1::2, 1] = second, first
+            chunks.append(both)
+        return np.concatenate(chunks, axis=0) if chunks else np.zeros((0, 2), dtype=np.int64)
+
     def _flatten(self, coords: np.ndarray) -> np.ndarray:
         _, Ly, Lz = self.shape
         return coords[..., 2] + Lz * (coords[..., 1] + Ly * coords[..., 0])
@@ -134,13 +154,11 @@ class CubicLattice(Lattice):
 
         Returns (B, 2) site indices, or (B, 2, 3) coordinates when coords=True.
         """
-        table = self._directed(axis, wrap=False)
-        return table if coords else self._flatten(table)
+        return self._directed(axis, wrap=False) if coords else self._directed_indices(axis, wrap=False)
 
     def edge_array(self, axis=None, coords: bool = False) -> np.ndarray:
         """Directed opposite-face pairs in generator order (see `bond_array`)."""
-        table = self._directed(axis, wrap=True)
-        return table if coords else self._flatten(table)
+        return self._directed(axis, wrap=True) if coords else self._directed_indices(axis, wrap=True)
 
     # -------------------------------------------------------------- generators
     def sites(self) -> Iterator[Coord]:

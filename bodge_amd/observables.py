@@ -40,8 +40,7 @@ def _warn(message: str) -> None:
 def _scale_of(system, pad: float = 1.01) -> float:
     # zero blocks add nothing to the row sums: the skeleton arrays give the same bound as the
     # trimmed ones, without the copy; cached until the next `with` block
-    bound = system._memoized(
-        "gershgorin", lambda: cheb.spectral_bound(system._matrix.indptr, system._data, pad=1.0))
+    bound = system.gershgorin_bound()  # (= cheb.spectral_bound(indptr, data, pad=1.0), same summation order)
     return pad * bound if bound > 0 else 1.0
 
 

@@ -193,6 +193,31 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out);
 int bdg_hermiticity_defect(bdg_system* sys, double* defect_out);
 
 /*
+ * Host-side assembly helpers: CPU threads only, no device call, usable without a GPU.  They make
+ * the passes over the BSR blocks that precede bdg_create with every core instead of one.
+ *
+ * bdg_host_fill_terms: scatter `count` 2x2 complex spin matrices (`values`: 8 doubles each if
+ *   per_term, else one matrix used for every term) into blocks `ids[n]` of `data` (nnzb x 4 x 4
+ *   complex128), in term order.  kind 0: hopping H_ij -> blk[0:2,0:2] = v, blk[2:4,2:4] = -conj(v)
+ *   (hamiltonian.py:106-108); kind 1: pairing Δ_ij -> blk[0:2,2:4] = v (:112-113); kind 2: the
+ *   transposed block of a pairing term, blk[2:4,0:2] = v^† (:115-116).  `touched` (nnzb bytes or
+ *   NULL) gets 1 at every block written.
+ * bdg_host_scan_blocks: one read of every block.  nonzero[k] = block k has a non-zero entry (the
+ *   blocks `matrix("bsr")` keeps, :142-143); ph_defect = max |blk[2:4,2:4] + conj(blk[0:2,0:2])|,
+ *   |blk[2:4,0:2] + conj(blk[0:2,2:4])| (0 = spectrum symmetric about zero); row_sum_max = max
+ *   over scalar rows of Σ|H_rc| (Gershgorin bound); all_real = imag(data) == 0.  Any output may
+ *   be NULL.  A NaN entry makes both floating-point results NaN.
+ * bdg_host_compact_blocks: the BSR triple without the blocks whose keep[k] is 0; outputs are
+ *   caller-allocated (indptr_out nb+1, the others n_nonzero long).
+ */
+int bdg_host_fill_terms(double* data, int64_t nnzb, const int64_t* ids, int64_t count, const double* values,
+                        int per_term, int kind, uint8_t* touched);
+int bdg_host_scan_blocks(const double* data, const int32_t* indptr, int64_t nb, uint8_t* nonzero, int64_t* n_nonzero,
+                         double* ph_defect, double* row_sum_max, int32_t* all_real);
+int bdg_host_compact_blocks(const double* data, const int32_t* indices, const int32_t* indptr, int64_t nb,
+                            const uint8_t* keep, double* data_out, int32_t* indices_out, int32_t* indptr_out);
+
+/*
  * Optional: start reading the rocSOLVER / rocBLAS shared objects into the page cache on a
  * background thread (file I/O only; returns at once, idempotent).  The first dense eigensolve
  * above 4*nb = 2048 loads a 931 MB library, which takes minutes from cold storage; a caller who

@@ -301,3 +301,125 @@ def test_partial_updates_are_checked_and_a_failed_check_is_not_forgotten(api):
         H[(3, 1, 0), (3, 1, 0)] = 0.25 * api.σ1      # partial update on a healthy matrix
     dense = np.asarray(system.matrix("dense"))
     assert np.array_equal(dense, dense.conj().T)
+
+
+# ---------------------------------------------------------------------------
+# The threaded host helpers (bdg_host_*, csrc/host_assembly.hpp) and the written-down cubic skeleton
+# against the numpy forms they replace: same arrays, bit for bit, signs of zeros included.
+
+def _bits(array):
+    return np.ascontiguousarray(array).view(np.uint64)
+
+
+def _random_bulk_terms(api, shape, seed, native, monkeypatch):
+    monkeypatch.setenv("BODGE_AMD_HOST_NATIVE", "1" if native else "0")
+    rng = np.random.default_rng(seed)
+    lattice = api.CubicLattice(shape)
+    system = api.Hamiltonian(lattice)
+    n_bonds, n_edges = len(lattice.bond_array()), len(lattice.edge_array())
+    with system as (H, Δ):
+        H.set_sites(rng.normal(size=(lattice.size, 1, 1)) * σ0 + rng.normal(size=(lattice.size, 1, 1)) * σ3)
+        Δ.set_sites(-0.1 * jσ2)  # one matrix for every site
+        if n_bonds:
+            hop = rng.normal(size=(n_bonds // 2, 1, 1)) * σ0 + 1j * rng.normal(size=(n_bonds // 2, 1, 1)) * σ2
+            both = np.empty((n_bonds, 2, 2), complex)
+            both[0::2], both[1::2] = hop, hop.conj().transpose(0, 2, 1)
+            H.set_bonds(both)
+            Δ.set_bonds(0.05 * jσ2)  # singlet pairing on the bonds: Δ_ji = Δ_ij
+        if n_edges:  # on an axis of extent 1 these are self-pairs (two terms per diagonal block: the later wins)
+            hop = rng.normal(size=(n_edges // 2, 1, 1)) * σ0
+            both = np.empty((n_edges, 2, 2), complex)
+            both[0::2], both[1::2] = hop, hop
+            H.set_edges(both)
+        sites = list(lattice.sites())
+        H[sites[0], sites[0]] = 2.5 * σ0 - 0.0 * σ3  # keyed entries go last and carry a negative zero
+        Δ[sites[-1], sites[-1]] = -0.3 * jσ2
+    return system
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 1), (1, 1, 3), (2, 1, 1), (2, 2, 2), (1, 2, 3), (3, 3, 1), (4, 1, 2), (2, 3, 4),
+                                   (3, 1, 3), (5, 4, 3), (17, 9, 1), (6, 5, 4)])
+def test_host_helpers_and_cubic_skeleton_match_the_numpy_forms(api, monkeypatch, shape):
+    from bodge_amd import chebyshev
+
+    native = _random_bulk_terms(api, shape, 3, True, monkeypatch)
+    plain = _random_bulk_terms(api, shape, 3, False, monkeypatch)
+    # skeleton: the written-down one against the sorted pair list of a generic lattice
+    rows, cols = native._skeleton_pairs()
+    n = native.lattice.size
+    keys = np.unique(np.concatenate([rows * n + cols, cols * n + rows]))
+    assert np.array_equal(native._keys, keys)
+    assert np.array_equal(native._matrix.indices, (keys % n).astype(np.int32))
+    assert np.array_equal(native._matrix.indptr[1:], np.cumsum(np.bincount(keys // n, minlength=n)))
+    assert np.array_equal(native._mirror, np.searchsorted(keys, (keys % n) * n + keys // n))
+    # fills
+    assert np.array_equal(_bits(native._data), _bits(plain._data))
+    # scan + export
+    monkeypatch.setenv("BODGE_AMD_HOST_NATIVE", "1")
+    scan_n, triple_n, bound_n = native._block_scan(), native.bsr_arrays(), native.gershgorin_bound()
+    monkeypatch.setenv("BODGE_AMD_HOST_NATIVE", "0")
+    scan_p, triple_p, bound_p = plain._block_scan(), plain.bsr_arrays(), plain.gershgorin_bound()
+    assert np.array_equal(scan_n["nonzero"], scan_p["nonzero"]) and scan_n["n_nonzero"] == scan_p["n_nonzero"]
+    assert scan_n["ph_defect"] == scan_p["ph_defect"]
+    assert bound_n == bound_p == chebyshev.spectral_bound(native._matrix.indptr, native._data, pad=1.0)
+    for a, b in zip(triple_n, triple_p):
+        assert a.dtype == b.dtype and a.shape == b.shape and np.array_equal(_bits(a) if a.dtype == complex else a, _bits(b) if b.dtype == complex else b)
+    trimmed = native.matrix("bsr")
+    assert np.array_equal(triple_n[0], trimmed.indptr) and np.array_equal(triple_n[1], trimmed.indices)
+    assert np.array_equal(triple_n[2], trimmed.data)
+
+
+def test_host_fill_applies_terms_in_order_and_checks_its_arguments(api):
+    import ctypes as C
+
+    from bodge_amd import backend
+
+    lib = backend.load()
+    data = np.zeros((5, 4, 4), complex)
+    touched = np.zeros(5, np.uint8)
+    ids = np.array([3, 1, 3, 3], np.int64)  # block 3 named three times: the last term stays
+    values = (np.arange(4)[:, None, None] + 1) * (σ0 + 1j * σ1)
+    backend.check(lib.bdg_host_fill_terms(backend.as_f64p(data), 5, backend.as_i64p(ids), 4,
+                                          backend.as_f64p(np.ascontiguousarray(values)), 1, 0, backend.as_u8p(touched)))
+    assert touched.tolist() == [0, 1, 0, 1, 0]
+    assert np.array_equal(data[3, 0:2, 0:2], values[3]) and np.array_equal(data[3, 2:4, 2:4], -values[3].conj())
+    assert np.array_equal(data[1, 0:2, 0:2], values[1]) and not data[[0, 2, 4]].any()
+    pair = np.ascontiguousarray(np.array([[1 + 2j, 3 - 1j], [0.5j, -2.0]]))
+    backend.check(lib.bdg_host_fill_terms(backend.as_f64p(data), 5, backend.as_i64p(ids), 4, backend.as_f64p(pair), 0, 1, None))
+    backend.check(lib.bdg_host_fill_terms(backend.as_f64p(data), 5, backend.as_i64p(ids[:1]), 1, backend.as_f64p(pair), 0, 2, None))
+    assert np.array_equal(data[1, 0:2, 2:4], pair) and np.array_equal(data[3, 2:4, 0:2], pair.conj().T)
+    with raises(ValueError):
+        backend.check(lib.bdg_host_fill_terms(backend.as_f64p(data), 5, backend.as_i64p(np.array([5], np.int64)), 1,
+                                              backend.as_f64p(pair), 0, 0, None))
+    with raises(ValueError):
+        backend.check(lib.bdg_host_fill_terms(backend.as_f64p(data), 5, backend.as_i64p(ids), 4, backend.as_f64p(pair), 0, 7, None))
+    with raises(ValueError):
+        backend.check(lib.bdg_host_scan_blocks(backend.as_f64p(data), backend.as_i32p(np.array([0, 3, 2], np.int32)), 2,
+                                               None, None, None, None, None))
+    # a NaN anywhere makes the bound and the defect NaN (numpy's max does the same)
+    data[2, 1, 1] = np.nan
+    defect, bound = C.c_double(0.0), C.c_double(0.0)
+    backend.check(lib.bdg_host_scan_blocks(backend.as_f64p(data), backend.as_i32p(np.array([0, 2, 5], np.int32)), 2,
+                                           None, None, C.byref(defect), C.byref(bound), None))
+    assert np.isnan(defect.value) and np.isnan(bound.value)
+
+
+def test_long_block_rows_sum_like_numpy(api):
+    """Rows of 8 and more blocks take the unrolled branches of numpy's pairwise sum: for real and purely
+    imaginary entries (every BASELINE configuration) the bound is numpy's double exactly."""
+    import ctypes as C
+
+    from bodge_amd import backend, chebyshev
+
+    rng = np.random.default_rng(0)
+    lengths = np.array([1, 2, 7, 8, 9, 10, 16, 17, 24, 129, 130, 300, 3])
+    indptr = np.concatenate([[0], np.cumsum(lengths)]).astype(np.int32)
+    for real in (True, False):
+        data = rng.normal(size=(indptr[-1], 4, 4)) + (0 if real else 1j) * rng.normal(size=(indptr[-1], 4, 4))
+        data = np.ascontiguousarray(data, dtype=complex)
+        bound = C.c_double(0.0)
+        backend.check(backend.load().bdg_host_scan_blocks(backend.as_f64p(data), backend.as_i32p(indptr), len(lengths),
+                                                         None, None, None, C.byref(bound), None))
+        expected = chebyshev.spectral_bound(indptr, data, pad=1.0)
+        # (general complex entries: numpy's vectorised |z| and libm's hypot differ in the last bit)
+        assert bound.value == expected if real else abs(bound.value - expected) <= 4e-16 * expected
