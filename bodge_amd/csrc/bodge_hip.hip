@@ -581,6 +581,25 @@ SweepKernel sweep3_kernel_for(int lanes, bool reverse) {
     return nullptr;
 }
 
+// cheb_sweep3 that makes the random start block itself (first sweep of a run; marches forward)
+template <typename Mode>
+SweepKernel sweep3_gen_kernel_for(int lanes) {
+    switch (lanes) {
+        case 2: return bdg::cheb_sweep3<Mode, 2, false, true>;
+        case 4: return bdg::cheb_sweep3<Mode, 4, false, true>;
+    }
+    return nullptr;
+}
+
+SweepKernel sweep3_gen_kernel(const ModeInfo& mode, int lanes) {
+    switch (mode.id) {
+        case 1: return sweep3_gen_kernel_for<RealMode>(lanes);
+        case 2: return sweep3_gen_kernel_for<ComplexPHMode>(lanes);
+        case 3: return sweep3_gen_kernel_for<RealPHMode>(lanes);
+    }
+    return sweep3_gen_kernel_for<ComplexMode>(lanes);
+}
+
 SweepKernel sweep3_kernel(const ModeInfo& mode, int lanes, bool reverse) {
     switch (mode.id) {
         case 1: return sweep3_kernel_for<RealMode>(lanes, reverse);
@@ -594,6 +613,7 @@ struct SweepPlan {
     int lanes = bdg::kSweepLanes;
     int depth = 2;  // recurrence steps per sweep: 2 (cheb_sweep) or 3 (cheb_sweep3)
     SweepKernel kernel = nullptr, kernel_reverse = nullptr;
+    SweepKernel kernel_gen = nullptr;  // depth 3: first sweep of a random-start run, t_0 made in registers
     int grid = 0;
     size_t lds_bytes = 0;
     bdg::SweepArgs args{};
@@ -678,14 +698,15 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     plan->depth = depth;
     plan->kernel = depth == 3 ? sweep3_kernel(mode, lanes, false) : sweep_kernel(mode, lanes, false);
     plan->kernel_reverse = depth == 3 ? sweep3_kernel(mode, lanes, true) : sweep_kernel(mode, lanes, true);
+    plan->kernel_gen = depth == 3 ? sweep3_gen_kernel(mode, lanes) : nullptr;
     if (!plan->kernel) return fail(BDG_EINVAL, "the sweep kernel has 1, 2 or 4 lanes per site, not %d", lanes);
     const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
     if (table > kDictLdsLimit) return fail(BDG_EINVAL, "block table too large for the sweep kernel");
     const size_t rows = (size_t)bdg::kSweepWaves * depth * bdg::kWave * 4 * sizeof(double2);
     plan->lds_bytes = table + rows;
     if (plan->lds_bytes > 64 * 1024)
-        for (SweepKernel k : {plan->kernel, plan->kernel_reverse})
-            HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+        for (SweepKernel k : {plan->kernel, plan->kernel_reverse, plan->kernel_gen})
+            if (k) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)plan->lds_bytes));
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(plan->kernel),
@@ -1045,6 +1066,11 @@ struct Batch {
     int n_chunks = 0;
     // two-steps-per-sweep form
     bool sweep = false, roll = false;
+    bool gen_start = false;  // the first sweep makes the random start block itself (no fill kernel)
+    // A call cut into several batches enqueues them back to back and waits once: batch `slot` of
+    // `n_slots` has its own timing events and its own piece of the pinned result buffer.
+    int slot = 0, n_slots = 1, ev_base = 0;
+    size_t host_stride = 0;
     SweepPlan splan;
     RollPlan rplan;
     double2 *spare1 = nullptr, *spare2 = nullptr;
@@ -1145,12 +1171,15 @@ struct Batch {
         if (int rc = sys->partial.reserve((size_t)kChunk * per_step)) return rc;
         const size_t dots_count = (size_t)std::max(n_steps, 1024) * width;
         if (int rc = sys->dots.reserve(dots_count)) return rc;
-        if (sys->host_dots_count < dots_count) {
+        host_stride = dots_count;
+        ev_base = slot * ((n_steps + chunk - 1) / chunk);
+        if (sys->host_dots_count < dots_count * n_slots) {
+            HIP_TRY(hipStreamSynchronize(sys->stream));  // (an earlier batch of this call may still be copying into it)
             if (sys->host_dots) (void)hipHostFree(sys->host_dots);
             sys->host_dots = nullptr;
             sys->host_dots_count = 0;
-            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sys->host_dots), dots_count * sizeof(double), 0));
-            sys->host_dots_count = dots_count;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sys->host_dots), dots_count * n_slots * sizeof(double), 0));
+            sys->host_dots_count = dots_count * n_slots;
         }
         if (sys->send_total > 0)
             if (int rc = sys->send_buf.reserve((size_t)sys->send_total * 4 * rl)) return rc;
@@ -1159,7 +1188,17 @@ struct Batch {
 
         hipStream_t st = sys->stream;
         const int fill_grid = (int)std::min<size_t>(4096, (vec_count + 255) / 256);
-        if (start.kind == StartKind::Random) {
+        // Three-step sweeps make a random t_0 in registers during the first sweep (cheb_sweep3 GEN):
+        // no fill kernel, and vec_a is only ever a spare buffer.  BODGE_AMD_SWEEP_GEN=0: fill and read.
+        gen_start = sweep && splan.depth == 3 && splan.kernel_gen && start.kind == StartKind::Random &&
+                    sys->row_offset == 0 && sys->ncols == sys->nb;
+        if (const char* env = getenv("BODGE_AMD_SWEEP_GEN")) gen_start = gen_start && atoi(env) != 0;
+        if (gen_start) {
+            splan.args.gen_seed = start.seed;
+            splan.args.gen_first_id = start.first_id;
+            splan.args.gen_kind = real ? BDG_VEC_RADEMACHER : start.vec_kind;
+            splan.args.gen_active = n_active;
+        } else if (start.kind == StartKind::Random) {
             if (real)
                 bdg::fill_random_real<<<fill_grid, 256, 0, st>>>(
                     reinterpret_cast<double*>(sys->vec_a.ptr), sys->nb, sys->ncols, rv, n_active,
@@ -1307,7 +1346,7 @@ struct Batch {
         hipStream_t st = sys->stream, cs = sys->comm_stream;
         const int in_chunk = n % chunk;
         const int chunk_id = n / chunk;
-        while ((int)sys->ev_pool.size() < 2 * (chunk_id + 1)) {
+        while ((int)sys->ev_pool.size() < 2 * (ev_base + chunk_id + 1)) {
             hipEvent_t ev = nullptr;
             HIP_TRY(hipEventCreate(&ev));
             sys->ev_pool.push_back(ev);
@@ -1320,7 +1359,7 @@ struct Batch {
         if (int rc = unpack(cs)) return rc;
         HIP_TRY(hipEventRecord(sys->ev_halo_ready, cs));
 
-        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id], st));
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id)], st));
         args.cur = cur;
         args.prev = prev;
         args.coef = (n == 0 ? 1.0 : 2.0) / scale;
@@ -1339,7 +1378,7 @@ struct Batch {
         std::swap(cur, prev);
         if (in_chunk == chunk - 1 || n == n_steps - 1) {
             const int s0 = n - in_chunk;
-            HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id + 1], st));
+            HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id) + 1], st));
             bdg::reduce_partials<<<in_chunk + 1, 256, 0, st>>>(sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width,
                                                               grid_interior + grid_boundary, (int)width);
             HIP_TRY(hipGetLastError());
@@ -1378,12 +1417,12 @@ struct Batch {
         const int in_chunk = n % chunk;
         const int chunk_id = n / chunk;
         // one event pair per chunk, read back in finish(): the host never waits inside the loop
-        while ((int)sys->ev_pool.size() < 2 * (chunk_id + 1)) {
+        while ((int)sys->ev_pool.size() < 2 * (ev_base + chunk_id + 1)) {
             hipEvent_t ev = nullptr;
             HIP_TRY(hipEventCreate(&ev));
             sys->ev_pool.push_back(ev);
         }
-        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id], st));
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id)], st));
         args.cur = cur;
         args.prev = prev;
         args.coef = (n == 0 ? 1.0 : 2.0) / scale;
@@ -1416,7 +1455,7 @@ struct Batch {
         std::swap(cur, prev);
         if (in_chunk == chunk - 1 || n == n_steps - 1) {
             const int s0 = n - in_chunk;
-            HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id + 1], st));
+            HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id) + 1], st));
             bdg::reduce_partials<<<in_chunk + 1, 256, 0, st>>>(
                 sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, launch_grid, (int)width);
             HIP_TRY(hipGetLastError());
@@ -1435,12 +1474,12 @@ struct Batch {
         const int chunk_id = n / chunk;
         const int now = std::min({splan.depth, n_steps - n, chunk - in_chunk});
         *made = now;
-        while ((int)sys->ev_pool.size() < 2 * (chunk_id + 1)) {
+        while ((int)sys->ev_pool.size() < 2 * (ev_base + chunk_id + 1)) {
             hipEvent_t ev = nullptr;
             HIP_TRY(hipEventCreate(&ev));
             sys->ev_pool.push_back(ev);
         }
-        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id], st));
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id)], st));
         bdg::SweepArgs& a = splan.args;
         a.cur = cur;
         a.prev = n == 0 ? nullptr : prev;
@@ -1453,8 +1492,10 @@ struct Batch {
         a.partial1 = sys->partial.ptr + (size_t)in_chunk * per_step;
         a.partial2 = a.partial1 + per_step;
         a.partial3 = a.partial2 + per_step;
-        (alternate && (n_launches & 1) ? splan.kernel_reverse : splan.kernel)<<<splan.grid, bdg::kSweepThreads,
-                                                                                  splan.lds_bytes, st>>>(a);
+        const SweepKernel kernel = n == 0 && gen_start ? splan.kernel_gen
+                                   : alternate && (n_launches & 1) ? splan.kernel_reverse : splan.kernel;
+        if (n == 0 && gen_start) a.cur = nullptr;  // (never read)
+        kernel<<<splan.grid, bdg::kSweepThreads, splan.lds_bytes, st>>>(a);
         ++n_launches;
         double2* old_cur = cur;
         double2* old_prev = prev;
@@ -1476,7 +1517,7 @@ struct Batch {
         const int last_in_chunk = last % chunk;
         if (last_in_chunk == chunk - 1 || last == n_steps - 1) {
             const int s0 = last - last_in_chunk;
-            HIP_TRY(hipEventRecord(sys->ev_pool[2 * chunk_id + 1], st));
+            HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id) + 1], st));
             bdg::reduce_partials<<<last_in_chunk + 1, 256, 0, st>>>(
                 sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, launch_grid, (int)width);
             HIP_TRY(hipGetLastError());
@@ -1488,14 +1529,25 @@ struct Batch {
     // d/e of this handle's rows into columns [col0, col0 + n_active) of (n_steps x ld) arrays;
     // accumulate = true adds to what is there (summing the slabs of a group).
     int finish(double* d_out, double* e_out, int ld, int col0, bool accumulate, bool first_batch) {
-        HIP_TRY(hipSetDevice(sys->device));
-        double* host = sys->host_dots;  // pinned: a pageable target costs ~8 ms on its first use
-        HIP_TRY(hipMemcpyAsync(host, sys->dots.ptr, (size_t)n_steps * width * sizeof(double),
-                               hipMemcpyDeviceToHost, sys->stream));
+        if (int rc = finish_enqueue()) return rc;
         HIP_TRY(hipStreamSynchronize(sys->stream));
+        return finish_collect(d_out, e_out, ld, col0, accumulate, first_batch);
+    }
+    // copy of the batch's dot products to the host, enqueued behind its last reduction
+    int finish_enqueue() {
+        HIP_TRY(hipSetDevice(sys->device));
+        // pinned: a pageable target costs ~8 ms on its first use
+        HIP_TRY(hipMemcpyAsync(sys->host_dots + (size_t)slot * host_stride, sys->dots.ptr,
+                               (size_t)n_steps * width * sizeof(double), hipMemcpyDeviceToHost, sys->stream));
+        return BDG_OK;
+    }
+    // after the stream has been waited for
+    int finish_collect(double* d_out, double* e_out, int ld, int col0, bool accumulate, bool first_batch) {
+        HIP_TRY(hipSetDevice(sys->device));
+        const double* host = sys->host_dots + (size_t)slot * host_stride;
         for (int c = 0; c < n_chunks; ++c) {
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, sys->ev_pool[2 * c], sys->ev_pool[2 * c + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, sys->ev_pool[2 * (ev_base + c)], sys->ev_pool[2 * (ev_base + c) + 1]));
             kernel_ms += ms;
         }
         for (int n = 0; n < n_steps; ++n)
@@ -1583,12 +1635,29 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const int width = batch_width(sys, start, n_vectors);
-    for (int col = 0; col < n_vectors; col += width) {
-        Batch batch;
+    // Batches are enqueued back to back and waited for once (whole matrices; a slab's batches are
+    // paced by its halo exchange anyway): the GPU does not idle while the host turns a batch around.
+    const int n_batches = (n_vectors + width - 1) / width;
+    const size_t staged = (size_t)n_batches * std::max(n_steps, 1024) * 2 * (size_t)width;  // doubles of pinned memory
+    const bool pipelined = n_batches > 1 && n_batches <= 64 && staged <= ((size_t)4 << 20) && sys->ncols == sys->nb &&
+                           !getenv("BODGE_AMD_NO_BATCH_PIPELINE");
+    std::vector<Batch> queued(pipelined ? (size_t)n_batches : 0);
+    size_t stride0 = 0;
+    for (int col = 0, index = 0; col < n_vectors; col += width, ++index) {
+        Batch single;
+        Batch& batch = pipelined ? queued[(size_t)index] : single;
+        if (pipelined) {
+            batch.slot = index;
+            batch.n_slots = n_batches;
+        }
         const auto t0 = now();
         if (int rc = batch.begin(sys, scale, n_steps, std::min(width, n_vectors - col),
                                  batch_start(start, col), -1))
             return rc;
+        if (pipelined) {  // one spacing of the result pieces for the whole call: the first batch is the widest
+            if (index == 0) stride0 = batch.host_stride;
+            batch.host_stride = stride0;
+        }
         const auto t1 = now();
         for (int n = 0; n < n_steps; ++n) {
             if (batch.sweep) {
@@ -1605,10 +1674,21 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
             if (int rc = batch.step(n)) return rc;
         }
         const auto t2 = now();
-        if (int rc = batch.finish(d_out, e_out, n_vectors, col, false, col == 0)) return rc;
+        if (pipelined) {
+            if (int rc = batch.finish_enqueue()) return rc;
+        } else if (int rc = batch.finish(d_out, e_out, n_vectors, col, false, col == 0)) {
+            return rc;
+        }
         if (trace)
             fprintf(stderr, "[bdg] begin %.3f ms, steps %.3f ms (kernels %.3f), finish %.3f ms\n", ms(t0, t1),
                     ms(t1, t2), batch.kernel_ms, ms(t2, now()));
+    }
+    if (pipelined) {
+        HIP_TRY(hipSetDevice(sys->device));
+        HIP_TRY(hipStreamSynchronize(sys->stream));
+        for (int index = 0; index < n_batches; ++index)
+            if (int rc = queued[(size_t)index].finish_collect(d_out, e_out, n_vectors, index * width, false, index == 0))
+                return rc;
     }
     return BDG_OK;
 }

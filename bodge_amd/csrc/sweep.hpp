@@ -74,6 +74,11 @@ struct SweepArgs {
     int zigzag;              // 1 = odd segments march against the even ones
     int wrap_p;              // 1 = the plane is a ring: position P-1 neighbours position 0 (periodic edge blocks)
     int wrap_x;              // 1 = the planes form a ring: plane lx-1 neighbours plane 0
+    // cheb_sweep3<..., GEN = true>: t_n is the random start vector block and is made in registers
+    // from the counter-based generator (the values fill_random would have written) instead of read
+    uint64_t gen_seed, gen_first_id;
+    int gen_kind;            // BDG_VEC_* (real modes: Rademacher)
+    int gen_active;          // vectors of the launch that exist (the others are zero)
 };
 
 // Stencil table + eligibility test, on the device from the uploaded arrays.  `words` is the
@@ -384,7 +389,11 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
 constexpr int kSweep3Owned = kSweepSlots - 6;  // 10 owned positions per wave window (4 lanes per site)
 constexpr int sweep3_owned(int rl) { return kWave / rl - 6; }
 
-template <typename Mode, int RL, bool REV>
+// GEN: the first sweep of a stochastic-trace run.  t_0 is a block of random vectors whose entries are
+// a pure function of (seed, vector, scalar row) (K3), so the sweep makes the planes of t_0 it needs
+// in registers - the halo slots and segment-end planes included - and the 128 MB of t_0 are neither
+// written by a fill kernel nor read back: a 40-moment call (7 sweeps per lane group) is 7 % shorter.
+template <typename Mode, int RL, bool REV, bool GEN = false>
 __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
     extern __shared__ double2 lds[];
     constexpr int SLOTS = kWave / RL;
@@ -416,6 +425,16 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
     const size_t nb = (size_t)a.nb;
     const int steps = a.steps;  // uniform
     const bool nt_prev = a.stream & 1, nt_store = a.stream & 2, nt_cur = a.stream & 4;
+    // GEN: the lane's vector(s) - real modes carry vectors 2r, 2r+1 in (x, y), complex modes vector r
+    uint64_t gen_key0 = 0, gen_key1 = 0;
+    bool gen_on0 = false, gen_on1 = false;
+    if constexpr (GEN) {
+        const int v0 = Mode::kVec == 2 ? 2 * r : r;
+        gen_on0 = v0 < a.gen_active;
+        gen_on1 = Mode::kVec == 2 && v0 + 1 < a.gen_active;
+        gen_key0 = vector_key(a.gen_seed, a.gen_first_id + v0);
+        gen_key1 = vector_key(a.gen_seed, a.gen_first_id + v0 + 1);
+    }
 
     for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
         const int seg = u / a.n_cols, col = u - seg * a.n_cols;
@@ -451,6 +470,29 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
             for (int al = 0; al < 4; ++al) {
                 if (nt_store) store_stream(buf + vslot(al, site, r, nb, RL), v[al]);
                 else buf[vslot(al, site, r, nb, RL)] = v[al];
+            }
+        };
+        // plane k of t_n: read, or (GEN) made from the generator
+        auto cur_plane = [&](int k, bool wanted, double2 out[4]) {
+            if constexpr (GEN) {
+                k = ring(act(k));
+                if (wanted && k >= 0 && k < a.lx) {
+                    const uint64_t element = 4 * ((uint64_t)k * a.plane + pw);
+#pragma unroll
+                    for (int al = 0; al < 4; ++al) {
+                        if constexpr (Mode::kVec == 2) {
+                            out[al].x = gen_on0 ? start_entry(gen_key0, element + al, 0).x : 0.0;
+                            out[al].y = gen_on1 ? start_entry(gen_key1, element + al, 0).x : 0.0;
+                        } else {
+                            out[al] = gen_on0 ? start_entry(gen_key0, element + al, a.gen_kind) : zero;
+                        }
+                    }
+                } else {
+#pragma unroll
+                    for (int al = 0; al < 4; ++al) out[al] = zero;
+                }
+            } else {
+                load_plane(a.cur, nt_cur, k, wanted, out);
             }
         };
         auto load_ids = [&](int k) {
@@ -506,10 +548,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
 
         // ---- prologue
         double2 cn_m[4], cn_0[4], cn_p[4], pv[4], c1_m[4], c2_m[4];
-        load_plane(a.cur, nt_cur, k_first - 1, valid, cn_m);
-        load_plane(a.cur, nt_cur, k_first, valid, cn_0);
-        load_plane(a.cur, nt_cur, k_first + 1, valid, cn_p);
-        load_plane(a.prev, nt_prev, k_first, ok1 && a.prev != nullptr, pv);
+        cur_plane(k_first - 1, valid, cn_m);
+        cur_plane(k_first, valid, cn_0);
+        cur_plane(k_first + 1, valid, cn_p);
+        load_plane(a.prev, nt_prev, k_first, !GEN && ok1 && a.prev != nullptr, pv);  // (GEN: t_{-1} = 0)
         uint2 ids_0 = load_ids(k_first), ids_1 = make_uint2(0xFFFFFFFFu, 0xFFu), ids_2 = ids_1;
 #pragma unroll
         for (int al = 0; al < 4; ++al) c1_m[al] = c2_m[al] = zero;
@@ -520,8 +562,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
             // ---- prefetch what the next iteration consumes
             double2 nx_cn[4], nx_pv[4];
             const bool more = k < k_last;
-            load_plane(a.cur, nt_cur, k + 2, valid && more, nx_cn);
-            load_plane(a.prev, nt_prev, k + 1, ok1 && more && a.prev != nullptr, nx_pv);
+            cur_plane(k + 2, valid && more, nx_cn);
+            load_plane(a.prev, nt_prev, k + 1, !GEN && ok1 && more && a.prev != nullptr, nx_pv);
             const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFu);
 
             put_own(row_0, cn_0);

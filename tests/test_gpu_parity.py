@@ -292,6 +292,8 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
                                       (5, 3, {"BODGE_AMD_SWEEP_LANES": "2"}),  # 26-position windows (3 steps), the default from 4.5e5 sites
                                       (7, 5, {"BODGE_AMD_SWEEP_LANES": "2", "BODGE_AMD_SWEEP_SEGMENTS": "2"}),
                                       (5, 5, {"BODGE_AMD_SWEEP_LANES": "2", "BODGE_AMD_SWEEP_STEPS": "2"}),  # 28-position windows
+                                      (8, per_group, {"BODGE_AMD_SWEEP_GEN": "0"}),  # start block written by the fill kernel and read back
+                                      (1, 3, {}), (2, per_group, {}),  # runs shorter than one sweep
                                       (4, 3, {"BODGE_AMD_NO_DIAGONAL_BLOCKS": "1"})]:  # (read at upload: no effect here, see below)
             ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 5, range(vectors), vec_kind))
             monkeypatch.setenv("BODGE_AMD_SWEEP", "0")
@@ -317,6 +319,10 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
             if rolled:
                 assert perf["launches"] == batches * steps
             assert np.array_equal(got[0], again[0]) and np.array_equal(got[1], again[1])  # bit reproducible
+            if "BODGE_AMD_SWEEP_GEN" in extra:  # the first sweep making t_0 in registers changes no bit
+                assert np.array_equal(got[0], first[0]) and np.array_equal(got[1], first[1])
+            if not extra and steps == 8:
+                first = got
             for other in (ref, one):
                 assert np.abs(got[0] - other[0]).max() <= 1e-12 * n and np.abs(got[1] - other[1]).max() <= 1e-12 * n
     # blocks that are diagonal as 4x4 matrices (plain hopping) take a 4-MAC path in K7/K8; with the
