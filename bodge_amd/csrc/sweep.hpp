@@ -547,10 +547,15 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
         const int k_first = x0 - (steps - 1), k_last = x1 + steps - 2;
 
         // ---- prologue
-        double2 cn_m[4], cn_0[4], cn_p[4], pv[4], c1_m[4], c2_m[4];
+        // Rolling state.  t_n: `cn_m` = plane k-1; two buffers hold planes k and k+1 and swap roles
+        // every iteration (the loop is unrolled by two): the centre plane goes to its LDS row at the
+        // top of the iteration, which frees its registers for the load of plane k+2 - issued there and
+        // first used a whole iteration later, with no register-to-register hand-over in between.
+        // t_{n-1} of plane k+1 is loaded into `pv` as soon as step 1 has consumed plane k's.
+        double2 cn_m[4], buf_a[4], buf_b[4], pv[4], c1_m[4], c2_m[4];
         cur_plane(k_first - 1, valid, cn_m);
-        cur_plane(k_first, valid, cn_0);
-        cur_plane(k_first + 1, valid, cn_p);
+        cur_plane(k_first, valid, buf_a);
+        cur_plane(k_first + 1, valid, buf_b);
         load_plane(a.prev, nt_prev, k_first, !GEN && ok1 && a.prev != nullptr, pv);  // (GEN: t_{-1} = 0)
         uint2 ids_0 = load_ids(k_first), ids_1 = make_uint2(0xFFFFFFFFu, 0xFFu), ids_2 = ids_1;
 #pragma unroll
@@ -558,16 +563,13 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
         put_own(row_1, c1_m);  // the rows still hold the previous unit's planes
         put_own(row_2, c1_m);
 
-        for (int k = k_first; k <= k_last; ++k) {
-            // ---- prefetch what the next iteration consumes
-            double2 nx_cn[4], nx_pv[4];
+        // one iteration: `centre` holds plane k on entry and plane k+2 (in flight) on exit, `after` plane k+1
+        auto iterate = [&](int k, double2 (&centre)[4], const double2 (&after)[4]) {
             const bool more = k < k_last;
-            cur_plane(k + 2, valid && more, nx_cn);
-            load_plane(a.prev, nt_prev, k + 1, !GEN && ok1 && more && a.prev != nullptr, nx_pv);
             const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFu);
-
-            put_own(row_0, cn_0);
+            put_own(row_0, centre);
             wave_sync();
+            cur_plane(k + 2, valid && more, centre);
 
             // ---- step 1 on plane k: level 1 = c1 H t_n - t_{n-1}
             double2 new1[4], new2[4];
@@ -578,7 +580,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
 #pragma unroll
                 for (int al = 0; al < 4; ++al) acc[al] = zero;
                 own_of(row_0, mid);
-                apply(ids_0, cn_m, row_0, mid, cn_p, acc);
+                apply(ids_0, cn_m, row_0, mid, after, acc);
 #pragma unroll
                 for (int al = 0; al < 4; ++al) {
                     new1[al].x = fma(a.coef1, acc[al].x, -pv[al].x);
@@ -591,6 +593,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
                     if (steps == 2) store_plane(a.out1, k, new1);
                 }
             }
+            load_plane(a.prev, nt_prev, k + 1, !GEN && ok1 && more && a.prev != nullptr, pv);
 
             // ---- step 2 on plane k-1: level 2 = c2 H level1 - t_n        (row_1 = level 1, plane k-1)
             if (steps >= 2 && ok2 && in_lattice(k - 1) && k - 1 >= x0 - (steps - 2) && k - 1 < x1 + (steps - 2)) {
@@ -636,16 +639,16 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
             wave_sync();
             put_own(row_1, new1);  // level 1, plane k
             put_own(row_2, new2);  // level 2, plane k-1
-#pragma unroll
-            for (int al = 0; al < 4; ++al) {
-                cn_0[al] = cn_p[al];
-                cn_p[al] = nx_cn[al];
-                pv[al] = nx_pv[al];
-            }
             ids_2 = ids_1;
             ids_1 = ids_0;
             ids_0 = nx_ids;
+        };
+        int k = k_first;
+        for (; k + 1 <= k_last; k += 2) {
+            iterate(k, buf_a, buf_b);
+            iterate(k + 1, buf_b, buf_a);
         }
+        if (k <= k_last) iterate(k, buf_a, buf_b);
     }
 
     __syncthreads();
