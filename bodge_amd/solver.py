@@ -9,6 +9,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 
 import numpy as np
 
@@ -389,6 +390,17 @@ class Communicator:
             return None  # (the override builds a one-rank communicator: exercises the RCCL path on one GPU)
         rank = int(os.environ.get("RANK", "0"))
         local = int(os.environ.get("LOCAL_RANK", rank))
+        # The RCCL object is 573 MB; from cold storage its first read takes minutes.  Every rank
+        # streams it into the page cache (shared: one read serves all) BEFORE the id exchange, so
+        # that the exchange's timeout covers the exchange and not rank 0's library load.
+        prefetch_rccl_library()
+        waited = 0
+        while not rccl_library_ready(30.0):
+            waited += 30
+            if rank == 0:
+                print(f"[bodge_amd] reading the RCCL library from cold storage ... {waited} s", file=sys.stderr, flush=True)
+            if waited >= 1800:
+                raise RuntimeError("the RCCL shared object could not be read within 30 minutes")
         if world <= 1:
             uid = cls.new_unique_id()
         else:
