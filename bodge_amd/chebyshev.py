@@ -20,11 +20,40 @@ import numpy as np
 MAX_MOMENTS = 1 << 17  # default cap of the expansion order (low temperatures)
 
 
+def _native_row_sum_max(indptr: np.ndarray, data: np.ndarray):
+    """The row-sum maximum from the library's threaded block scan (`bdg_host_scan_blocks`: numpy's
+    summation order, so the same double for real or purely imaginary entries), or None when the
+    arrays are not the library's layout or the library is absent (BODGE_AMD_HOST_NATIVE=0: never)."""
+    import ctypes as C
+    import os
+
+    if os.environ.get("BODGE_AMD_HOST_NATIVE", "1") == "0":
+        return None
+    if not (isinstance(data, np.ndarray) and data.dtype == np.complex128 and data.ndim == 3 and data.shape[1:] == (4, 4)
+            and data.flags.c_contiguous and isinstance(indptr, np.ndarray) and indptr.dtype == np.int32
+            and indptr.flags.c_contiguous and len(indptr) >= 1 and int(indptr[-1]) == len(data)):
+        return None
+    try:
+        from . import backend
+
+        lib = backend.load()
+    except (RuntimeError, OSError):
+        return None
+    bound = C.c_double(0.0)
+    if lib.bdg_host_scan_blocks(backend.as_f64p(data), backend.as_i32p(indptr), len(indptr) - 1, None, None, None,
+                                C.byref(bound), None) != 0:
+        return None
+    return float(bound.value)
+
+
 def spectral_bound(indptr: np.ndarray, data: np.ndarray, pad: float = 1.01) -> float:
     """max over scalar rows of Σ|H_rc|, times `pad` (> 1 keeps the spectrum strictly inside)."""
     n_sites = len(indptr) - 1
     if len(data) == 0:
         return 1.0
+    bound = _native_row_sum_max(indptr, data)
+    if bound is not None:
+        return pad * bound if bound > 0 else 1.0
     if np.iscomplexobj(data) and not data.imag.any():
         per_block = np.abs(data.real).sum(axis=2)  # same numbers as |z|, without the hypot pass
     else:

@@ -404,7 +404,7 @@ def test_host_fill_applies_terms_in_order_and_checks_its_arguments(api):
     assert np.isnan(defect.value) and np.isnan(bound.value)
 
 
-def test_long_block_rows_sum_like_numpy(api):
+def test_long_block_rows_sum_like_numpy(api, monkeypatch):
     """Rows of 8 and more blocks take the unrolled branches of numpy's pairwise sum: for real and purely
     imaginary entries (every BASELINE configuration) the bound is numpy's double exactly."""
     import ctypes as C
@@ -420,6 +420,9 @@ def test_long_block_rows_sum_like_numpy(api):
         bound = C.c_double(0.0)
         backend.check(backend.load().bdg_host_scan_blocks(backend.as_f64p(data), backend.as_i32p(indptr), len(lengths),
                                                          None, None, None, C.byref(bound), None))
+        monkeypatch.setenv("BODGE_AMD_HOST_NATIVE", "0")  # the numpy form of the same function
         expected = chebyshev.spectral_bound(indptr, data, pad=1.0)
+        monkeypatch.delenv("BODGE_AMD_HOST_NATIVE")
+        assert chebyshev.spectral_bound(indptr, data, pad=1.0) == bound.value  # (default: the library's scan)
         # (general complex entries: numpy's vectorised |z| and libm's hypot differ in the last bit)
         assert bound.value == expected if real else abs(bound.value - expected) <= 4e-16 * expected
