@@ -18,7 +18,9 @@ CSRC = os.path.join(ROOT, "csrc")
 INCLUDE = os.path.join(os.path.dirname(ROOT), "include")
 LIBRARY = os.path.join(CSRC, "libbodge_hip.so")
 SOURCES = [os.path.join(CSRC, "bodge_hip.hip")]
-HEADERS = [os.path.join(CSRC, "kernels.hpp"), os.path.join(CSRC, "sweep.hpp"), os.path.join(CSRC, "host_assembly.hpp"), os.path.join(INCLUDE, "bodge_hip.h")]
+HEADERS = [os.path.join(CSRC, name) for name in (
+    "kernels.hpp", "sweep.hpp", "host_assembly.hpp", "core.hpp", "plans.hpp", "libraries.hpp", "recurrence.hpp",
+    "lanczos.hpp", "dense.hpp")] + [os.path.join(INCLUDE, "bodge_hip.h")]
 ARCH = "gfx950"
 
 

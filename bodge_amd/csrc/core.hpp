@@ -1,0 +1,147 @@
+// core.hpp - error reporting, device buffers, the handle structures (bdg_system, bdg_comm, bdg_group)
+// Part of the single translation unit bodge_hip.hip (included there, in this order:
+// core, plans, libraries, recurrence, lanczos, dense); everything lives in its unnamed namespace.
+#pragma once
+
+namespace {
+
+thread_local std::string g_error;
+
+int fail(int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    g_error = buf;
+    return code;
+}
+
+#define HIP_TRY(expr)                                                                   \
+    do {                                                                                \
+        hipError_t err__ = (expr);                                                      \
+        if (err__ != hipSuccess)                                                        \
+            return fail(err__ == hipErrorOutOfMemory ? BDG_ENOMEM : BDG_EDEVICE,        \
+                        "%s failed: %s (%s:%d)", #expr, hipGetErrorString(err__),       \
+                        __FILE__, __LINE__);                                            \
+    } while (0)
+
+template <typename T>
+struct DeviceBuffer {
+    T* ptr = nullptr;
+    size_t count = 0;
+    int reserve(size_t n) {
+        if (n <= count) return BDG_OK;
+        release();
+        hipError_t err = hipMalloc(reinterpret_cast<void**>(&ptr), n * sizeof(T));
+        if (err != hipSuccess) {
+            ptr = nullptr;
+            return fail(BDG_ENOMEM, "hipMalloc of %zu bytes failed: %s", n * sizeof(T),
+                        hipGetErrorString(err));
+        }
+        count = n;
+        return BDG_OK;
+    }
+    void release() {
+        if (ptr) (void)hipFree(ptr);
+        ptr = nullptr;
+        count = 0;
+    }
+};
+
+int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+
+}  // namespace
+
+struct bdg_system;
+namespace {
+// A Lanczos run keeps pointers into the handle's vector buffers; any other call that refills or
+// reallocates them ends the run first (bdg_lanczos_advance then reports that begin is needed).
+void lanczos_free(bdg_system* sys);
+}
+
+struct ExchangePeer {
+    int rank = 0;            // peer's rank (RCCL) or member index (same-process group)
+    int64_t send_begin = 0;  // offset into send_rows / send buffer rows
+    int64_t send_count = 0;
+    int64_t recv_col = 0;    // first local column of the rows received from this peer
+    int64_t recv_begin = 0;  // offset into the receive buffer rows
+    int64_t recv_count = 0;
+};
+
+struct bdg_system {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;
+    std::vector<hipEvent_t> ev_pool;  // extra (start, stop) pairs: one per reduction chunk of a call
+    int64_t nb = 0, nnzb = 0;
+    int64_t ncols = 0;       // block rows of the vector buffers: nb owned + halo
+    int64_t row_offset = 0;  // global block row of local row 0 (slab mode)
+    std::vector<ExchangePeer> peers;
+    DeviceBuffer<int64_t> send_rows;
+    DeviceBuffer<double2> send_buf, recv_buf;
+    int64_t send_total = 0, recv_total = 0;
+    bdg_comm* slab_comm = nullptr;  // RCCL transport for the halo exchange (not owned)
+    // agreed over slab_comm in bdg_slab_set_exchange: every rank must choose the same arithmetic
+    // mode and batch width, or the ncclSend/ncclRecv counts of the halo exchange do not match
+    bool slab_all_real = false;
+    int64_t slab_max_ncols = 0;
+    // overlap of the halo exchange with the rows that do not need it
+    std::vector<uint8_t> row_needs_halo;  // host: block row reads at least one halo column
+    hipStream_t comm_stream = nullptr;
+    hipEvent_t ev_step_done = nullptr, ev_halo_ready = nullptr;
+    DeviceBuffer<int> tiles_interior, tiles_boundary;
+    int split_rows_per_tile = 0, n_interior = 0, n_boundary = 0;
+    void* lanczos = nullptr;  // LanczosState of a run in progress (defined with the driver)
+    int max_row_blocks = 0;
+    int64_t bandwidth = 0;  // max |column - row| over the stored blocks (square matrices)
+    int num_cus = 0;
+    int lanes_override = 0;
+    DeviceBuffer<int> indptr, indices;
+    DeviceBuffer<double2> blocks;
+    DeviceBuffer<double2> packed[4];   // re-packed blocks per storage mode, built on first use
+    bool is_real = false;              // imag(H) == 0 everywhere (checked at upload)
+    bool is_ph = false;                // every block is [[A, B], [C, -conj(A)]] (checked at upload)
+    double gershgorin = 0.0;           // max over scalar rows of sum |H_rc| (bound on |H|)
+    // dictionary form: the distinct blocks and one id per stored block (0 entries = not used)
+    int n_unique = 0;
+    int dict_skipped = 0;  // why there is no dictionary: 0 = there is one, 1 = > 256 distinct blocks,
+                           // 2 = more than 2^24 block columns (the packed word holds 24 bits), 3 = switched off
+    DeviceBuffer<int> dict_ids;
+    DeviceBuffer<int> dict_diagonal;      // per distinct block: 1 = diagonal as a 4x4 matrix (stencil kernels)
+    DeviceBuffer<double2> dict_full;      // n_unique x 16 complex entries
+    DeviceBuffer<double2> dict_table[4];  // packed per storage mode, built on first use
+    DeviceBuffer<double2> vec_a, vec_b;
+    DeviceBuffer<double2> vec_c, vec_d;  // two-steps-per-sweep form: t_{n+1}, t_{n+2} are written out of place
+    // lattice-stencil form of the matrix (sweep.hpp): 0 = not examined, 1 = 5-point table built (planes
+    // are lines), 2 = 7-point table built (3-D), -1 = not a stencil
+    DeviceBuffer<uint2> stencil;
+    int stencil_state = 0;
+    bool stencil_wrap_p = false, stencil_wrap_x = false;  // periodic edge blocks: planes / stack of planes are rings
+    DeviceBuffer<double> partial, dots;
+    double* host_dots = nullptr;  // pinned staging for the dot products (sized like `dots`)
+    size_t host_dots_count = 0;
+    DeviceBuffer<int64_t> rows;
+    // lattice geometry hint (rows = z + lz*(y + ly*x)) and the cached strip-major tile order
+    int shape[3] = {0, 0, 0};
+    DeviceBuffer<int> tile_order;
+    int order_rows_per_tile = 0, order_strip_rows = 0;
+    bdg_perf perf{};
+};
+
+struct bdg_comm {
+    int device = 0;
+    int n_ranks = 1, rank = 0;
+    ncclComm_t comm = nullptr;
+    hipStream_t stream = nullptr;
+    DeviceBuffer<double> scratch;
+};
+
+struct bdg_group {
+    std::vector<bdg_system*> members;
+    std::vector<hipEvent_t> packed, copied;  // per member
+};

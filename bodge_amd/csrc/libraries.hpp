@@ -1,0 +1,194 @@
+// libraries.hpp - rocSOLVER / rocBLAS / RCCL loaded on first use, with background prefetch of the shared objects
+// Part of the single translation unit bodge_hip.hip (included there, in this order:
+// core, plans, libraries, recurrence, lanczos, dense); everything lives in its unnamed namespace.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------- lazy libraries
+struct SolverApi {
+    void* blas = nullptr;
+    void* solver = nullptr;
+    decltype(&rocblas_create_handle) create_handle = nullptr;
+    decltype(&rocblas_destroy_handle) destroy_handle = nullptr;
+    decltype(&rocblas_set_stream) set_stream = nullptr;
+    decltype(&rocsolver_zheevd) zheevd = nullptr;
+    decltype(&rocsolver_zheev) zheev = nullptr;
+    decltype(&rocsolver_zheevj) zheevj = nullptr;
+    decltype(&rocsolver_dsyevd) dsyevd = nullptr;
+    decltype(&rocsolver_dsyevj) dsyevj = nullptr;
+};
+
+// Reading a shared object through the page cache before dlopen.  librocsolver.so is 931 MB; on a
+// machine whose page cache does not hold it yet, dlopen + first use fault it in a few KB at a
+// time in link order.  Measured on fresh boxes (profiles/r02_rocsolver_cold.log): 1.5-9 minutes
+// whichever way the bytes are asked for - the lazily provisioned root disk delivers ~2-3 MB/s
+// for data nobody has touched, sequential or not, and parallel readers only slow it down - and
+// well under a second once cached.  So the cost cannot be removed, only moved: `SolverPrefetch`
+// streams the files on a background thread (bdg_dense_prefetch) so that the read overlaps with
+// assembly, upload and whatever else the caller does before the first dense eigensolve above
+// 4N = 2048; load_solver() waits for it.  Pure I/O: no symbol is used from the files.
+void warm_page_cache(const char* path) {
+    const int fd = open(path, O_RDONLY);
+    if (fd < 0) return;
+    (void)posix_fadvise(fd, 0, 0, POSIX_FADV_SEQUENTIAL);
+    std::vector<char> chunk((size_t)8 << 20);
+    while (read(fd, chunk.data(), chunk.size()) > 0) {
+    }
+    close(fd);
+}
+
+struct FilePrefetch {
+    std::vector<const char*> paths;
+    FilePrefetch* after = nullptr;  // read only once that one is done (the disk serves one stream best)
+    std::mutex lock;
+    std::condition_variable changed;
+    bool started = false, done = false, reported = false;
+    double seconds = 0.0;
+    FilePrefetch(std::vector<const char*> files, FilePrefetch* first) : paths(std::move(files)), after(first) {}
+    void start() {
+        std::lock_guard<std::mutex> guard(lock);
+        if (started) return;
+        started = true;
+        if (getenv("BODGE_AMD_NO_PREFETCH")) {
+            done = true;
+            return;
+        }
+        // detached: a process that ends before the read has finished must not wait for it
+        // (the objects themselves are never destroyed, see below)
+        std::thread([this] {
+            if (after && after->is_started()) (void)after->wait(-1.0);
+            const auto t0 = std::chrono::steady_clock::now();
+            for (const char* path : paths) warm_page_cache(path);
+            std::lock_guard<std::mutex> inner(lock);
+            seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            done = true;
+            changed.notify_all();
+        }).detach();
+    }
+    bool is_started() {
+        std::lock_guard<std::mutex> guard(lock);
+        return started;
+    }
+    // true once the files have been read; waits at most `timeout_s` (negative: no limit)
+    bool wait(double timeout_s) {
+        start();
+        std::unique_lock<std::mutex> guard(lock);
+        if (timeout_s < 0) changed.wait(guard, [this] { return done; });
+        else changed.wait_for(guard, std::chrono::duration<double>(timeout_s), [this] { return done; });
+        if (done && !reported && getenv("BODGE_AMD_TRACE")) {
+            reported = true;
+            fprintf(stderr, "[bdg] %s%s read in %.1f s\n", paths[0], paths.size() > 1 ? " ..." : "", seconds);
+        }
+        return done;
+    }
+};
+// deliberately immortal: they outlive every exit path.  One stream at a time - side by side the two
+// reads take as long as one after the other (the cold storage delivers ~2.5 MB/s in total) - and the
+// dense-solver objects first when both are wanted: a diagonalize() call is waiting for those.
+FilePrefetch& g_solver_prefetch =
+    *new FilePrefetch({"/opt/rocm/lib/librocblas.so", "/opt/rocm/lib/librocsolver.so"}, nullptr);
+FilePrefetch& g_rccl_prefetch = *new FilePrefetch({"/opt/rocm/lib/librccl.so"}, &g_solver_prefetch);
+
+int load_solver(SolverApi** out) {
+    static SolverApi api;
+    static bool tried = false, ok = false;
+    if (!tried) {
+        tried = true;
+        g_solver_prefetch.wait(-1.0);
+        api.blas = dlopen("librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!api.blas) api.blas = dlopen("/opt/rocm/lib/librocblas.so", RTLD_NOW | RTLD_GLOBAL);
+        api.solver = dlopen("librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!api.solver) api.solver = dlopen("/opt/rocm/lib/librocsolver.so", RTLD_NOW | RTLD_GLOBAL);
+        if (api.blas && api.solver) {
+            api.create_handle =
+                reinterpret_cast<decltype(api.create_handle)>(dlsym(api.blas, "rocblas_create_handle"));
+            api.destroy_handle =
+                reinterpret_cast<decltype(api.destroy_handle)>(dlsym(api.blas, "rocblas_destroy_handle"));
+            api.set_stream =
+                reinterpret_cast<decltype(api.set_stream)>(dlsym(api.blas, "rocblas_set_stream"));
+            api.zheevd = reinterpret_cast<decltype(api.zheevd)>(dlsym(api.solver, "rocsolver_zheevd"));
+            api.zheev = reinterpret_cast<decltype(api.zheev)>(dlsym(api.solver, "rocsolver_zheev"));
+            api.zheevj = reinterpret_cast<decltype(api.zheevj)>(dlsym(api.solver, "rocsolver_zheevj"));
+            api.dsyevd = reinterpret_cast<decltype(api.dsyevd)>(dlsym(api.solver, "rocsolver_dsyevd"));
+            api.dsyevj = reinterpret_cast<decltype(api.dsyevj)>(dlsym(api.solver, "rocsolver_dsyevj"));
+            ok = api.create_handle && api.destroy_handle && api.set_stream && api.zheevd && api.zheev &&
+                 api.zheevj && api.dsyevd && api.dsyevj;
+        }
+    }
+    if (!ok) return fail(BDG_ELIBRARY, "rocSOLVER/rocBLAS could not be loaded: %s", dlerror());
+    *out = &api;
+    return BDG_OK;
+}
+
+struct RcclApi {
+    void* lib = nullptr;
+    decltype(&ncclGetUniqueId) get_unique_id = nullptr;
+    decltype(&ncclCommInitRank) comm_init_rank = nullptr;
+    decltype(&ncclAllReduce) all_reduce = nullptr;
+    decltype(&ncclCommDestroy) comm_destroy = nullptr;
+    decltype(&ncclGetErrorString) error_string = nullptr;
+    decltype(&ncclSend) send = nullptr;
+    decltype(&ncclRecv) recv = nullptr;
+    decltype(&ncclGroupStart) group_start = nullptr;
+    decltype(&ncclGroupEnd) group_end = nullptr;
+    decltype(&ncclCommCount) comm_count = nullptr;
+};
+
+int load_rccl(RcclApi** out) {
+    static RcclApi api;
+    static bool tried = false, ok = false;
+    if (!tried) {
+        tried = true;
+        (void)g_rccl_prefetch.wait(-1.0);  // 573 MB: streamed in before dlopen faults it in piecemeal
+        api.lib = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (!api.lib) api.lib = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+        if (!api.lib) api.lib = dlopen("/opt/rocm/lib/librccl.so", RTLD_NOW | RTLD_GLOBAL);
+        if (api.lib) {
+            api.get_unique_id =
+                reinterpret_cast<decltype(api.get_unique_id)>(dlsym(api.lib, "ncclGetUniqueId"));
+            api.comm_init_rank =
+                reinterpret_cast<decltype(api.comm_init_rank)>(dlsym(api.lib, "ncclCommInitRank"));
+            api.all_reduce = reinterpret_cast<decltype(api.all_reduce)>(dlsym(api.lib, "ncclAllReduce"));
+            api.comm_destroy =
+                reinterpret_cast<decltype(api.comm_destroy)>(dlsym(api.lib, "ncclCommDestroy"));
+            api.error_string =
+                reinterpret_cast<decltype(api.error_string)>(dlsym(api.lib, "ncclGetErrorString"));
+            api.send = reinterpret_cast<decltype(api.send)>(dlsym(api.lib, "ncclSend"));
+            api.recv = reinterpret_cast<decltype(api.recv)>(dlsym(api.lib, "ncclRecv"));
+            api.group_start = reinterpret_cast<decltype(api.group_start)>(dlsym(api.lib, "ncclGroupStart"));
+            api.group_end = reinterpret_cast<decltype(api.group_end)>(dlsym(api.lib, "ncclGroupEnd"));
+            api.comm_count = reinterpret_cast<decltype(api.comm_count)>(dlsym(api.lib, "ncclCommCount"));
+            ok = api.get_unique_id && api.comm_init_rank && api.all_reduce && api.comm_destroy &&
+                 api.error_string && api.send && api.recv && api.group_start && api.group_end && api.comm_count;
+        }
+    }
+    if (!ok) return fail(BDG_ELIBRARY, "RCCL could not be loaded: %s", dlerror());
+    *out = &api;
+    return BDG_OK;
+}
+
+#define NCCL_TRY(api, expr)                                                                  \
+    do {                                                                                     \
+        ncclResult_t res__ = (expr);                                                         \
+        if (res__ != ncclSuccess)                                                            \
+            return fail(BDG_ELIBRARY, "%s failed: %s", #expr, (api)->error_string(res__));   \
+    } while (0)
+
+int comm_allreduce(bdg_comm* comm, double* buf, int64_t count, ncclRedOp_t op) {
+    if (!comm || !buf || count < 0) return fail(BDG_EINVAL, "bad all-reduce arguments");
+    RcclApi* api = nullptr;
+    if (int rc = load_rccl(&api)) return rc;
+    HIP_TRY(hipSetDevice(comm->device));
+    if (int rc = comm->scratch.reserve((size_t)count)) return rc;
+    HIP_TRY(hipMemcpyAsync(comm->scratch.ptr, buf, sizeof(double) * count, hipMemcpyHostToDevice,
+                           comm->stream));
+    NCCL_TRY(api, api->all_reduce(comm->scratch.ptr, comm->scratch.ptr, (size_t)count, ncclDouble,
+                                  op, comm->comm, comm->stream));
+    HIP_TRY(hipMemcpyAsync(buf, comm->scratch.ptr, sizeof(double) * count, hipMemcpyDeviceToHost,
+                           comm->stream));
+    HIP_TRY(hipStreamSynchronize(comm->stream));
+    return BDG_OK;
+}
+
+}  // namespace

@@ -1,0 +1,726 @@
+// recurrence.hpp - one batch of start vectors through the recurrence (Batch), single handles and same-process slab groups
+// Part of the single translation unit bodge_hip.hip (included there, in this order:
+// core, plans, libraries, recurrence, lanczos, dense); everything lives in its unnamed namespace.
+#pragma once
+
+namespace {
+
+// ------------------------------------------------------------------ recurrence
+// One batch = up to 64 start vectors advanced together on one handle.  The three
+// phases are separate so that a group of slabs can be driven in lock step:
+//   begin()  choose kernel + mode, allocate, write t_0 (own rows) and zero t_{-1}
+//   step(n)  one launch of K1 (after the caller has refreshed the halo of t_n)
+//   finish() reduce partials (done per chunk inside step), copy dots to the host
+struct Batch {
+    bdg_system* sys = nullptr;
+    StepPlan plan;
+    bdg::StepArgs args{};
+    bool real = false;
+    bool alternate = false;  // dictionary kernel: sweep direction flips every launch
+    // unit start vectors: block rows that can be non-zero after n steps are within
+    // (n + 1) * bandwidth of [band_lo, band_hi]; -1 = no band (random vectors, slabs, strip order)
+    int64_t band_lo = -1, band_hi = -1;
+    ModeInfo mode{};
+    int rl = 0, rv = 0, n_active = 0, n_steps = 0, chunk = 1, strip_rows = 0;
+    size_t width = 0, per_step = 0, vec_count = 0;
+    double scale = 1.0;
+    double2* cur = nullptr;
+    double2* prev = nullptr;
+    float kernel_ms = 0.f;
+    int n_chunks = 0;
+    // two-steps-per-sweep form
+    bool sweep = false, roll = false;
+    bool gen_start = false;  // the first sweep makes the random start block itself (no fill kernel)
+    // A call cut into several batches enqueues them back to back and waits once: batch `slot` of
+    // `n_slots` has its own timing events and its own piece of the pinned result buffer.
+    int slot = 0, n_slots = 1, ev_base = 0;
+    size_t host_stride = 0;
+    SweepPlan splan;
+    RollPlan rplan;
+    double2 *spare1 = nullptr, *spare2 = nullptr;
+    int launch_grid = 0;   // workgroups whose dot partials one recurrence step leaves behind
+    int n_launches = 0;
+
+    int begin(bdg_system* system, double scale_in, int steps, int active, const StartSpec& start,
+              int force_real /* -1 auto, 0 complex, 1 real */, bool col_scalars = false) {
+        sys = system;
+        scale = scale_in;
+        n_steps = steps;
+        n_active = active;
+        HIP_TRY(hipSetDevice(sys->device));
+        // Real arithmetic applies when H has no imaginary part and the start vectors are real
+        // (±1 or unit vectors): every t_n then stays real.  BODGE_AMD_REAL=0 forces complex.
+        const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
+        const char* real_env = getenv("BODGE_AMD_REAL");
+        const bool matrix_real = sys->slab_comm ? sys->slab_all_real : sys->is_real;  // slabs: agreed over all ranks
+        real = matrix_real && start_is_real && !(real_env && real_env[0] == '0');
+        if (force_real >= 0) real = force_real != 0;
+        const char* ph_env = getenv("BODGE_AMD_PH");
+        mode = mode_info(real, sys->is_ph && !(ph_env && ph_env[0] == '0'));
+        const int per_lane = mode.per_lane;
+        // Fewer than 4 lanes per row would put 32-64 rows' blocks into one wave's LDS
+        // region with no reuse; small batches run with zero-padded columns.
+        rl = std::max(4, next_pow2((n_active + per_lane - 1) / per_lane));
+        if (sys->lanes_override * per_lane >= n_active && sys->lanes_override >= 4 &&
+            sys->lanes_override * per_lane <= 64)
+            rl = sys->lanes_override;
+        // lattice-stencil kernels (sweep.hpp): K7 runs with 4, 2 or 1 lanes per site, K8 with 4
+        sweep = roll = false;
+        int stencil_kind = 0;
+        if (sys->lanes_override == 0 && rl == 4)
+            if (int rc = sweep_wanted(sys, start.kind == StartKind::Random, col_scalars, &stencil_kind)) return rc;
+        if (stencil_kind == 1) {
+            const int lanes = sweep_lanes_for(sys, n_active, per_lane);
+            if (n_active <= lanes * per_lane) {
+                sweep = true;
+                rl = lanes;
+            }
+        } else if (stencil_kind == 2) {
+            roll = true;
+        }
+        rv = rl * per_lane;  // vector columns in the buffers
+        if (sys->slab_comm && sys->slab_comm->n_ranks > 1) {
+            // the halo messages are 4 * rl payloads per row: a rank with another rl would hang or mis-unpack
+            double probe[2] = {(double)(rl * 2 + (real ? 1 : 0)), -(double)(rl * 2 + (real ? 1 : 0))};
+            if (int rc = comm_allreduce(sys->slab_comm, probe, 2, ncclMax)) return rc;
+            if (probe[0] != -probe[1])
+                return fail(BDG_EINVAL, "slab ranks chose different kernel configurations (lanes x mode %d here)",
+                            rl * 2 + (real ? 1 : 0));
+        }
+        if (sweep) {
+            // (no one-step plan: the generic kernels start at 4 lanes per row; the odd last step of a
+            // run goes through the sweep kernel with its second step switched off)
+            plan = StepPlan{};
+            plan.rl = rl;
+            plan.mode = mode;
+            plan.dictionary = true;
+            args = bdg::StepArgs{};
+            if (int rc = make_sweep_plan(sys, mode, rl, sweep_depth_for(rl), &splan)) return rc;
+        } else {
+            if (int rc = make_plan(sys, rl, mode, &plan, col_scalars)) return rc;
+            if (int rc = matrix_args(sys, plan, &args)) return rc;
+            if (roll && !plan.dictionary) roll = false;
+            if (roll)
+                if (int rc = make_roll_plan(sys, mode, &rplan)) return rc;
+        }
+        launch_grid = sweep ? splan.grid : roll ? rplan.grid : plan.grid;
+        n_launches = 0;
+
+        vec_count = (size_t)4 * sys->ncols * rl;  // 16-byte lane payloads
+        // t_n and t_{n-1} together beyond the 256 MB Infinity Cache: the write of t_{n+1} and the
+        // read of t_{n-1} are hinted non-temporal (+6 % at 10^6 sites x 8 vectors); smaller buffers
+        // stay resident from one launch to the next and are faster with plain accesses
+        // (profiles/r01_stream_probe.log)
+        args.stream_vectors = 2 * vec_count * sizeof(double2) > kStreamVectorBytes ? 3 : 0;
+        if (const char* env = std::getenv("BODGE_AMD_STREAM_VECTORS")) args.stream_vectors = std::atoi(env);
+        alternate = true;
+        if (const char* env = std::getenv("BODGE_AMD_ALTERNATE")) alternate = std::atoi(env) != 0;
+        if (int rc = sys->vec_a.reserve(vec_count)) return rc;
+        if (int rc = sys->vec_b.reserve(vec_count)) return rc;
+        if (sweep) {
+            if (int rc = sys->vec_c.reserve(vec_count)) return rc;
+            if (int rc = sys->vec_d.reserve(vec_count)) return rc;
+            spare1 = sys->vec_c.ptr;
+            spare2 = sys->vec_d.ptr;
+            splan.args.stream = 2 * vec_count * sizeof(double2) > kStreamVectorBytes ? 1 : 0;
+            if (const char* env = std::getenv("BODGE_AMD_SWEEP_STREAM")) splan.args.stream = std::atoi(env);
+        }
+        width = (size_t)2 * rv;
+        if (int rc = prepare_overlap()) return rc;
+        // Dot partials are reduced every `chunk` launches.  Buffer sizes do not depend on
+        // n_steps (up to 1024), so a short warm-up call leaves nothing to allocate later.
+        per_step = (size_t)(overlapped ? grid_interior + grid_boundary : launch_grid) * width;
+        constexpr int kChunk = 64;
+        chunk = std::min(n_steps, sweep && splan.depth == 3 ? 63 : kChunk);  // a sweep must not straddle two chunks
+        if (int rc = sys->partial.reserve((size_t)kChunk * per_step)) return rc;
+        const size_t dots_count = (size_t)std::max(n_steps, 1024) * width;
+        if (int rc = sys->dots.reserve(dots_count)) return rc;
+        host_stride = dots_count;
+        ev_base = slot * ((n_steps + chunk - 1) / chunk);
+        if (sys->host_dots_count < dots_count * n_slots) {
+            HIP_TRY(hipStreamSynchronize(sys->stream));  // (an earlier batch of this call may still be copying into it)
+            if (sys->host_dots) (void)hipHostFree(sys->host_dots);
+            sys->host_dots = nullptr;
+            sys->host_dots_count = 0;
+            HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sys->host_dots), dots_count * n_slots * sizeof(double), 0));
+            sys->host_dots_count = dots_count * n_slots;
+        }
+        if (sys->send_total > 0)
+            if (int rc = sys->send_buf.reserve((size_t)sys->send_total * 4 * rl)) return rc;
+        if (sys->recv_total > 0)
+            if (int rc = sys->recv_buf.reserve((size_t)sys->recv_total * 4 * rl)) return rc;
+
+        hipStream_t st = sys->stream;
+        const int fill_grid = (int)std::min<size_t>(4096, (vec_count + 255) / 256);
+        // Three-step sweeps make a random t_0 in registers during the first sweep (cheb_sweep3 GEN):
+        // no fill kernel, and vec_a is only ever a spare buffer.  BODGE_AMD_SWEEP_GEN=0: fill and read.
+        gen_start = sweep && splan.depth == 3 && splan.kernel_gen && start.kind == StartKind::Random &&
+                    sys->row_offset == 0 && sys->ncols == sys->nb;
+        if (const char* env = getenv("BODGE_AMD_SWEEP_GEN")) gen_start = gen_start && atoi(env) != 0;
+        if (gen_start) {
+            splan.args.gen_seed = start.seed;
+            splan.args.gen_first_id = start.first_id;
+            splan.args.gen_kind = real ? BDG_VEC_RADEMACHER : start.vec_kind;
+            splan.args.gen_active = n_active;
+        } else if (start.kind == StartKind::Random) {
+            if (real)
+                bdg::fill_random_real<<<fill_grid, 256, 0, st>>>(
+                    reinterpret_cast<double*>(sys->vec_a.ptr), sys->nb, sys->ncols, rv, n_active,
+                    start.seed, start.first_id, sys->row_offset);
+            else
+                bdg::fill_random<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, sys->nb, sys->ncols, rv,
+                                                            n_active, start.seed, start.first_id,
+                                                            start.vec_kind, sys->row_offset);
+        } else {
+            if (int rc = sys->rows.reserve(64)) return rc;
+            HIP_TRY(hipMemcpyAsync(sys->rows.ptr, start.rows, sizeof(int64_t) * n_active,
+                                   hipMemcpyHostToDevice, st));
+            if (sys->ncols == sys->nb && !getenv("BODGE_AMD_NO_BAND")) {
+                band_lo = sys->nb;
+                band_hi = 0;
+                for (int r = 0; r < n_active; ++r) {
+                    band_lo = std::min<int64_t>(band_lo, start.rows[r] >> 2);
+                    band_hi = std::max<int64_t>(band_hi, start.rows[r] >> 2);
+                }
+            }
+            bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, (int64_t)vec_count);
+            if (real)
+                bdg::set_unit_real<<<1, 64, 0, st>>>(reinterpret_cast<double*>(sys->vec_a.ptr), sys->nb,
+                                                     sys->ncols, rv, n_active, sys->rows.ptr,
+                                                     sys->row_offset);
+            else
+                bdg::set_unit<<<1, 64, 0, st>>>(sys->vec_a.ptr, sys->nb, sys->ncols, rv, n_active,
+                                                sys->rows.ptr, sys->row_offset);
+        }
+        if (!sweep)  // (the sweep kernels are told that t_{-1} = 0 instead of reading 256 MB of zeros)
+            bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)vec_count);
+        HIP_TRY(hipGetLastError());
+
+        // bytes of t_n per block row that neighbouring rows re-read: 4 entries per vector
+        if (!sweep)
+            if (int rc = prepare_tile_order(sys, plan.rows_per_tile, plan.n_tiles,
+                                            (real ? 32.0 : 64.0) * rv, &args.tile_order, &strip_rows))
+                return rc;
+        if (args.tile_order) band_lo = band_hi = -1;  // the band is a range of naturally ordered tiles
+        if (sweep || roll) {
+            strip_rows = 0;
+            band_lo = band_hi = -1;
+        }
+        cur = sys->vec_a.ptr;
+        prev = sys->vec_b.ptr;
+        kernel_ms = 0.f;
+        n_chunks = 0;
+        return BDG_OK;
+    }
+
+    // Halo exchange, split so that a same-process group can interleave its members.
+    int pack(hipStream_t st = nullptr) {
+        if (sys->send_total == 0) return BDG_OK;
+        if (!st) st = sys->stream;
+        HIP_TRY(hipSetDevice(sys->device));
+        const int64_t total = sys->send_total * 4 * rl;
+        bdg::halo_pack<<<(unsigned)std::min<int64_t>(2048, (total + 255) / 256), 256, 0, st>>>(
+            cur, sys->send_rows.ptr, sys->send_total, sys->ncols, rl, sys->send_buf.ptr);
+        HIP_TRY(hipGetLastError());
+        return BDG_OK;
+    }
+    int unpack(hipStream_t st = nullptr) {
+        if (!st) st = sys->stream;
+        HIP_TRY(hipSetDevice(sys->device));
+        for (const ExchangePeer& peer : sys->peers) {
+            if (peer.recv_count == 0) continue;
+            const int64_t total = peer.recv_count * 4 * rl;
+            bdg::halo_unpack<<<(unsigned)std::min<int64_t>(2048, (total + 255) / 256), 256, 0, st>>>(
+                cur, peer.recv_col, peer.recv_count, sys->ncols, rl,
+                sys->recv_buf.ptr + (size_t)peer.recv_begin * 4 * rl);
+        }
+        HIP_TRY(hipGetLastError());
+        return BDG_OK;
+    }
+
+    // ---- overlap: rows that read no halo column ("interior") do not have to wait for the
+    // exchange.  The workgroup tiles are split into two lists; per launch of the recurrence
+    //   comm stream   : wait(previous step) -> pack -> ncclSend/Recv -> unpack -> ev_halo_ready
+    //   compute stream: K1(interior tiles) -> wait(ev_halo_ready) -> K1(boundary tiles) -> ev_step_done
+    // so the transfer hides behind the interior launch.  Hazards: the exchange only reads owned
+    // rows of t_n and writes halo rows of the same buffer, which nothing but the boundary launch of
+    // this step reads; both launches write owned rows of the other buffer.
+    int grid_interior = 0, grid_boundary = 0;
+    bool overlapped = false;
+
+    int prepare_overlap() {
+        overlapped = false;
+        const char* env = getenv("BODGE_AMD_OVERLAP");
+        if (sys->peers.empty() || !sys->slab_comm || sys->row_needs_halo.empty() || (env && env[0] == '0'))
+            return BDG_OK;
+        if (sys->split_rows_per_tile != plan.rows_per_tile) {
+            std::vector<int> interior, boundary;
+            for (int t = 0; t < plan.n_tiles; ++t) {
+                bool needs = false;
+                const int64_t r0 = (int64_t)t * plan.rows_per_tile;
+                for (int64_t i = r0; i < std::min<int64_t>(sys->nb, r0 + plan.rows_per_tile); ++i)
+                    needs = needs || sys->row_needs_halo[(size_t)i];
+                (needs ? boundary : interior).push_back(t);
+            }
+            if (int rc = sys->tiles_interior.reserve(std::max<size_t>(1, interior.size()))) return rc;
+            if (int rc = sys->tiles_boundary.reserve(std::max<size_t>(1, boundary.size()))) return rc;
+            if (!interior.empty())
+                HIP_TRY(hipMemcpy(sys->tiles_interior.ptr, interior.data(), sizeof(int) * interior.size(),
+                                  hipMemcpyHostToDevice));
+            if (!boundary.empty())
+                HIP_TRY(hipMemcpy(sys->tiles_boundary.ptr, boundary.data(), sizeof(int) * boundary.size(),
+                                  hipMemcpyHostToDevice));
+            sys->n_interior = (int)interior.size();
+            sys->n_boundary = (int)boundary.size();
+            sys->split_rows_per_tile = plan.rows_per_tile;
+        }
+        if (sys->n_interior == 0 || sys->n_boundary == 0) return BDG_OK;  // nothing to hide behind
+        if (!sys->comm_stream) {
+            HIP_TRY(hipStreamCreateWithFlags(&sys->comm_stream, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&sys->ev_step_done, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&sys->ev_halo_ready, hipEventDisableTiming));
+        }
+        auto grid_for = [&](int tiles) { return std::max(8, (std::min(tiles, plan.grid) + 7) / 8 * 8); };
+        grid_interior = grid_for(sys->n_interior);
+        grid_boundary = grid_for(sys->n_boundary);
+        overlapped = true;
+        return BDG_OK;
+    }
+
+    int rccl_transfer(hipStream_t st) {
+        bdg_comm* comm = sys->slab_comm;
+        RcclApi* api = nullptr;
+        if (int rc = load_rccl(&api)) return rc;
+        NCCL_TRY(api, api->group_start());
+        for (const ExchangePeer& peer : sys->peers) {
+            const size_t unit = (size_t)4 * rl * 2;  // doubles per exchanged block row
+            if (peer.send_count > 0)
+                NCCL_TRY(api, api->send(sys->send_buf.ptr + (size_t)peer.send_begin * 4 * rl,
+                                        (size_t)peer.send_count * unit, ncclDouble, peer.rank, comm->comm, st));
+            if (peer.recv_count > 0)
+                NCCL_TRY(api, api->recv(sys->recv_buf.ptr + (size_t)peer.recv_begin * 4 * rl,
+                                        (size_t)peer.recv_count * unit, ncclDouble, peer.rank, comm->comm, st));
+        }
+        NCCL_TRY(api, api->group_end());
+        return BDG_OK;
+    }
+
+    int step_overlapped(int n) {
+        HIP_TRY(hipSetDevice(sys->device));
+        hipStream_t st = sys->stream, cs = sys->comm_stream;
+        const int in_chunk = n % chunk;
+        const int chunk_id = n / chunk;
+        while ((int)sys->ev_pool.size() < 2 * (ev_base + chunk_id + 1)) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreate(&ev));
+            sys->ev_pool.push_back(ev);
+        }
+        // exchange of t_n on the communication stream, after everything that produced t_n
+        HIP_TRY(hipEventRecord(sys->ev_step_done, st));
+        HIP_TRY(hipStreamWaitEvent(cs, sys->ev_step_done, 0));
+        if (int rc = pack(cs)) return rc;
+        if (int rc = rccl_transfer(cs)) return rc;
+        if (int rc = unpack(cs)) return rc;
+        HIP_TRY(hipEventRecord(sys->ev_halo_ready, cs));
+
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id)], st));
+        args.cur = cur;
+        args.prev = prev;
+        args.coef = (n == 0 ? 1.0 : 2.0) / scale;
+        double* slot = sys->partial.ptr + (size_t)in_chunk * per_step;
+        bdg::StepArgs part = args;
+        part.tile_order = sys->tiles_interior.ptr;
+        part.n_tiles = sys->n_interior;
+        part.partial = slot;
+        part.reverse = alternate ? (n & 1) : 0;  // same cache-aware sweep as the plain step
+        plan.kernel<<<grid_interior, bdg::kBlockThreads, plan.lds_bytes, st>>>(part);
+        HIP_TRY(hipStreamWaitEvent(st, sys->ev_halo_ready, 0));
+        part.tile_order = sys->tiles_boundary.ptr;
+        part.n_tiles = sys->n_boundary;
+        part.partial = slot + (size_t)grid_interior * width;
+        plan.kernel<<<grid_boundary, bdg::kBlockThreads, plan.lds_bytes, st>>>(part);
+        std::swap(cur, prev);
+        if (in_chunk == chunk - 1 || n == n_steps - 1) {
+            const int s0 = n - in_chunk;
+            HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id) + 1], st));
+            bdg::reduce_partials<<<in_chunk + 1, 256, 0, st>>>(sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width,
+                                                              grid_interior + grid_boundary, (int)width);
+            HIP_TRY(hipGetLastError());
+            n_chunks = chunk_id + 1;
+        }
+        return BDG_OK;
+    }
+
+    // RCCL transport without overlap: grouped send/recv of the packed rows on the compute stream.
+    int exchange_rccl() {
+        if (sys->peers.empty()) return BDG_OK;
+        bdg_comm* comm = sys->slab_comm;
+        if (!comm) return fail(BDG_EINVAL, "slab handle has exchange peers but no communicator");
+        RcclApi* api = nullptr;
+        if (int rc = load_rccl(&api)) return rc;
+        if (int rc = pack()) return rc;
+        NCCL_TRY(api, api->group_start());
+        for (const ExchangePeer& peer : sys->peers) {
+            const size_t unit = (size_t)4 * rl * 2;  // doubles per exchanged block row
+            if (peer.send_count > 0)
+                NCCL_TRY(api, api->send(sys->send_buf.ptr + (size_t)peer.send_begin * 4 * rl,
+                                        (size_t)peer.send_count * unit, ncclDouble, peer.rank, comm->comm,
+                                        sys->stream));
+            if (peer.recv_count > 0)
+                NCCL_TRY(api, api->recv(sys->recv_buf.ptr + (size_t)peer.recv_begin * 4 * rl,
+                                        (size_t)peer.recv_count * unit, ncclDouble, peer.rank, comm->comm,
+                                        sys->stream));
+        }
+        NCCL_TRY(api, api->group_end());
+        return unpack();
+    }
+
+    int step(int n) {
+        HIP_TRY(hipSetDevice(sys->device));
+        hipStream_t st = sys->stream;
+        const int in_chunk = n % chunk;
+        const int chunk_id = n / chunk;
+        // one event pair per chunk, read back in finish(): the host never waits inside the loop
+        while ((int)sys->ev_pool.size() < 2 * (ev_base + chunk_id + 1)) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreate(&ev));
+            sys->ev_pool.push_back(ev);
+        }
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id)], st));
+        args.cur = cur;
+        args.prev = prev;
+        args.coef = (n == 0 ? 1.0 : 2.0) / scale;
+        args.partial = sys->partial.ptr + (size_t)in_chunk * per_step;
+        args.reverse = alternate ? (n & 1) : 0;
+        args.tile_base = 0;
+        args.n_tiles = plan.n_tiles;
+        if (band_lo >= 0) {
+            // t_{n+1} can be non-zero only where t_n or a neighbour within the bandwidth was
+            const int64_t reach = (int64_t)(n + 1) * sys->bandwidth;
+            const int64_t lo = std::max<int64_t>(0, band_lo - reach);
+            const int64_t hi = std::min<int64_t>(sys->nb, band_hi + reach + 1);
+            const int first = (int)(lo / plan.rows_per_tile);
+            const int last = (int)((hi + plan.rows_per_tile - 1) / plan.rows_per_tile);
+            args.tile_base = first;
+            args.n_tiles = std::min(plan.n_tiles, last) - first;
+        }
+        if (roll) {
+            bdg::RollArgs& ra = rplan.args;
+            ra.cur = cur;
+            ra.prev = prev;
+            ra.coef = args.coef;
+            ra.partial = args.partial;
+            ra.reverse = args.reverse;
+            ra.stream = args.stream_vectors;
+            rplan.kernel<<<rplan.grid, bdg::kBlockThreads, rplan.lds_bytes, st>>>(ra);
+        } else {
+            plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
+        }
+        std::swap(cur, prev);
+        if (in_chunk == chunk - 1 || n == n_steps - 1) {
+            const int s0 = n - in_chunk;
+            HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id) + 1], st));
+            bdg::reduce_partials<<<in_chunk + 1, 256, 0, st>>>(
+                sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, launch_grid, (int)width);
+            HIP_TRY(hipGetLastError());
+            n_chunks = chunk_id + 1;
+        }
+        return BDG_OK;
+    }
+
+    // Steps n .. n + depth - 1 in one sweep (sweep.hpp); what is left at the end of a run in a
+    // shorter one.  Returns the number of steps made.  Buffers rotate:
+    // (t_n, t_{n-1}, spare, spare) -> (t_{n+k}, t_{n+k-1}, spare, spare).
+    int step_sweep(int n, int* made) {
+        HIP_TRY(hipSetDevice(sys->device));
+        hipStream_t st = sys->stream;
+        const int in_chunk = n % chunk;
+        const int chunk_id = n / chunk;
+        const int now = std::min({splan.depth, n_steps - n, chunk - in_chunk});
+        *made = now;
+        while ((int)sys->ev_pool.size() < 2 * (ev_base + chunk_id + 1)) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreate(&ev));
+            sys->ev_pool.push_back(ev);
+        }
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id)], st));
+        bdg::SweepArgs& a = splan.args;
+        a.cur = cur;
+        a.prev = n == 0 ? nullptr : prev;
+        a.out1 = spare1;
+        a.out2 = spare2;
+        a.coef1 = (n == 0 ? 1.0 : 2.0) / scale;
+        a.coef2 = 2.0 / scale;
+        a.two = now >= 2 ? 1 : 0;
+        a.steps = now;
+        a.partial1 = sys->partial.ptr + (size_t)in_chunk * per_step;
+        a.partial2 = a.partial1 + per_step;
+        a.partial3 = a.partial2 + per_step;
+        const SweepKernel kernel = n == 0 && gen_start ? splan.kernel_gen
+                                   : alternate && (n_launches & 1) ? splan.kernel_reverse : splan.kernel;
+        if (n == 0 && gen_start) a.cur = nullptr;  // (never read)
+        kernel<<<splan.grid, bdg::kSweepThreads, splan.lds_bytes, st>>>(a);
+        ++n_launches;
+        double2* old_cur = cur;
+        double2* old_prev = prev;
+        if (splan.depth == 2 && now == 1) {  // cheb_sweep writes a lone step to out1
+            cur = spare1;
+            prev = old_cur;
+            spare1 = old_prev;
+        } else if (now == 1) {               // cheb_sweep3 writes the last level to out2, the one before to out1
+            cur = spare2;
+            prev = old_cur;
+            spare2 = old_prev;
+        } else {
+            cur = spare2;
+            prev = spare1;
+            spare1 = old_prev;
+            spare2 = old_cur;
+        }
+        const int last = n + now - 1;
+        const int last_in_chunk = last % chunk;
+        if (last_in_chunk == chunk - 1 || last == n_steps - 1) {
+            const int s0 = last - last_in_chunk;
+            HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id) + 1], st));
+            bdg::reduce_partials<<<last_in_chunk + 1, 256, 0, st>>>(
+                sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, launch_grid, (int)width);
+            HIP_TRY(hipGetLastError());
+            n_chunks = chunk_id + 1;
+        }
+        return BDG_OK;
+    }
+
+    // d/e of this handle's rows into columns [col0, col0 + n_active) of (n_steps x ld) arrays;
+    // accumulate = true adds to what is there (summing the slabs of a group).
+    int finish(double* d_out, double* e_out, int ld, int col0, bool accumulate, bool first_batch) {
+        if (int rc = finish_enqueue()) return rc;
+        HIP_TRY(hipStreamSynchronize(sys->stream));
+        return finish_collect(d_out, e_out, ld, col0, accumulate, first_batch);
+    }
+    // copy of the batch's dot products to the host, enqueued behind its last reduction
+    int finish_enqueue() {
+        HIP_TRY(hipSetDevice(sys->device));
+        // pinned: a pageable target costs ~8 ms on its first use
+        HIP_TRY(hipMemcpyAsync(sys->host_dots + (size_t)slot * host_stride, sys->dots.ptr,
+                               (size_t)n_steps * width * sizeof(double), hipMemcpyDeviceToHost, sys->stream));
+        return BDG_OK;
+    }
+    // after the stream has been waited for
+    int finish_collect(double* d_out, double* e_out, int ld, int col0, bool accumulate, bool first_batch) {
+        HIP_TRY(hipSetDevice(sys->device));
+        const double* host = sys->host_dots + (size_t)slot * host_stride;
+        for (int c = 0; c < n_chunks; ++c) {
+            float ms = 0.f;
+            HIP_TRY(hipEventElapsedTime(&ms, sys->ev_pool[2 * (ev_base + c)], sys->ev_pool[2 * (ev_base + c) + 1]));
+            kernel_ms += ms;
+        }
+        for (int n = 0; n < n_steps; ++n)
+            for (int r = 0; r < n_active; ++r) {
+                double& d = d_out[(size_t)n * ld + col0 + r];
+                double& e = e_out[(size_t)n * ld + col0 + r];
+                const double dv = host[(size_t)n * width + 2 * r], ev = host[(size_t)n * width + 2 * r + 1];
+                d = accumulate ? d + dv : dv;
+                e = accumulate ? e + ev : ev;
+            }
+        bdg_perf& p = sys->perf;
+        if (first_batch) p = bdg_perf{};
+        p.kernel_ms += kernel_ms;
+        p.launches += sweep ? n_launches : n_steps;
+        p.vector_steps += (int64_t)n_steps * n_active;
+        p.bytes_per_launch = sweep  ? sweep_bytes(sys, mode, rl)
+                             : roll ? roll_bytes(sys, mode)
+                                    : algorithmic_bytes(sys, rv, mode, plan.dictionary);
+        p.steps_per_launch = sweep ? splan.depth : 1;
+        p.rolling = roll ? 1 : 0;
+        p.dict_skipped = sys->dict_skipped;
+        p.lanes_per_row = rl;
+        p.vectors_per_launch = rv;
+        p.real_arithmetic = real ? 1 : 0;
+        p.ph_packed = mode.ph ? 1 : 0;
+        p.dict_blocks = plan.dictionary ? sys->n_unique : 0;
+        p.strip_rows = strip_rows;
+        p.grid = launch_grid;
+        p.lds_bytes = (int32_t)(sweep ? splan.lds_bytes : roll ? rplan.lds_bytes : plan.lds_footprint);
+        p.pipelined = plan.pipelined ? 1 : 0;
+        return BDG_OK;
+    }
+};
+
+int check_recurrence_args(const void* sys, double scale, int n_steps, int n_vectors, const double* d_out,
+                          const double* e_out) {
+    if (!sys) return fail(BDG_EINVAL, "null system handle");
+    if (!(scale > 0.0)) return fail(BDG_EINVAL, "scale must be positive");
+    if (n_steps < 1 || n_vectors < 1) return fail(BDG_EINVAL, "n_steps and n_vectors must be >= 1");
+    if (!d_out || !e_out) return fail(BDG_EINVAL, "null output buffer");
+    return BDG_OK;
+}
+
+StartSpec batch_start(const StartSpec& start, int col) {
+    StartSpec batch = start;
+    if (start.kind == StartKind::Random) batch.first_id = start.first_id + col;
+    else batch.rows = start.rows + col;
+    return batch;
+}
+
+// Vectors advanced together.  Wide batches amortise launch latency and the matrix stream, narrow
+// ones keep t_n and t_{n-1} close to the caches: measured optimum (wall time per vector-step of
+// 64 vectors, profiles/r01_batch_width.log) is ~2.5 M site-vectors per launch, i.e. 64 vectors up
+// to 200x200 sites, 32 at 300x300, 16 at 400x400, 8 from 64^3 on (10^6 sites: 18.0 us per
+// vector-step at 8 per batch, 21.3 us at 64).  Rule: the largest power of two that keeps one
+// vector buffer within 96 MB, at least one full lane group (8 real / 4 complex), at most 64.
+int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors) {
+    if (const char* env = getenv("BODGE_AMD_BATCH")) return std::clamp(atoi(env), 1, 64);
+    const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
+    const char* real_env = getenv("BODGE_AMD_REAL");
+    const bool real = (sys->slab_comm ? sys->slab_all_real : sys->is_real) && start_is_real &&
+                      !(real_env && real_env[0] == '0');
+    int stencil_kind = 0;
+    if (sys->lanes_override == 0 && sweep_wanted(sys, start.kind == StartKind::Random, false, &stencil_kind) == BDG_OK &&
+        stencil_kind != 0) {
+        const int per_lane = real ? 2 : 1;
+        const int lanes = stencil_kind == 1 ? sweep_lanes_for(sys, n_vectors, per_lane) : bdg::kSweepLanes;
+        return std::min(lanes * per_lane, std::max(n_vectors, 1));  // one lane group per launch
+    }
+    // (slabs: the widest slab of the run decides, so that every rank cuts the same batches)
+    const double per_vector = (double)std::max(sys->ncols, sys->slab_max_ncols) * 4 * (real ? 8.0 : 16.0);
+    const int granule = 8;  // (the register-pipelined complex kernels start at 8 lanes per row)
+    constexpr double kBufferTarget = 96.0 * 1024 * 1024;
+    int width = 64;
+    while (width > granule && width * per_vector > kBufferTarget) width >>= 1;
+    return std::min(width, std::max(n_vectors, 1));
+}
+
+// Single handle (whole matrix, or one slab of a multi-process run with RCCL halos).
+int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, StartSpec start,
+                   double* d_out, double* e_out) {
+    if (int rc = check_recurrence_args(sys, scale, n_steps, n_vectors, d_out, e_out)) return rc;
+    lanczos_free(sys);
+    const bool trace = getenv("BODGE_AMD_TRACE") != nullptr;
+    auto now = [] { return std::chrono::steady_clock::now(); };
+    auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
+    const int width = batch_width(sys, start, n_vectors);
+    // Batches are enqueued back to back and waited for once (whole matrices; a slab's batches are
+    // paced by its halo exchange anyway): the GPU does not idle while the host turns a batch around.
+    const int n_batches = (n_vectors + width - 1) / width;
+    const size_t staged = (size_t)n_batches * std::max(n_steps, 1024) * 2 * (size_t)width;  // doubles of pinned memory
+    const bool pipelined = n_batches > 1 && n_batches <= 64 && staged <= ((size_t)4 << 20) && sys->ncols == sys->nb &&
+                           !getenv("BODGE_AMD_NO_BATCH_PIPELINE");
+    std::vector<Batch> queued(pipelined ? (size_t)n_batches : 0);
+    size_t stride0 = 0;
+    for (int col = 0, index = 0; col < n_vectors; col += width, ++index) {
+        Batch single;
+        Batch& batch = pipelined ? queued[(size_t)index] : single;
+        if (pipelined) {
+            batch.slot = index;
+            batch.n_slots = n_batches;
+        }
+        const auto t0 = now();
+        if (int rc = batch.begin(sys, scale, n_steps, std::min(width, n_vectors - col),
+                                 batch_start(start, col), -1))
+            return rc;
+        if (pipelined) {  // one spacing of the result pieces for the whole call: the first batch is the widest
+            if (index == 0) stride0 = batch.host_stride;
+            batch.host_stride = stride0;
+        }
+        const auto t1 = now();
+        for (int n = 0; n < n_steps; ++n) {
+            if (batch.sweep) {
+                int made = 1;
+                if (int rc = batch.step_sweep(n, &made)) return rc;
+                n += made - 1;
+                continue;
+            }
+            if (batch.overlapped) {
+                if (int rc = batch.step_overlapped(n)) return rc;
+                continue;
+            }
+            if (int rc = batch.exchange_rccl()) return rc;
+            if (int rc = batch.step(n)) return rc;
+        }
+        const auto t2 = now();
+        if (pipelined) {
+            if (int rc = batch.finish_enqueue()) return rc;
+        } else if (int rc = batch.finish(d_out, e_out, n_vectors, col, false, col == 0)) {
+            return rc;
+        }
+        if (trace)
+            fprintf(stderr, "[bdg] begin %.3f ms, steps %.3f ms (kernels %.3f), finish %.3f ms\n", ms(t0, t1),
+                    ms(t1, t2), batch.kernel_ms, ms(t2, now()));
+    }
+    if (pipelined) {
+        HIP_TRY(hipSetDevice(sys->device));
+        HIP_TRY(hipStreamSynchronize(sys->stream));
+        for (int index = 0; index < n_batches; ++index)
+            if (int rc = queued[(size_t)index].finish_collect(d_out, e_out, n_vectors, index * width, false, index == 0))
+                return rc;
+    }
+    return BDG_OK;
+}
+
+// Same-process group of slabs (one handle per slab, on one or several devices of this
+// process): the halo rows travel by device-to-device copies ordered with events.
+//   stream m:  [wait until my previous send buffer was consumed] pack -> ev packed[m]
+//              for each peer p: wait packed[p]; copy p.send segment -> my recv segment
+//              -> ev copied[m]; unpack; K1
+int run_group(bdg_group* group, double scale, int n_steps, int n_vectors, StartSpec start,
+              double* d_out, double* e_out) {
+    if (int rc = check_recurrence_args(group, scale, n_steps, n_vectors, d_out, e_out)) return rc;
+    const size_t n_members = group->members.size();
+    bool all_real = true;
+    for (bdg_system* m : group->members) {
+        all_real = all_real && m->is_real;
+        lanczos_free(m);
+    }
+    // (storage packing is per member: it changes what a member reads, not what it exchanges)
+    const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
+    const char* real_env = getenv("BODGE_AMD_REAL");
+    const int force_real = (all_real && start_is_real && !(real_env && real_env[0] == '0')) ? 1 : 0;
+
+    for (int col = 0; col < n_vectors; col += 64) {
+        std::vector<Batch> batch(n_members);
+        for (size_t m = 0; m < n_members; ++m)
+            if (int rc = batch[m].begin(group->members[m], scale, n_steps, std::min(64, n_vectors - col),
+                                        batch_start(start, col), force_real))
+                return rc;
+        for (size_t m = 1; m < n_members; ++m)
+            if (batch[m].rl != batch[0].rl)
+                return fail(BDG_EINVAL, "group members chose different kernel configurations");
+        const size_t unit = (size_t)4 * batch[0].rl * sizeof(double2);  // bytes per exchanged block row
+        for (int n = 0; n < n_steps; ++n) {
+            for (size_t m = 0; m < n_members; ++m) {
+                bdg_system* sys = group->members[m];
+                HIP_TRY(hipSetDevice(sys->device));
+                if (n > 0)
+                    for (const ExchangePeer& peer : sys->peers)
+                        HIP_TRY(hipStreamWaitEvent(sys->stream, group->copied[peer.rank], 0));
+                if (int rc = batch[m].pack()) return rc;
+                HIP_TRY(hipEventRecord(group->packed[m], sys->stream));
+            }
+            for (size_t m = 0; m < n_members; ++m) {
+                bdg_system* sys = group->members[m];
+                HIP_TRY(hipSetDevice(sys->device));
+                for (const ExchangePeer& peer : sys->peers) {
+                    if (peer.recv_count == 0) continue;
+                    bdg_system* src = group->members[peer.rank];
+                    const ExchangePeer* back = nullptr;
+                    for (const ExchangePeer& q : src->peers)
+                        if (q.rank == (int)m) back = &q;
+                    HIP_TRY(hipStreamWaitEvent(sys->stream, group->packed[peer.rank], 0));
+                    HIP_TRY(hipMemcpyPeerAsync(
+                        reinterpret_cast<char*>(sys->recv_buf.ptr) + (size_t)peer.recv_begin * unit,
+                        sys->device,
+                        reinterpret_cast<const char*>(src->send_buf.ptr) + (size_t)back->send_begin * unit,
+                        src->device, (size_t)peer.recv_count * unit, sys->stream));
+                }
+                HIP_TRY(hipEventRecord(group->copied[m], sys->stream));
+                if (int rc = batch[m].unpack()) return rc;
+                if (int rc = batch[m].step(n)) return rc;
+            }
+        }
+        for (size_t m = 0; m < n_members; ++m)
+            if (int rc = batch[m].finish(d_out, e_out, n_vectors, col, m > 0, col == 0)) return rc;
+    }
+    return BDG_OK;
+}
+
+}  // namespace

@@ -643,12 +643,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
             ids_1 = ids_0;
             ids_0 = nx_ids;
         };
-        int k = k_first;
-        for (; k + 1 <= k_last; k += 2) {
+        for (int k = k_first; k <= k_last; k += 2) {
             iterate(k, buf_a, buf_b);
-            iterate(k + 1, buf_b, buf_a);
+            if (k + 1 <= k_last) iterate(k + 1, buf_b, buf_a);
         }
-        if (k <= k_last) iterate(k, buf_a, buf_b);
     }
 
     __syncthreads();
