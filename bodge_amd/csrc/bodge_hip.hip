@@ -7,6 +7,7 @@
 // on first use so that the core library has no load-time dependency on them.
 //
 // One translation unit.  This file holds the extern "C" entry points; what they call sits in
+//   knobs.hpp       every environment switch, documented, behind one accessor
 //   core.hpp        error reporting, DeviceBuffer, bdg_system / bdg_comm / bdg_group
 //   plans.hpp       kernel dispatch tables, launch plans (one-step, sweeps, 3-D rolling), stencil tables
 //   libraries.hpp   rocSOLVER / rocBLAS / RCCL via dlopen, background prefetch of the shared objects
@@ -43,6 +44,7 @@
 #include <unordered_map>
 #include <vector>
 
+#include "knobs.hpp"
 #include "host_assembly.hpp"
 #include "kernels.hpp"
 #include "sweep.hpp"
@@ -114,7 +116,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     std::vector<int> ids;
     std::vector<double> distinct;  // n_unique x 32 doubles
     {
-        const char* env = getenv("BODGE_AMD_DICT");
+        const char* env = knob::raw("BODGE_AMD_DICT");
         bool wanted = !(env && env[0] == '0') && nnzb > 0 && ncols <= (1 << 24);
         dict_skipped = (env && env[0] == '0') ? 3 : ncols > (1 << 24) ? 2 : 0;
         if (wanted) {
@@ -278,7 +280,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
             for (int e = 0; e < 16; ++e)
                 if ((e >> 2) != (e & 3) && (distinct[(size_t)32 * d + 2 * e] != 0.0 || distinct[(size_t)32 * d + 2 * e + 1] != 0.0))
                     diagonal[(size_t)d] = 0;
-        if (getenv("BODGE_AMD_NO_DIAGONAL_BLOCKS")) std::fill(diagonal.begin(), diagonal.end(), 0);
+        if (knob::raw("BODGE_AMD_NO_DIAGONAL_BLOCKS")) std::fill(diagonal.begin(), diagonal.end(), 0);
         if (int rc = sys->dict_diagonal.reserve((size_t)sys->n_unique)) return cleanup(rc);
         if (hipMemcpy(sys->dict_diagonal.ptr, diagonal.data(), sizeof(int) * diagonal.size(), hipMemcpyHostToDevice) != hipSuccess)
             return cleanup(fail(BDG_EDEVICE, "upload of the block dictionary failed"));
@@ -592,7 +594,7 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     HIP_TRY(hipSetDevice(sys->device));
     const int64_t n = 4 * sys->nb;
     {
-        const char* forced = getenv("BODGE_AMD_EIGH");
+        const char* forced = knob::raw("BODGE_AMD_EIGH");
         bool own = forced ? std::string(forced) == "jacobi" : n <= kJacobiLimit;
         if (!forced && n > kJacobiLimit && n <= kJacobiWideLimit) {
             // the library solves this size in 0.1-0.2 s once loaded, but from cold storage its 931 MB take
@@ -614,7 +616,7 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     // imag(H) = 0 everywhere (checked at upload): real symmetric drivers, half the memory and a
     // quarter of the arithmetic of the Hermitian ones (BASELINE config 5 names dsyevd).
     bool real_route = sys->is_real;
-    if (const char* env = getenv("BODGE_AMD_EIGH_REAL")) real_route = real_route && atoi(env) != 0;
+    if (const char* env = knob::raw("BODGE_AMD_EIGH_REAL")) real_route = real_route && atoi(env) != 0;
 
     // One attempt with the named rocSOLVER driver: "evd" divide & conquer, "evj" Jacobi, "ev" QL/QR.
     // `copy_bad`: copy the results out even if they contain non-finite values
@@ -706,7 +708,7 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
             return fail(BDG_ELIBRARY, "rocblas_create_handle failed");
         if (api->set_stream(handle, sys->stream) != rocblas_status_success)
             return fail(BDG_ELIBRARY, "rocblas_set_stream failed");
-        const char* forced = getenv("BODGE_AMD_EIGH");
+        const char* forced = knob::raw("BODGE_AMD_EIGH");
         bool nonfinite = false;
         // a forced driver returns whatever it produced (tests look at the defect itself)
         if (forced && *forced && std::string(forced) != "rocsolver") return attempt(forced, true, &nonfinite);

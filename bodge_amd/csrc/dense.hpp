@@ -101,7 +101,7 @@ int eigh_jacobi_typed(bdg_system* sys, double* w_out, double* z_out) {
 
 int eigh_jacobi(bdg_system* sys, double* w_out, double* z_out) {
     bool real_route = sys->is_real;
-    if (const char* env = getenv("BODGE_AMD_EIGH_REAL")) real_route = real_route && atoi(env) != 0;
+    if (const char* env = knob::raw("BODGE_AMD_EIGH_REAL")) real_route = real_route && atoi(env) != 0;
     return real_route ? eigh_jacobi_typed<double>(sys, w_out, z_out) : eigh_jacobi_typed<double2>(sys, w_out, z_out);
 }
 

@@ -24,13 +24,15 @@
 #include <thread>
 #include <vector>
 
+#include "knobs.hpp"
+
 namespace bdg_host {
 
 inline int thread_count(int64_t items, int64_t items_per_thread) {
     int want = (int)std::thread::hardware_concurrency();
     if (want < 1) want = 1;
     want = std::min(want, 32);
-    if (const char* env = std::getenv("BODGE_AMD_HOST_THREADS")) want = std::max(1, std::atoi(env));
+    if (const char* env = knob::raw("BODGE_AMD_HOST_THREADS")) want = std::max(1, std::atoi(env));
     const int64_t useful = std::max<int64_t>(1, items / std::max<int64_t>(1, items_per_thread));
     return (int)std::min<int64_t>(want, useful);
 }

@@ -1,0 +1,41 @@
+// knobs.hpp - every run-time switch of the library, in one place.
+//
+// All of them are environment variables read at the point of use through knob::raw (so a test can
+// change one between two calls); none is needed in normal use - the defaults are the product, the
+// switches exist for the parity tests (every kernel form against every other) and for the A/B
+// measurements behind DESIGN.md's tables.  "=0" disables, any other value enables, unless stated.
+//
+//   kernel choice
+//     BODGE_AMD_KERNEL=generic|pipelined     one-step kernel form (default: by lanes per row)
+//     BODGE_AMD_DICT=0                       no block dictionary: stream the blocks (also disables the stencil kernels)
+//     BODGE_AMD_REAL=0 / BODGE_AMD_PH=0      complex arithmetic although H and the vectors are real / full 16-entry blocks
+//     BODGE_AMD_SWEEP=0|1                    never / whenever possible use the lattice-stencil kernels (default: by size)
+//     BODGE_AMD_SWEEP_STEPS=2|3              steps per sweep (cheb_sweep / cheb_sweep3)
+//     BODGE_AMD_SWEEP_LANES=1|2|4            lanes per site of the sweep kernels
+//     BODGE_AMD_SWEEP_GEN=0                  write the random start block with the fill kernel instead of making it in the first sweep
+//     BODGE_AMD_EIGH=jacobi|rocsolver|...    dense solver route;  BODGE_AMD_EIGH_REAL=0  complex route for a real matrix
+//     BODGE_AMD_NO_DIAGONAL_BLOCKS           withhold the "diagonal as a 4x4 matrix" flag of dictionary blocks (read at upload)
+//   launch shape and memory hints
+//     BODGE_AMD_BLOCKS_PER_CU=n              cap on resident workgroups per CU
+//     BODGE_AMD_SWEEP_SEGMENTS=n             x-segments of the sweep / rolling kernels (default: choose_segments)
+//     BODGE_AMD_SWEEP_ZIGZAG=0               all segments march the same way
+//     BODGE_AMD_ALTERNATE=0                  launches do not alternate their marching direction
+//     BODGE_AMD_SWEEP_STREAM=bits            non-temporal hints of the sweep kernels (1 t_{n-1} loads, 2 stores, 4 t_n loads)
+//     BODGE_AMD_STREAM_VECTORS=bits          the same for the one-step and rolling kernels
+//     BODGE_AMD_L2_BUDGET=bytes              per-XCD budget behind the strip width of the tile order
+//     BODGE_AMD_BATCH=n                      vectors per launch of the one-step kernels (default: batch_width)
+//     BODGE_AMD_NO_BAND                      LDOS / unit starts sweep the whole matrix instead of the growing band
+//     BODGE_AMD_NO_BATCH_PIPELINE            wait for every batch of a call before beginning the next
+//     BODGE_AMD_OVERLAP=0|1                  slab halo exchange on the compute stream / overlapped on a second stream
+//   host side
+//     BODGE_AMD_HOST_THREADS=n               threads of the bdg_host_* passes (default: all cores, at most 32)
+//     BODGE_AMD_NO_PREFETCH                  no background read of the rocSOLVER / RCCL shared objects
+//     BODGE_AMD_TRACE                        timing lines on stderr
+//   (read by the Python side: BODGE_AMD_LIBRARY, BODGE_AMD_DEVICE, BODGE_AMD_HOST_NATIVE, BODGE_AMD_FORCE_COMM)
+#pragma once
+
+#include <cstdlib>
+
+namespace knob {
+inline const char* raw(const char* name) { return std::getenv(name); }
+}  // namespace knob

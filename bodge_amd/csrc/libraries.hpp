@@ -50,7 +50,7 @@ struct FilePrefetch {
         std::lock_guard<std::mutex> guard(lock);
         if (started) return;
         started = true;
-        if (getenv("BODGE_AMD_NO_PREFETCH")) {
+        if (knob::raw("BODGE_AMD_NO_PREFETCH")) {
             done = true;
             return;
         }
@@ -76,7 +76,7 @@ struct FilePrefetch {
         std::unique_lock<std::mutex> guard(lock);
         if (timeout_s < 0) changed.wait(guard, [this] { return done; });
         else changed.wait_for(guard, std::chrono::duration<double>(timeout_s), [this] { return done; });
-        if (done && !reported && getenv("BODGE_AMD_TRACE")) {
+        if (done && !reported && knob::raw("BODGE_AMD_TRACE")) {
             reported = true;
             fprintf(stderr, "[bdg] %s%s read in %.1f s\n", paths[0], paths.size() > 1 ? " ..." : "", seconds);
         }

@@ -144,7 +144,7 @@ constexpr size_t kDictLdsLimit = 32 * 1024;  // bytes of LDS the block table may
 
 // Dictionary kernel if the matrix has few enough distinct blocks for the table to sit in LDS.
 StepKernel dict_kernel(const bdg_system* sys, const ModeInfo& mode, int rl) {
-    const char* env = getenv("BODGE_AMD_DICT");
+    const char* env = knob::raw("BODGE_AMD_DICT");
     if (env && env[0] == '0') return nullptr;
     if (sys->n_unique <= 0 || (size_t)sys->n_unique * mode.stride * sizeof(double2) > kDictLdsLimit)
         return nullptr;
@@ -155,7 +155,7 @@ StepKernel dict_kernel(const bdg_system* sys, const ModeInfo& mode, int rl) {
 }
 
 StepKernel pipelined_kernel(const ModeInfo& mode, int rl, int max_row_blocks, int* maxb_out) {
-    const char* env = getenv("BODGE_AMD_KERNEL");
+    const char* env = knob::raw("BODGE_AMD_KERNEL");
     if (env && std::string(env) == "generic") return nullptr;
     if (max_row_blocks <= 3) { *maxb_out = 3; return pipelined_for<3>(mode, rl); }
     if (max_row_blocks <= 5) { *maxb_out = 5; return pipelined_for<5>(mode, rl); }
@@ -228,7 +228,7 @@ int make_plan(bdg_system* sys, int rl, const ModeInfo& mode, StepPlan* plan, boo
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
         &per_cu, reinterpret_cast<const void*>(plan->kernel), bdg::kBlockThreads, plan->lds_bytes));
     per_cu = std::max(1, std::min(per_cu, 8));
-    if (const char* cap = getenv("BODGE_AMD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(cap));
+    if (const char* cap = knob::raw("BODGE_AMD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(cap));
     int grid = std::min(plan->n_tiles, per_cu * sys->num_cus);
     plan->grid = std::max(8, (grid + 7) / 8 * 8);
     return BDG_OK;
@@ -321,7 +321,7 @@ int prepare_tile_order(bdg_system* sys, int rows_per_tile, int n_tiles, double r
     const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
     if (plane <= 0 || (int64_t)sys->shape[0] * plane != sys->nb) return BDG_OK;
     double budget = 1024.0 * 1024.0;  // bytes of t_n lines an XCD should have to hold between re-uses
-    if (const char* env = getenv("BODGE_AMD_L2_BUDGET")) budget = atof(env);
+    if (const char* env = knob::raw("BODGE_AMD_L2_BUDGET")) budget = atof(env);
     int64_t strip = (int64_t)(budget / (2.0 * row_bytes));
     strip = std::max<int64_t>(rows_per_tile, strip / rows_per_tile * rows_per_tile);
     if (strip >= plane || budget <= 0) return BDG_OK;
@@ -504,11 +504,11 @@ int ensure_stencil(bdg_system* sys, int* kind) {
 // random start vectors (unit vectors use the band-limited one-step sweeps), no per-column scalars.
 int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, int* kind) {
     *kind = 0;
-    const char* env = getenv("BODGE_AMD_SWEEP");
+    const char* env = knob::raw("BODGE_AMD_SWEEP");
     if ((env && env[0] == '0') || !random_start || col_scalars || !sys->peers.empty()) return BDG_OK;
     const bool forced = env && env[0] == '1';
     if (!forced && sys->nb < std::min(kSweepMinSites, kRollMinSites)) return BDG_OK;
-    const char* dict_env = getenv("BODGE_AMD_DICT");
+    const char* dict_env = knob::raw("BODGE_AMD_DICT");
     if (dict_env && dict_env[0] == '0') return BDG_OK;
     if (int rc = ensure_stencil(sys, kind)) return rc;
     if (!forced && sys->nb < (*kind == 2 ? kRollMinSites : kSweepMinSites)) *kind = 0;
@@ -534,7 +534,7 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(plan->kernel),
                                                          bdg::kSweepThreads, plan->lds_bytes));
     per_cu = std::max(1, std::min(per_cu, 2 * bdg::kWavesPerBlock / bdg::kSweepWaves));
-    if (const char* cap = getenv("BODGE_AMD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(cap));
+    if (const char* cap = knob::raw("BODGE_AMD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(cap));
     const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
     bdg::SweepArgs& a = plan->args;
     a = bdg::SweepArgs{};
@@ -549,10 +549,10 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     // one unit (segment x window) per resident wave, segments of at least 8 planes
     const int waves = per_cu * sys->num_cus * bdg::kSweepWaves;
     int n_segs = choose_segments(a.n_cols, a.lx, waves, 2 * depth, 8);
-    if (const char* env = getenv("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
+    if (const char* env = knob::raw("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
     a.n_segs = std::max(1, std::min(n_segs, a.lx / 8));
     a.zigzag = 1;
-    if (const char* env = getenv("BODGE_AMD_SWEEP_ZIGZAG")) a.zigzag = atoi(env) != 0;
+    if (const char* env = knob::raw("BODGE_AMD_SWEEP_ZIGZAG")) a.zigzag = atoi(env) != 0;
     a.wrap_p = sys->stencil_wrap_p ? 1 : 0;
     a.wrap_x = sys->stencil_wrap_x ? 1 : 0;
     const int64_t units = (int64_t)a.n_cols * a.n_segs;
@@ -578,7 +578,7 @@ double sweep_bytes(const bdg_system* sys, const ModeInfo& mode, int lanes) {
 // bytes against 2/3 for 2.  BODGE_AMD_SWEEP_STEPS=2|3 overrides.
 int sweep_depth_for(int lanes) {
     int depth = lanes >= 2 ? 3 : 2;
-    if (const char* env = getenv("BODGE_AMD_SWEEP_STEPS")) {
+    if (const char* env = knob::raw("BODGE_AMD_SWEEP_STEPS")) {
         const int forced = atoi(env);
         if (forced == 2 || (forced == 3 && lanes >= 2)) depth = forced;
     }
@@ -590,7 +590,7 @@ int sweep_depth_for(int lanes) {
 // shorter x-segments.  Measured on 1000x1000, 8 real vectors: 2 lanes 106.6 k vector-steps/s,
 // 4 lanes 99.9 k (profiles/r02_sweep_experiments.log).
 int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane) {
-    if (const char* env = getenv("BODGE_AMD_SWEEP_LANES")) {
+    if (const char* env = knob::raw("BODGE_AMD_SWEEP_LANES")) {
         const int forced = atoi(env);
         if (forced == 1 || forced == 2 || forced == 4) return forced;
     }
@@ -627,7 +627,7 @@ int make_roll_plan(bdg_system* sys, const ModeInfo& mode, RollPlan* plan) {
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(plan->kernel),
                                                          bdg::kBlockThreads, plan->lds_bytes));
     per_cu = std::max(1, std::min(per_cu, 2));
-    if (const char* cap = getenv("BODGE_AMD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(cap));
+    if (const char* cap = knob::raw("BODGE_AMD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(cap));
     const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
     bdg::RollArgs& a = plan->args;
     a = bdg::RollArgs{};
@@ -641,7 +641,7 @@ int make_roll_plan(bdg_system* sys, const ModeInfo& mode, RollPlan* plan) {
     a.n_cols = (int)((plane + bdg::kRollOwned - 1) / bdg::kRollOwned);
     const int waves = per_cu * sys->num_cus * bdg::kWavesPerBlock;
     int n_segs = choose_segments(a.n_cols, a.lx, waves, 2, 4);
-    if (const char* env = getenv("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
+    if (const char* env = knob::raw("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
     a.n_segs = std::max(1, std::min(n_segs, a.lx / 4));
     const int64_t units = (int64_t)a.n_cols * a.n_segs;
     const int grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus,

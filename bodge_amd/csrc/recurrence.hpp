@@ -51,11 +51,11 @@ struct Batch {
         // Real arithmetic applies when H has no imaginary part and the start vectors are real
         // (±1 or unit vectors): every t_n then stays real.  BODGE_AMD_REAL=0 forces complex.
         const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
-        const char* real_env = getenv("BODGE_AMD_REAL");
+        const char* real_env = knob::raw("BODGE_AMD_REAL");
         const bool matrix_real = sys->slab_comm ? sys->slab_all_real : sys->is_real;  // slabs: agreed over all ranks
         real = matrix_real && start_is_real && !(real_env && real_env[0] == '0');
         if (force_real >= 0) real = force_real != 0;
-        const char* ph_env = getenv("BODGE_AMD_PH");
+        const char* ph_env = knob::raw("BODGE_AMD_PH");
         mode = mode_info(real, sys->is_ph && !(ph_env && ph_env[0] == '0'));
         const int per_lane = mode.per_lane;
         // Fewer than 4 lanes per row would put 32-64 rows' blocks into one wave's LDS
@@ -112,9 +112,9 @@ struct Batch {
         // stay resident from one launch to the next and are faster with plain accesses
         // (profiles/r01_stream_probe.log)
         args.stream_vectors = 2 * vec_count * sizeof(double2) > kStreamVectorBytes ? 3 : 0;
-        if (const char* env = std::getenv("BODGE_AMD_STREAM_VECTORS")) args.stream_vectors = std::atoi(env);
+        if (const char* env = knob::raw("BODGE_AMD_STREAM_VECTORS")) args.stream_vectors = std::atoi(env);
         alternate = true;
-        if (const char* env = std::getenv("BODGE_AMD_ALTERNATE")) alternate = std::atoi(env) != 0;
+        if (const char* env = knob::raw("BODGE_AMD_ALTERNATE")) alternate = std::atoi(env) != 0;
         if (int rc = sys->vec_a.reserve(vec_count)) return rc;
         if (int rc = sys->vec_b.reserve(vec_count)) return rc;
         if (sweep) {
@@ -123,7 +123,7 @@ struct Batch {
             spare1 = sys->vec_c.ptr;
             spare2 = sys->vec_d.ptr;
             splan.args.stream = 2 * vec_count * sizeof(double2) > kStreamVectorBytes ? 1 : 0;
-            if (const char* env = std::getenv("BODGE_AMD_SWEEP_STREAM")) splan.args.stream = std::atoi(env);
+            if (const char* env = knob::raw("BODGE_AMD_SWEEP_STREAM")) splan.args.stream = std::atoi(env);
         }
         width = (size_t)2 * rv;
         if (int rc = prepare_overlap()) return rc;
@@ -156,7 +156,7 @@ struct Batch {
         // no fill kernel, and vec_a is only ever a spare buffer.  BODGE_AMD_SWEEP_GEN=0: fill and read.
         gen_start = sweep && splan.depth == 3 && splan.kernel_gen && start.kind == StartKind::Random &&
                     sys->row_offset == 0 && sys->ncols == sys->nb;
-        if (const char* env = getenv("BODGE_AMD_SWEEP_GEN")) gen_start = gen_start && atoi(env) != 0;
+        if (const char* env = knob::raw("BODGE_AMD_SWEEP_GEN")) gen_start = gen_start && atoi(env) != 0;
         if (gen_start) {
             splan.args.gen_seed = start.seed;
             splan.args.gen_first_id = start.first_id;
@@ -175,7 +175,7 @@ struct Batch {
             if (int rc = sys->rows.reserve(64)) return rc;
             HIP_TRY(hipMemcpyAsync(sys->rows.ptr, start.rows, sizeof(int64_t) * n_active,
                                    hipMemcpyHostToDevice, st));
-            if (sys->ncols == sys->nb && !getenv("BODGE_AMD_NO_BAND")) {
+            if (sys->ncols == sys->nb && !knob::raw("BODGE_AMD_NO_BAND")) {
                 band_lo = sys->nb;
                 band_hi = 0;
                 for (int r = 0; r < n_active; ++r) {
@@ -250,7 +250,7 @@ struct Batch {
 
     int prepare_overlap() {
         overlapped = false;
-        const char* env = getenv("BODGE_AMD_OVERLAP");
+        const char* env = knob::raw("BODGE_AMD_OVERLAP");
         if (sys->peers.empty() || !sys->slab_comm || sys->row_needs_halo.empty() || (env && env[0] == '0'))
             return BDG_OK;
         if (sys->split_rows_per_tile != plan.rows_per_tile) {
@@ -569,9 +569,9 @@ StartSpec batch_start(const StartSpec& start, int col) {
 // vector-step at 8 per batch, 21.3 us at 64).  Rule: the largest power of two that keeps one
 // vector buffer within 96 MB, at least one full lane group (8 real / 4 complex), at most 64.
 int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors) {
-    if (const char* env = getenv("BODGE_AMD_BATCH")) return std::clamp(atoi(env), 1, 64);
+    if (const char* env = knob::raw("BODGE_AMD_BATCH")) return std::clamp(atoi(env), 1, 64);
     const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
-    const char* real_env = getenv("BODGE_AMD_REAL");
+    const char* real_env = knob::raw("BODGE_AMD_REAL");
     const bool real = (sys->slab_comm ? sys->slab_all_real : sys->is_real) && start_is_real &&
                       !(real_env && real_env[0] == '0');
     int stencil_kind = 0;
@@ -595,7 +595,7 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
                    double* d_out, double* e_out) {
     if (int rc = check_recurrence_args(sys, scale, n_steps, n_vectors, d_out, e_out)) return rc;
     lanczos_free(sys);
-    const bool trace = getenv("BODGE_AMD_TRACE") != nullptr;
+    const bool trace = knob::raw("BODGE_AMD_TRACE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     const int width = batch_width(sys, start, n_vectors);
@@ -604,7 +604,7 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
     const int n_batches = (n_vectors + width - 1) / width;
     const size_t staged = (size_t)n_batches * std::max(n_steps, 1024) * 2 * (size_t)width;  // doubles of pinned memory
     const bool pipelined = n_batches > 1 && n_batches <= 64 && staged <= ((size_t)4 << 20) && sys->ncols == sys->nb &&
-                           !getenv("BODGE_AMD_NO_BATCH_PIPELINE");
+                           !knob::raw("BODGE_AMD_NO_BATCH_PIPELINE");
     std::vector<Batch> queued(pipelined ? (size_t)n_batches : 0);
     size_t stride0 = 0;
     for (int col = 0, index = 0; col < n_vectors; col += width, ++index) {
@@ -673,7 +673,7 @@ int run_group(bdg_group* group, double scale, int n_steps, int n_vectors, StartS
     }
     // (storage packing is per member: it changes what a member reads, not what it exchanges)
     const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
-    const char* real_env = getenv("BODGE_AMD_REAL");
+    const char* real_env = knob::raw("BODGE_AMD_REAL");
     const int force_real = (all_real && start_is_real && !(real_env && real_env[0] == '0')) ? 1 : 0;
 
     for (int col = 0; col < n_vectors; col += 64) {
