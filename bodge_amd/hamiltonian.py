@@ -238,9 +238,29 @@ class Hamiltonian:
         return found
 
     def _dict_to_arrays(self, table: TermTable):
+        """The individually keyed entries of a `with` block as (rows, cols, values) arrays."""
         if not table:
             return None
         lat = self.lattice
+        if type(lat) is CubicLattice:
+            # reference-style scripts assign one term per site / bond in a Python loop (ref :70-89 and
+            # README.md:73-86); turning the keys into site indices must not cost another loop with a
+            # type-checked `lattice[coord]` per key
+            try:
+                keys = np.array(list(table.keys()))
+                vals = np.array(list(table.values()), dtype=np.complex128)
+            except (TypeError, ValueError):
+                keys = vals = None
+            # (anything but integer coordinates and 2x2 values goes the per-key way below and meets its checks)
+            if (keys is not None and keys.dtype.kind in "iu" and keys.shape == (len(table), 2, 3)
+                    and vals.shape == (len(table), 2, 2)):
+                keys = keys.astype(np.int64, copy=False)
+                outside = (keys < 0) | (keys >= np.asarray(lat.shape, dtype=np.int64))
+                if outside.any():
+                    coord = keys.reshape(-1, 3)[np.flatnonzero(outside.reshape(-1, 3).any(axis=1))[0]]
+                    raise ValueError(f"Coordinate {tuple(int(v) for v in coord)} out of bounds")
+                flat = lat._flatten(keys)
+                return flat[:, 0].copy(), flat[:, 1].copy(), vals
         rows = np.fromiter((lat[i] for i, _ in table.keys()), dtype=np.int64, count=len(table))
         cols = np.fromiter((lat[j] for _, j in table.keys()), dtype=np.int64, count=len(table))
         vals = np.empty((len(table), 2, 2), dtype=np.complex128)

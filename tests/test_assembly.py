@@ -426,3 +426,44 @@ def test_long_block_rows_sum_like_numpy(api, monkeypatch):
         assert chebyshev.spectral_bound(indptr, data, pad=1.0) == bound.value  # (default: the library's scan)
         # (general complex entries: numpy's vectorised |z| and libm's hypot differ in the last bit)
         assert bound.value == expected if real else abs(bound.value - expected) <= 4e-16 * expected
+
+
+def test_reference_style_loops_take_the_array_route_and_a_subclass_the_per_key_route(api):
+    """`H[i, j] = ...` in Python loops (the reference's way, ref README.md:73-86): for a CubicLattice
+    the keys become site indices in one array operation, for any other Lattice one `lattice[coord]`
+    at a time - and the skeleton is written down for the one, sorted from the pair list for the other.
+    Same matrix either way; errors of the keyed route unchanged."""
+    class Relabelled(CubicLattice):  # not `type(...) is CubicLattice`: generic skeleton, per-key conversion
+        pass
+
+    rng = np.random.default_rng(5)
+    built = []
+    for cls in (CubicLattice, Relabelled):
+        lattice = cls((5, 4, 3))
+        system = Hamiltonian(lattice)
+        values = np.random.default_rng(5)
+        with system as (H, Δ):
+            for i in lattice.sites():
+                H[i, i] = values.normal() * σ0 + values.normal() * σ3
+                Δ[i, i] = values.normal() * jσ2
+            for i, j in lattice.bonds():
+                H[i, j] = -1.0 * σ0 + (0.3j if i < j else -0.3j) * σ2
+            for i, j in lattice.edges(axis=0):
+                H[i, j] = -0.5 * σ0
+        built.append(system)
+    a, b = built
+    assert np.array_equal(a._matrix.indptr, b._matrix.indptr) and np.array_equal(a._matrix.indices, b._matrix.indices)
+    assert np.array_equal(_bits(a._data), _bits(b._data))
+    for bad_key, error in [(((0, 0, 0), (5, 0, 0)), ValueError), (((0, 0, -1), (0, 0, 0)), ValueError),
+                           (((0, 0, 0), (2, 2, 1)), IndexError)]:
+        for system in built:
+            with raises(error):
+                with system as (H, Δ):
+                    H[bad_key] = σ0
+    for system in built:
+        with raises(Exception):
+            with system as (H, Δ):
+                H[(0.5, 0, 0), (0, 0, 0)] = σ0
+        with raises(ValueError):
+            with system as (H, Δ):
+                H[(0, 0, 0), (0, 0, 0)] = np.eye(3)

@@ -337,6 +337,29 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
     assert np.abs(general[0] - flagged[0]).max() <= 1e-13 * n and np.abs(general[1] - flagged[1]).max() <= 1e-13 * n
 
 
+@pytest.mark.parametrize("sweep", ["0", "1"])
+def test_batches_of_one_call_enqueued_back_to_back_change_no_bit(api, solver_cls, monkeypatch, sweep):
+    """A call with more vectors than one launch carries is cut into batches; whole matrices enqueue
+    them back to back (own timing events, own piece of the pinned result buffer) and wait once.
+    Same numbers as one batch at a time, for random and for unit starts, ragged last batch included."""
+    system = _sweep_system(api, (64, 48, 1), "swave")
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    rows = np.arange(0, 4 * 64 * 48, 97)[:70]  # 70 unit vectors: two batches of the one-step kernels
+    monkeypatch.setenv("BODGE_AMD_SWEEP", sweep)
+    monkeypatch.setenv("BODGE_AMD_BATCH", "32")
+    with solver_cls.from_hamiltonian(system) as dev:
+        queued = dev.dots_random(scale, 7, 27, seed=3), dev.dots_unit(scale, 6, rows)
+        launches = dev.perf()["launches"]
+        monkeypatch.setenv("BODGE_AMD_NO_BATCH_PIPELINE", "1")
+        single = dev.dots_random(scale, 7, 27, seed=3), dev.dots_unit(scale, 6, rows)
+        assert dev.perf()["launches"] == launches
+    for a, b in zip(queued, single):
+        assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
+    ref = cheb_ref.recurrence_dots(bsr, scale, 14, cheb_ref.random_block(bsr.shape[0], 3, range(27), cheb_ref.VEC_RADEMACHER))
+    assert np.abs(queued[0][0] - ref[0]).max() <= 1e-12 * bsr.shape[0] and np.abs(queued[0][1] - ref[1]).max() <= 1e-12 * bsr.shape[0]
+
+
 @pytest.mark.parametrize("name,n_vectors,kind", [
     ("random357", 6, cheb_ref.VEC_Z4),          # complex blocks, periodic
     ("complex235", 3, cheb_ref.VEC_RADEMACHER),  # complex H with real start vectors
