@@ -69,6 +69,9 @@ struct Batch {
         int stencil_kind = 0;
         if (sys->lanes_override == 0 && rl == 4)
             if (int rc = sweep_wanted(sys, start.kind == StartKind::Random, col_scalars, &stencil_kind)) return rc;
+        // (the stencil kernels keep the whole block table in LDS; a matrix with many distinct blocks in a
+        // wide arithmetic mode can exceed that: it takes the one-step kernels, which then stream its blocks)
+        if ((size_t)sys->n_unique * mode.stride * sizeof(double2) > kDictLdsLimit) stencil_kind = 0;
         if (stencil_kind == 1) {
             const int lanes = sweep_lanes_for(sys, n_active, per_lane);
             if (n_active <= lanes * per_lane) {

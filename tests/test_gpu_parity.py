@@ -337,6 +337,29 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
     assert np.abs(general[0] - flagged[0]).max() <= 1e-13 * n and np.abs(general[1] - flagged[1]).max() <= 1e-13 * n
 
 
+def test_stencil_kernels_step_aside_when_the_block_table_exceeds_lds(api, solver_cls, monkeypatch, block_storage):
+    """192 sites with random on-site terms: 193 distinct blocks - a dictionary, but in complex arithmetic
+    its table (13 LDS slots per block) is beyond the 32 KB the kernels give it.  Asked for the stencil
+    kernels, such a matrix must take the one-step kernels (found by scratch/fuzz_sweep.py: it raised)."""
+    rng = np.random.default_rng(11)
+    lattice = api.CubicLattice((8, 24, 1))
+    system = api.Hamiltonian(lattice)
+    with system as (H, Δ):
+        H.set_sites(rng.normal(size=(lattice.size, 1, 1)) * api.σ0 + 0.1 * rng.normal(size=(lattice.size, 1, 1)) * api.σ3)
+        Δ.set_sites(-0.1 * api.jσ2)
+        H.set_bonds(-1.0 * api.σ0)
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    n = bsr.shape[0]
+    monkeypatch.setenv("BODGE_AMD_SWEEP", "1")
+    with solver_cls.from_hamiltonian(system) as dev:
+        for kind, expect_sweep in ((cheb_ref.VEC_Z4, False), (cheb_ref.VEC_RADEMACHER, block_storage == "dictionary")):
+            got = dev.dots_random(scale, 7, 5, seed=2, kind=kind)
+            assert (dev.perf()["steps_per_launch"] == 3) == expect_sweep
+            ref = cheb_ref.recurrence_dots(bsr, scale, 14, cheb_ref.random_block(n, 2, range(5), kind))
+            assert np.abs(got[0] - ref[0]).max() <= 1e-12 * n and np.abs(got[1] - ref[1]).max() <= 1e-12 * n
+
+
 @pytest.mark.parametrize("sweep", ["0", "1"])
 def test_batches_of_one_call_enqueued_back_to_back_change_no_bit(api, solver_cls, monkeypatch, sweep):
     """A call with more vectors than one launch carries is cut into batches; whole matrices enqueue
