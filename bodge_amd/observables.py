@@ -19,6 +19,8 @@ DENSE_AUTO_LIMIT_T0) and the Chebyshev expansion (`_auto_method`).
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import chebyshev as cheb
@@ -424,8 +426,19 @@ def diagonalize(system, format: str = "reshape"):
 
 
 # --------------------------------------------------- gap beyond dense reach
+def _krylov_length(beta_column: np.ndarray, scale2: float) -> int:
+    """Number of Lanczos steps of one start vector that are meaningful.  When the Krylov space of
+    the vector is exhausted (a matrix with few distinct eigenvalues: small, or highly symmetric)
+    β drops to round-off level and everything the process produces afterwards is noise - Ritz
+    values below the spectrum included.  The tridiagonal matrix is cut at the first such β: its
+    eigenvalues are then exact eigenvalues of H² (the space is invariant)."""
+    tiny = np.flatnonzero(beta_column <= 1e-7 * scale2)
+    return int(tiny[0]) + 1 if tiny.size else len(beta_column)
+
+
+
 def lowest_eigenvalues(system, k: int = 1, *, tol: float = 1e-6, vectors: int = 4, seed: int = 0,
-                       max_iter: int = 50000, check_every: int = 250) -> np.ndarray:
+                       max_iter: int = 50000, check_every: int = 250, method: str = "auto") -> np.ndarray:
     """The k smallest *distinct* positive eigenvalues of H, ascending, for systems where the dense
     `diagonalize()` is out of reach (the reference uses `min(E)` as a gap probe,
     e.g. tests/test_physics.py:43-56, :370).
@@ -441,6 +454,8 @@ def lowest_eigenvalues(system, k: int = 1, *, tol: float = 1e-6, vectors: int = 
     warning is issued and the current estimate returned.
     Degenerate eigenvalues (e.g. spin-degenerate pairs) are reported once; repeated copies that
     plain Lanczos produces after convergence are merged the same way.
+    method="auto" answers matrices up to 4N = 2048 from the dense solver instead (exact; a Krylov
+    process exhausts so small a space); method="lanczos" always runs the process.
     """
     import warnings
 
@@ -448,6 +463,16 @@ def lowest_eigenvalues(system, k: int = 1, *, tol: float = 1e-6, vectors: int = 
 
     if k < 1:
         raise ValueError("k must be at least 1")
+    if method not in ("auto", "lanczos"):
+        raise ValueError("method must be 'auto' or 'lanczos'")
+    if method == "auto" and system.shape[0] <= DENSE_AUTO_LIMIT:
+        # a Krylov process on a matrix this small exhausts its space within a few checks and breaks
+        # down; the library-free dense solve takes a fraction of a second and is exact
+        values = diagonalize(system, format="raw")[0]
+        distinct = values[np.concatenate([[True], np.diff(values) > 1e-9 * max(1.0, float(values[-1]))])] if len(values) else values
+        if len(distinct) < k:
+            warnings.warn(f"lowest_eigenvalues: the matrix has only {len(distinct)} distinct positive eigenvalues", RuntimeWarning)
+        return distinct[:k]
     solver = system._solver()
     solver.lanczos_begin(vectors, seed=seed, max_iter=max_iter)
     alpha = np.zeros((0, vectors))
@@ -459,12 +484,13 @@ def lowest_eigenvalues(system, k: int = 1, *, tol: float = 1e-6, vectors: int = 
         alpha, beta = np.vstack([alpha, a]), np.vstack([beta, b])
         m = alpha.shape[0]
         if scale2 is None:
-            scale2 = float(alpha.max())  # ~ |H|^2, sets the merge resolution
+            scale2 = float(alpha[: min(m, 8)].max())  # ~ |H|^2, sets the merge resolution
         estimates = []
         for c in range(vectors):
-            want = min(m, 4 * k + 8)
-            theta = eigh_tridiagonal(alpha[:, c], beta[: m - 1, c], select="i", select_range=(0, want - 1),
-                                     eigvals_only=True)
+            mc = _krylov_length(beta[:, c], scale2)
+            want = min(mc, 4 * k + 8)
+            theta = eigh_tridiagonal(alpha[:mc, c], beta[: mc - 1, c], select="i", select_range=(0, want - 1),
+                                     eigvals_only=True) if mc > 1 else alpha[:1, c]
             eps = np.sqrt(np.clip(theta, 0.0, None))
             distinct = [eps[0]]
             for value in eps[1:]:
@@ -486,7 +512,7 @@ def lowest_eigenvalues(system, k: int = 1, *, tol: float = 1e-6, vectors: int = 
 
 
 def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8, seed: int = 0,
-                      max_iter: int = 20000, check_every: int = 50, format: str = "reshape"):
+                      max_iter: int = 20000, check_every: int = 50, format: str = "reshape", method: str = "auto"):
     """The k lowest positive eigenvalues of H **with their multiplicities** and orthonormal
     eigenvectors, for systems where the dense `diagonalize()` is out of reach: what
     `E, v = system.diagonalize()` followed by `E[:k], v[:k]` gives the reference's callers
@@ -505,6 +531,8 @@ def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8
     eigenspace (up to `vectors` dimensions): their Gram matrix gives the multiplicity, and a
     Rayleigh-Ritz step with H inside that span the final pairs.  Residuals ‖Hv − εv‖ come out at
     about `tol`; eigenvalues, being Rayleigh quotients, at about tol².
+    method="auto" answers matrices up to 4N = 2048 from `diagonalize()` itself; method="lanczos"
+    always runs the two passes.
     """
     import warnings
 
@@ -514,6 +542,16 @@ def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8
         raise ValueError("k must be at least 1")
     if format not in ("raw", "reshape"):
         raise RuntimeError(f"Eigenstate format '{format}' is not yet supported.")
+    if method not in ("auto", "lanczos"):
+        raise ValueError("method must be 'auto' or 'lanczos'")
+    if method == "auto" and system.shape[0] <= DENSE_AUTO_LIMIT:
+        # small matrices: the dense solve is exact and cheaper than a Krylov process that would
+        # exhaust its space (found by scratch/fuzz_api.py on a 72x72 matrix)
+        values, states = diagonalize(system, format="raw")
+        if len(values) < k:
+            raise RuntimeError(f"lowest_eigenpairs: the matrix has only {len(values)} positive eigenvalues, {k} asked for")
+        values, states = values[:k], np.asarray(states)[:, :k]
+        return (values, states) if format == "raw" else (values, states.T.reshape(k, -1, 4))
     solver = system._solver()
     dim = system.shape[0]
     levels = k  # k distinct levels hold at least k states
@@ -529,19 +567,23 @@ def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8
         a, b = solver.lanczos_advance(min(check_every, max_iter - alpha.shape[0]))
         alpha, beta = np.vstack([alpha, a]), np.vstack([beta, b])
         m = alpha.shape[0]
-        scale2 = float(alpha.max())  # ~ |H|^2
+        scale2 = float(alpha[: min(m, 8)].max())  # ~ |H|^2 (early rows: noise after a breakdown can be large)
         same = 1e-9 * scale2         # two Ritz values this close are one level (or a ghost of it)
-        want = min(m, 4 * levels + 8)
         pending = []                 # per start vector: lowest Ritz value that is neither converged nor a ghost
         for c in range(vectors):
-            theta, s = eigh_tridiagonal(alpha[:, c], beta[: m - 1, c], select="i", select_range=(0, want - 1))
-            residual = beta[m - 1, c] * np.abs(s[-1, :])
+            mc = _krylov_length(beta[:, c], scale2)  # (< m: this vector's Krylov space is exhausted, its Ritz pairs exact)
+            want = min(mc, 4 * levels + 8)
+            if mc > 1:
+                theta, s = eigh_tridiagonal(alpha[:mc, c], beta[: mc - 1, c], select="i", select_range=(0, want - 1))
+            else:
+                theta, s = alpha[:1, c].copy(), np.ones((1, 1))
+            residual = (beta[mc - 1, c] if mc == m else 0.0) * np.abs(s[-1, :])
             lowest_open = np.inf
             for idx in range(want):
                 known = any(abs(theta[idx] - t) <= same for t, _, _ in records[c])
                 eps = np.sqrt(max(theta[idx], 0.0))
                 if not known and residual[idx] <= tol * max(eps, 1e-6 * np.sqrt(scale2)):
-                    records[c].append((float(theta[idx]), m, s[:, idx].copy()))
+                    records[c].append((float(theta[idx]), mc, s[:, idx].copy()))
                     known = True
                 if not known:
                     lowest_open = min(lowest_open, theta[idx])
@@ -561,7 +603,7 @@ def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8
     if targets is None:
         merged = []
         for t in sorted(t for rec in records for t, _, _ in rec):
-            if not merged or t - merged[-1] > 1e-9 * float(alpha.max()):
+            if not merged or t - merged[-1] > 1e-9 * scale2:
                 merged.append(t)
         targets = merged[:levels]
         if not targets:
@@ -569,7 +611,7 @@ def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8
         warnings.warn(f"lowest_eigenpairs: only {len(targets)} of {levels} levels converged to {tol:g} in every start "
                       f"vector after {alpha.shape[0]} iterations; returning what was found", RuntimeWarning)
     levels = len(targets)
-    same = 1e-9 * float(alpha.max())
+    same = 1e-9 * scale2
     chosen = [[next(((m, s) for t, m, s in rec if abs(t - w) <= same), None) for w in targets] for rec in records]
     n_iter = max(entry[0] for row in chosen for entry in row if entry is not None)
     coef = np.zeros((n_iter, levels, vectors))
@@ -586,7 +628,11 @@ def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8
         # candidates in the +eps eigenspace of H, then an orthonormal basis of what they span
         have = [c for c in range(vectors) if chosen[c][l] is not None]
         cand = np.stack([solver.spmv(ritz[l, c]) + eps * ritz[l, c] for c in have])
-        cand /= np.maximum(np.linalg.norm(cand, axis=1, keepdims=True), 1e-300)
+        # a Ritz vector may happen to lie (almost) wholly in the -eps eigenspace: its projection is
+        # round-off noise and must not be blown up to a unit vector (scratch/fuzz_api.py found one)
+        length = np.linalg.norm(cand, axis=1)
+        cand = cand[length > 1e-6 * length.max()]
+        cand /= np.linalg.norm(cand, axis=1, keepdims=True)
         gram = cand.conj() @ cand.T
         weight, mix = np.linalg.eigh(gram)
         keep = weight > 1e-4 * weight[-1]
