@@ -24,7 +24,9 @@ def check(ok, what, case, detail):
 
 for case in range(n_cases):
     dims = rng.choice([1, 2, 3], p=[0.2, 0.5, 0.3])
-    if dims == 1:
+    if os.environ.get("FUZZ_SIZE") == "mid":  # 4N between 2300 and 4000: beyond the small-matrix shortcuts
+        shape = (int(rng.integers(24, 32)), int(rng.integers(24, 32)), 1) if dims != 3 else (int(rng.integers(8, 11)), int(rng.integers(8, 11)), int(rng.integers(8, 10)))
+    elif dims == 1:
         shape = (int(rng.integers(3, 120)), 1, 1)
     elif dims == 2:
         shape = (int(rng.integers(2, 16)), int(rng.integers(2, 16)), 1)
@@ -95,7 +97,7 @@ for case in range(n_cases):
         err = max(np.abs(parts[0] - whole[0]).max(), np.abs(parts[1] - whole[1]).max()) / n
         check(err <= 1e-12, "slab group", case, f"{tag} slabs={n_slabs} err {err}")
     # lowest eigenpairs (Lanczos on H^2, two passes) against the dense spectrum; gapped, PH-symmetric systems
-    if os.environ.get("FUZZ_LANCZOS", "1") == "1" and system.has_symmetric_spectrum(1e-12) and 40 <= n <= 1600 and len(wpos) >= 6 and wpos[0] > 1e-3:
+    if os.environ.get("FUZZ_LANCZOS", "1") == "1" and system.has_symmetric_spectrum(1e-12) and 40 <= n <= 4200 and len(wpos) >= 6 and wpos[0] > 1e-3:
         k = int(rng.integers(1, 5))
         try:
             vals, vecs = system.lowest_eigenpairs(k, format="raw", method="lanczos" if n > 300 else "auto")
