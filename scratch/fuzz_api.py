@@ -83,6 +83,15 @@ for case in range(n_cases):
         ref = dense_ref.ldos(system.matrix("csc"), system.lattice[site], energies)
         got = system.ldos(site, energies)
         check(np.allclose(got, ref, rtol=1e-8, atol=1e-10), "ldos", case, f"{tag} site {site} max diff {np.abs(got - ref).max()}")
+        other = tuple(int(rng.integers(0, s)) for s in shape)
+        both = system.ldos([site, other, site], energies)  # several sites share the recurrence launches
+        alone = system.ldos(other, energies)
+        check(both.shape == (3, len(energies)) and np.allclose(both[0], got, rtol=1e-10, atol=1e-12) and np.allclose(both[2], got, rtol=1e-10, atol=1e-12)
+              and np.allclose(both[1], alone, rtol=1e-10, atol=1e-12), "ldos multi-site", case, f"{tag} {site} {other}")
+        os.environ["BODGE_AMD_NO_BAND"] = "1"
+        whole = system.ldos(site, energies)
+        del os.environ["BODGE_AMD_NO_BAND"]
+        check(np.allclose(whole, got, rtol=1e-10, atol=1e-12), "ldos band-limited vs whole", case, f"{tag} {np.abs(whole - got).max()}")
     # slab group vs whole
     if shape[0] >= 4:
         n_slabs = int(rng.integers(2, min(4, shape[0] // 2) + 1))

@@ -15,9 +15,11 @@ t_start = time.time()
 for case in range(n_cases):
     three_d = rng.random() < 0.25
     if three_d:
-        shape = (int(rng.integers(8, 14)), int(rng.integers(5, 9)), int(rng.integers(5, 9)))
+        big3 = os.environ.get("FUZZ_SIZE") == "large"
+        shape = (int(rng.integers(8, 30 if big3 else 14)), int(rng.integers(5, 30 if big3 else 9)), int(rng.integers(5, 30 if big3 else 9)))
     else:
-        shape = (int(rng.integers(8, 40)), int(rng.integers(24, 90)), 1)
+        big = os.environ.get("FUZZ_SIZE") == "large"
+        shape = (int(rng.integers(8, 120 if big else 40)), int(rng.integers(24, 500 if big else 90)), 1)
         if rng.random() < 0.3:
             shape = (shape[0], 1, shape[1])
     lat = ba.CubicLattice(shape)
