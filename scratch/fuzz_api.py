@@ -68,6 +68,19 @@ for case in range(n_cases):
         ref = dense_ref.free_energy(dense, T)
         got = system.free_energy(T, method="chebyshev", trace="exact")
         check(abs(got - ref) <= 1e-9 * max(1.0, abs(ref)), "free_energy chebyshev", case, f"{tag} T={T} {got} vs {ref}")
+    # stochastic trace on the oracle's vectors (same counter-based generator), both vector kinds
+    if system.has_symmetric_spectrum(1e-12):
+        from bodge_amd.observables import free_energy_stochastic
+        bsr = system.matrix("bsr")
+        scale = cheb_ref.spectral_bound(bsr)
+        R, M, sd = int(rng.integers(1, 40)), 2 * int(rng.integers(4, 40)), int(rng.integers(0, 1000))
+        for vk, ok_kind in (("rademacher", cheb_ref.VEC_RADEMACHER), ("z4", cheb_ref.VEC_Z4)):
+            ref = cheb_ref.free_energy_stochastic(bsr, 0.7, M, R, seed=sd, kind=ok_kind, scale=scale)
+            got, _ = free_energy_stochastic(system, 0.7, moments=M, vectors=R, seed=sd, vector_kind=vk, scale=scale)
+            check(abs(got - ref) <= 1e-10 * max(1.0, abs(ref)), "free_energy stochastic", case, f"{tag} {vk} R={R} M={M} seed={sd}: {got} vs {ref}")
+        two = system.free_energy(0.7, method="chebyshev", trace="stochastic", moments=M, vectors=R, seed=sd, devices=[0, 0])
+        one = system.free_energy(0.7, method="chebyshev", trace="stochastic", moments=M, vectors=R, seed=sd)
+        check(abs(one - two) <= 1e-11 * max(1.0, abs(one)), "stochastic devices=[0,0]", case, f"{tag} {one} vs {two}")
     # diagonalize
     E, X = system.diagonalize(format="raw")
     w = np.linalg.eigvalsh(dense)
