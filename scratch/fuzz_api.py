@@ -81,6 +81,17 @@ for case in range(n_cases):
         two = system.free_energy(0.7, method="chebyshev", trace="stochastic", moments=M, vectors=R, seed=sd, devices=[0, 0])
         one = system.free_energy(0.7, method="chebyshev", trace="stochastic", moments=M, vectors=R, seed=sd)
         check(abs(one - two) <= 1e-11 * max(1.0, abs(one)), "stochastic devices=[0,0]", case, f"{tag} {one} vs {two}")
+    # unit start vectors (the LDOS / exact-trace building block): random rows with repeats, several batches
+    if n <= 2500:
+        bsr_u = system.matrix("bsr")
+        scale_u = cheb_ref.spectral_bound(bsr_u)
+        rows = rng.integers(0, n, size=int(rng.integers(1, 150)))
+        steps_u = int(rng.integers(1, 12))
+        with DeviceSolver.from_hamiltonian(system) as dev:
+            got_u = dev.dots_unit(scale_u, steps_u, rows)
+        ref_u = cheb_ref.recurrence_dots(bsr_u, scale_u, 2 * steps_u, cheb_ref.unit_block(n, rows))
+        err_u = max(np.abs(got_u[0] - ref_u[0]).max(), np.abs(got_u[1] - ref_u[1]).max())
+        check(err_u <= 1e-12, "dots_unit", case, f"{tag} rows={len(rows)} steps={steps_u} err {err_u}")
     # diagonalize
     E, X = system.diagonalize(format="raw")
     w = np.linalg.eigvalsh(dense)
