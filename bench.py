@@ -302,7 +302,7 @@ def main():
         if pf["steps_per_launch"] == 2:
             return f"cheb_sweep<{mode},{pf['lanes_per_row']}>"
         if pf["rolling"]:
-            return f"cheb_roll3<{mode}>"
+            return f"cheb_roll3<{mode},{pf['lanes_per_row']}>"
         family = "cheb_step_dict" if pf["dict_blocks"] else "cheb_step_pipelined" if pf["pipelined"] else "cheb_step"
         return f"{family}<{mode},{pf['lanes_per_row']}>"
 

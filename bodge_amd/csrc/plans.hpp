@@ -602,24 +602,47 @@ int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane) {
 // ---- 3-D: one step per launch with the x-neighbours in registers (cheb_roll3)
 using RollKernel = void (*)(bdg::RollArgs);
 
-RollKernel roll_kernel(const ModeInfo& mode) {
+template <typename Mode>
+RollKernel roll_kernel_for(int lanes) {
+    return lanes == 2 ? bdg::cheb_roll3<Mode, 2> : lanes == 4 ? bdg::cheb_roll3<Mode, 4> : nullptr;
+}
+
+RollKernel roll_kernel(const ModeInfo& mode, int lanes) {
     switch (mode.id) {
-        case 1: return bdg::cheb_roll3<RealMode>;
-        case 2: return bdg::cheb_roll3<ComplexPHMode>;
-        case 3: return bdg::cheb_roll3<RealPHMode>;
+        case 1: return roll_kernel_for<RealMode>(lanes);
+        case 2: return roll_kernel_for<ComplexPHMode>(lanes);
+        case 3: return roll_kernel_for<RealPHMode>(lanes);
     }
-    return bdg::cheb_roll3<ComplexMode>;
+    return roll_kernel_for<ComplexMode>(lanes);
+}
+
+// Lanes per site of the rolling kernel: 4 (8 real vectors per launch, windows of 14 owned positions
+// between two ghost slots), or 2 when the batch has no more vectors than two lanes carry (4 real /
+// 2 complex: windows of 30 positions, and the launch no longer moves 8 vectors' worth of bytes
+// for 4).  Measured on 100^3: 76.6 us per 4 vectors against 156.9 us per 8 - 2 lanes are 2 % faster
+// per vector, but their L2-miss traffic is 1.27 x the algorithmic bytes against 1.08 x (shorter
+// x-segments, more segment-end planes), so wide batches stay with 4.  BODGE_AMD_SWEEP_LANES overrides.
+int roll_lanes_for(const bdg_system* sys, int n_vectors, int per_lane) {
+    int lanes = n_vectors <= 2 * per_lane ? 2 : bdg::kSweepLanes;
+    if (const char* env = knob::raw("BODGE_AMD_SWEEP_LANES")) {
+        const int want = atoi(env);
+        if (want == 2 || want == 4) lanes = want;
+    }
+    return lanes;
 }
 
 struct RollPlan {
     RollKernel kernel = nullptr;
+    int lanes = bdg::kSweepLanes;
     int grid = 0;
     size_t lds_bytes = 0;
     bdg::RollArgs args{};
 };
 
-int make_roll_plan(bdg_system* sys, const ModeInfo& mode, RollPlan* plan) {
-    plan->kernel = roll_kernel(mode);
+int make_roll_plan(bdg_system* sys, const ModeInfo& mode, int lanes, RollPlan* plan) {
+    plan->lanes = lanes;
+    plan->kernel = roll_kernel(mode, lanes);
+    if (!plan->kernel) return fail(BDG_EINVAL, "the rolling kernel has 2 or 4 lanes per site, not %d", lanes);
     const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
     if (table > kDictLdsLimit) return fail(BDG_EINVAL, "block table too large for the rolling kernel");
     plan->lds_bytes = table + (size_t)bdg::kWavesPerBlock * bdg::kWave * 4 * sizeof(double2);
@@ -638,7 +661,7 @@ int make_roll_plan(bdg_system* sys, const ModeInfo& mode, RollPlan* plan) {
     a.plane = (int)plane;
     a.lz = sys->shape[2];
     a.lx = sys->shape[0];
-    a.n_cols = (int)((plane + bdg::kRollOwned - 1) / bdg::kRollOwned);
+    a.n_cols = (int)((plane + bdg::roll_owned(lanes) - 1) / bdg::roll_owned(lanes));
     const int waves = per_cu * sys->num_cus * bdg::kWavesPerBlock;
     int n_segs = choose_segments(a.n_cols, a.lx, waves, 2, 4);
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
@@ -651,9 +674,9 @@ int make_roll_plan(bdg_system* sys, const ModeInfo& mode, RollPlan* plan) {
 }
 
 // Algorithmic bytes of one launch of the rolling kernel: stencil word + three passes per site.
-double roll_bytes(const bdg_system* sys, const ModeInfo& mode) {
+double roll_bytes(const bdg_system* sys, const ModeInfo& mode, int lanes) {
     return 8.0 * (double)sys->nb + (mode.block_bytes - 4.0) * sys->n_unique +
-           3.0 * (4.0 * bdg::kSweepLanes * sizeof(double2)) * (double)sys->nb;
+           3.0 * (4.0 * lanes * sizeof(double2)) * (double)sys->nb;
 }
 
 enum class StartKind { Random, Unit };

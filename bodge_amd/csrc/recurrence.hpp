@@ -79,7 +79,11 @@ struct Batch {
                 rl = lanes;
             }
         } else if (stencil_kind == 2) {
-            roll = true;
+            const int lanes = roll_lanes_for(sys, n_active, per_lane);
+            if (n_active <= lanes * per_lane) {
+                roll = true;
+                rl = lanes;
+            }
         }
         rv = rl * per_lane;  // vector columns in the buffers
         if (sys->slab_comm && sys->slab_comm->n_ranks > 1) {
@@ -99,12 +103,17 @@ struct Batch {
             plan.dictionary = true;
             args = bdg::StepArgs{};
             if (int rc = make_sweep_plan(sys, mode, rl, sweep_depth_for(rl), &splan)) return rc;
+        } else if (roll) {
+            // (as for the sweeps: no one-step plan; the table was seen to fit its LDS budget above)
+            plan = StepPlan{};
+            plan.rl = rl;
+            plan.mode = mode;
+            plan.dictionary = true;
+            args = bdg::StepArgs{};
+            if (int rc = make_roll_plan(sys, mode, rl, &rplan)) return rc;
         } else {
             if (int rc = make_plan(sys, rl, mode, &plan, col_scalars)) return rc;
             if (int rc = matrix_args(sys, plan, &args)) return rc;
-            if (roll && !plan.dictionary) roll = false;
-            if (roll)
-                if (int rc = make_roll_plan(sys, mode, &rplan)) return rc;
         }
         launch_grid = sweep ? splan.grid : roll ? rplan.grid : plan.grid;
         n_launches = 0;
@@ -200,7 +209,7 @@ struct Batch {
         HIP_TRY(hipGetLastError());
 
         // bytes of t_n per block row that neighbouring rows re-read: 4 entries per vector
-        if (!sweep)
+        if (!sweep && !roll)
             if (int rc = prepare_tile_order(sys, plan.rows_per_tile, plan.n_tiles,
                                             (real ? 32.0 : 64.0) * rv, &args.tile_order, &strip_rows))
                 return rc;
@@ -531,7 +540,7 @@ struct Batch {
         p.launches += sweep ? n_launches : n_steps;
         p.vector_steps += (int64_t)n_steps * n_active;
         p.bytes_per_launch = sweep  ? sweep_bytes(sys, mode, rl)
-                             : roll ? roll_bytes(sys, mode)
+                             : roll ? roll_bytes(sys, mode, rl)
                                     : algorithmic_bytes(sys, rv, mode, plan.dictionary);
         p.steps_per_launch = sweep ? splan.depth : 1;
         p.rolling = roll ? 1 : 0;
@@ -581,7 +590,7 @@ int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors) {
     if (sys->lanes_override == 0 && sweep_wanted(sys, start.kind == StartKind::Random, false, &stencil_kind) == BDG_OK &&
         stencil_kind != 0) {
         const int per_lane = real ? 2 : 1;
-        const int lanes = stencil_kind == 1 ? sweep_lanes_for(sys, n_vectors, per_lane) : bdg::kSweepLanes;
+        const int lanes = stencil_kind == 1 ? sweep_lanes_for(sys, n_vectors, per_lane) : roll_lanes_for(sys, n_vectors, per_lane);
         return std::min(lanes * per_lane, std::max(n_vectors, 1));  // one lane group per launch
     }
     // (slabs: the widest slab of the run decides, so that every rank cuts the same batches)

@@ -678,7 +678,6 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
 // neighbours inside the lattice (open boundaries); anything else runs the one-step kernels.
 // Two steps per sweep are not possible here: step two would need t_{n+1} of the y-neighbours,
 // which other waves make.
-constexpr int kRollOwned = kSweepSlots - 2;  // 14 owned positions per wave window
 
 struct RollArgs {
     const uint2* stencil;    // per block row: table ids at offsets -P, -Lz, -1, 0, +1, +Lz, +P (bytes 0..6)
@@ -724,10 +723,15 @@ __global__ void build_stencil3(const int* __restrict__ indptr, const int* __rest
     }
 }
 
-template <typename Mode>
+// RL = lanes per site: 4 (8 real vectors per launch, 14 owned positions per window) or 2 (4 real
+// vectors, 30 owned positions: half the ghost slots, and half the bytes an XCD touches per plane).
+constexpr int roll_owned(int rl) { return kWave / rl - 2; }
+
+template <typename Mode, int RL = kSweepLanes>
 __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
     extern __shared__ double2 lds[];
-    constexpr int RL = kSweepLanes;
+    constexpr int SLOTS = kWave / RL;
+    constexpr int OWNED = SLOTS - 2;
     constexpr int SPB = Mode::kSlotsPerBlock;
     constexpr int STRIDE = Mode::kBlockStride;
     const int lane = threadIdx.x & (kWave - 1);
@@ -756,9 +760,9 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
         const int seg = u / a.n_cols, col = u - seg * a.n_cols;
         const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
         const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
-        const int p = col * kRollOwned - 1 + s;
+        const int p = col * OWNED - 1 + s;
         const bool valid = p >= 0 && p < a.plane;
-        const bool owned = valid && s >= 1 && s <= kSweepSlots - 2;
+        const bool owned = valid && s >= 1 && s <= SLOTS - 2;
         const bool rev = a.reverse != 0;  // wave-uniform
         auto act = [&](int k) { return rev ? x0 + x1 - 1 - k : k; };
 

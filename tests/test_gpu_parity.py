@@ -292,6 +292,7 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
                                       (5, 3, {"BODGE_AMD_SWEEP_LANES": "2"}),  # 26-position windows (3 steps), the default from 4.5e5 sites
                                       (7, 5, {"BODGE_AMD_SWEEP_LANES": "2", "BODGE_AMD_SWEEP_SEGMENTS": "2"}),
                                       (5, 5, {"BODGE_AMD_SWEEP_LANES": "2", "BODGE_AMD_SWEEP_STEPS": "2"}),  # 28-position windows
+                                      (6, 7, {"BODGE_AMD_SWEEP_LANES": "4"}),  # (K8: 14-position windows, 8 real vectors per launch)
                                       (8, per_group, {"BODGE_AMD_SWEEP_GEN": "0"}),  # start block written by the fill kernel and read back
                                       (1, 3, {}), (2, per_group, {}),  # runs shorter than one sweep
                                       (4, 3, {"BODGE_AMD_NO_DIAGONAL_BLOCKS": "1"})]:  # (read at upload: no effect here, see below)
@@ -310,6 +311,9 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
             stencil = is_stencil and block_storage == "dictionary"  # (the stencil forms read the block dictionary)
             swept, rolled = stencil and not three_d, stencil and three_d
             lanes = int(extra.get("BODGE_AMD_SWEEP_LANES", 4)) if swept else 4  # (default below 4.5e5 sites: 4 lanes per site)
+            if rolled:  # K8: 4 lanes per site, or 2 (30-position windows) for calls of at most 4 real / 2 complex vectors
+                lanes = int(extra["BODGE_AMD_SWEEP_LANES"]) if extra.get("BODGE_AMD_SWEEP_LANES") in ("2", "4") else (2 if vectors <= per_group // 2 else 4)
+                assert perf["lanes_per_row"] in (2, lanes)  # (a ragged last batch of a wide call takes 2)
             depth = int(extra.get("BODGE_AMD_SWEEP_STEPS", 3 if lanes >= 2 else 2))  # steps per sweep
             assert perf["steps_per_launch"] == (depth if swept else 1) and (perf["rolling"] == 1) == rolled, perf
             batches = -(-vectors // (per_group * lanes // 4))

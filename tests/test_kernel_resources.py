@@ -56,5 +56,6 @@ def test_sweep_kernels_fit_two_waves_per_simd_without_spilling(resources):
                 for gen in ("false", "true") if reverse == "false" else ("false",):  # (GEN: start block made in registers)
                     row = _row(resources, f"cheb_sweep3<bdg::{mode}, {lanes}, {reverse}, {gen}>")
                     assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, reverse, gen, row)
-        row = _row(resources, f"cheb_roll3<bdg::{mode}>")
-        assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, row)
+        for lanes in (2, 4):
+            row = _row(resources, f"cheb_roll3<bdg::{mode}, {lanes}>")
+            assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, row)

@@ -29,9 +29,9 @@ def kernel_key(name: str) -> str:
     m = re.search(r"(cheb_sweep3?)<bdg::(\w+), (\d), (?:true|false)[,>]", name)  # both marching directions count as one kernel
     if m:
         return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
-    m = re.search(r"cheb_roll3<bdg::(\w+)>", name)
+    m = re.search(r"cheb_roll3<bdg::(\w+), (\d)>", name)
     if m:
-        return f"cheb_roll3<{m.group(1)}>"
+        return f"cheb_roll3<{m.group(1)},{m.group(2)}>"
     m = re.search(r"(cheb_step\w*)<bdg::(\w+), (\d+)", name)
     return f"{m.group(1)}<{m.group(2)},{m.group(3)}>" if m else ""
 
