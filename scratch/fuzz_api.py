@@ -143,6 +143,22 @@ for case in range(n_cases):
         one = system.free_energy(0.5, method="chebyshev", trace="exact")
         two = system.free_energy(0.5, method="chebyshev", trace="exact", devices=[0, 0])
         check(abs(one - two) <= 1e-11 * max(1.0, abs(one)), "devices=[0,0]", case, f"{tag} {one} vs {two}")
+    # change a few terms (the device mirror must be rebuilt) and ask again; three mirrors with ragged shares
+    if case % 3 == 0:
+        sites = list(system.lattice.sites())
+        with system as (H, D):
+            for _ in range(int(rng.integers(1, 4))):
+                i = sites[int(rng.integers(len(sites)))]
+                H[i, i] = float(rng.normal()) * ba.σ0 + float(rng.normal()) * ba.σ3
+        dense2 = np.asarray(system.matrix("dense"))
+        ref2 = dense_ref.free_energy(dense2, 0.4)
+        got2 = system.free_energy(0.4, method="dense")
+        check(abs(got2 - ref2) <= 1e-10 * max(1.0, abs(ref2)), "free_energy after a second with-block", case, f"{tag} {got2} vs {ref2}")
+        if system.has_symmetric_spectrum(1e-12):
+            got3 = system.free_energy(0.4, method="chebyshev", trace="exact")
+            check(abs(got3 - ref2) <= 1e-9 * max(1.0, abs(ref2)), "chebyshev after a second with-block", case, f"{tag} {got3} vs {ref2}")
+            got4 = system.free_energy(0.4, method="chebyshev", trace="exact", devices=[0, 0, 0])
+            check(abs(got4 - got3) <= 1e-11 * max(1.0, abs(got3)), "devices=[0,0,0]", case, f"{tag} {got4} vs {got3}")
     if case % 10 == 0:
         print(f"ok through case {case} ({tag}) [{time.time() - t_start:.0f} s]", flush=True)
 print(f"{n_cases} cases, {failures} failures, {time.time() - t_start:.0f} s")
