@@ -1,0 +1,89 @@
+"""Random small lattices / step counts / vector counts / knobs: stencil kernels (forced) against the one-step
+kernels on the same vectors.  Prints one line per failure; exit code 1 if any."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]  # (also importable outside pytest)
+import numpy as np
+import bodge_amd as ba
+from bodge_amd import chebyshev
+from bodge_amd.solver import DeviceSolver, VEC_RADEMACHER, VEC_Z4
+
+def run(seed: int = 0, n_cases: int = 100, size: str | None = None, lanczos: bool = True) -> int:
+    """Returns the number of failing cases (each printed).  Environment switches set on the way are undone."""
+    saved = dict(os.environ)
+    try:
+        import warnings
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            return _run(seed, n_cases, size, lanczos)
+    finally:
+        os.environ.clear()
+        os.environ.update(saved)
+
+
+def _run(seed, n_cases, size, lanczos) -> int:
+    rng = np.random.default_rng(seed)
+    failures = 0
+    t_start = time.time()
+    for case in range(n_cases):
+        three_d = rng.random() < 0.25
+        if three_d:
+            big3 = size == "large"
+            shape = (int(rng.integers(8, 30 if big3 else 14)), int(rng.integers(5, 30 if big3 else 9)), int(rng.integers(5, 30 if big3 else 9)))
+        else:
+            big = size == "large"
+            shape = (int(rng.integers(8, 120 if big else 40)), int(rng.integers(24, 500 if big else 90)), 1)
+            if rng.random() < 0.3:
+                shape = (shape[0], 1, shape[1])
+        lat = ba.CubicLattice(shape)
+        s = ba.Hamiltonian(lat)
+        model = rng.choice(["uniform", "disorder", "complex", "periodic"])
+        with s as (H, D):
+            if model == "disorder":
+                H.set_sites(rng.normal(size=(lat.size, 1, 1)) * ba.σ0 + 0.1 * rng.normal(size=(lat.size, 1, 1)) * ba.σ3)
+            else:
+                H.set_sites(3.0 * ba.σ0 - 0.05 * ba.σ3)
+            D.set_sites(-0.1 * ba.jσ2)
+            H.set_bonds(-1.0 * ba.σ0)
+            if model == "complex":
+                pairs = lat.bond_array(axis=0, coords=True)
+                phase = np.where(pairs[:, 1, 0] > pairs[:, 0, 0], np.exp(0.3j), np.exp(-0.3j))
+                H.set_bonds(-phase[:, None, None] * ba.σ0, axis=0)
+            if model == "periodic" and not three_d:
+                H.set_edges(-0.7 * ba.σ0)
+        indptr, indices, data = s.bsr_arrays()
+        scale = chebyshev.spectral_bound(indptr, data)
+        steps = int(rng.integers(1, 14))
+        vectors = int(rng.integers(1, 23))
+        kind = VEC_Z4 if rng.random() < 0.3 else VEC_RADEMACHER
+        env = {}
+        if rng.random() < 0.4: env["BODGE_AMD_SWEEP_LANES"] = str(rng.choice([2, 4]))
+        if rng.random() < 0.2: env["BODGE_AMD_SWEEP_STEPS"] = "2"
+        if rng.random() < 0.2: env["BODGE_AMD_SWEEP_SEGMENTS"] = str(int(rng.integers(1, 5)))
+        if rng.random() < 0.2: env["BODGE_AMD_SWEEP_ZIGZAG"] = "0"
+        if rng.random() < 0.2: env["BODGE_AMD_ALTERNATE"] = "0"
+        disorder_has_dict = True
+        with DeviceSolver(indptr, indices, data) as dev:
+            dev.set_lattice_shape(shape)
+            os.environ["BODGE_AMD_SWEEP"] = "0"
+            one = dev.dots_random(scale, steps, vectors, seed=case, kind=kind)
+            os.environ["BODGE_AMD_SWEEP"] = "1"
+            os.environ.update(env)
+            got = dev.dots_random(scale, steps, vectors, seed=case, kind=kind)
+            perf = dev.perf()
+            for k in env: del os.environ[k]
+        n = 4 * lat.size
+        err = max(np.abs(got[0] - one[0]).max(), np.abs(got[1] - one[1]).max()) / n
+        tag = f"case {case}: {shape} {model} steps={steps} vectors={vectors} kind={kind} {env} -> steps/launch {perf['steps_per_launch']} rolling {perf['rolling']}"
+        if not err <= 1e-12:
+            failures += 1
+            print("FAIL", tag, "err", err, flush=True)
+        elif case % 25 == 0:
+            print("ok  ", tag, f"err {err:.1e}  [{time.time() - t_start:.0f} s]", flush=True)
+    print(f"{n_cases} cases, {failures} failures, {time.time() - t_start:.0f} s")
+    return failures
+
+
+if __name__ == "__main__":
+    sys.exit(1 if run(int(os.environ.get("FUZZ_SEED", "0")), int(os.environ.get("FUZZ_CASES", "100")),
+                      os.environ.get("FUZZ_SIZE"), os.environ.get("FUZZ_LANCZOS", "1") == "1") else 0)

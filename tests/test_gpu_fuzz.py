@@ -1,0 +1,27 @@
+"""Randomised parity on the GPU (fixed seeds): tests/fuzz_sweep.py and tests/fuzz_api.py (also runnable at
+length through scratch/fuzz_*.py) with a bounded number of cases.  They found three defects when they were written (profiles/r02_fuzz_api.log, the fuzz section of
+profiles/r02_sweep_experiments.log); here they keep watch.
+
+* fuzz_sweep.py  random lattice shapes / models / step and vector counts / tuning knobs: the
+                         lattice-stencil kernels (K7, K7b, K8, forced) against the one-step kernels, 1e-12·4N
+* fuzz_api.py    random small systems through the public API against the CPU oracle: free energy
+                         (dense, Chebyshev exact and stochastic trace), diagonalize, ldos (single, several
+                         sites, band-limited), unit-start recurrences, slab groups, lowest_eigenpairs,
+                         several mirrors on one GPU, a second `with` block
+"""
+
+import pytest
+
+import fuzz_api
+import fuzz_sweep
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("seed,size,cases", [(101, None, 400), (102, "large", 150)])
+def test_random_lattices_stencil_kernels_against_one_step_kernels(hip_library, seed, size, cases):
+    assert fuzz_sweep.run(seed=seed, n_cases=cases, size=size) == 0
+
+
+def test_random_systems_through_the_api_against_the_oracle(hip_library):
+    assert fuzz_api.run(seed=103, n_cases=40) == 0
