@@ -107,10 +107,31 @@ def jackson_kernel(n_moments: int) -> np.ndarray:
     return ((n_moments - m + 1) * np.cos(q * m) + np.sin(q * m) / np.tan(q)) / (n_moments + 1)
 
 
-def free_energy_series(mu_trace: np.ndarray, scale: float, temperature: float, damping: bool = False) -> float:
-    """F from trace moments μ_m ≈ Tr T_m(H/scale)."""
+def gapped_ground_state_density(width: float):
+    """ε -> -(ε/4)·erf(ε/width): the T = 0 density -|ε|/4 with its kink at ε = 0 smoothed over `width`.
+
+    On a spectrum with |ε| ≥ gap the two differ by (|ε|/4)·erfc(|ε|/width) ≤ (gap/4)·erfc(gap/width),
+    4e-13·gap for width = gap/5, and the smoothed function is entire: its Chebyshev series converges
+    faster than geometrically, M = 8·a/width moments leave ≲ 1e-13 of F (measured on four spectra,
+    DESIGN.md §2), a quarter of what f_T at T = gap/20 needs for 1e-11."""
+    import math
+
+    erf = np.vectorize(math.erf, otypes=[float])  # (scipy.special costs seconds to import from a cold disk)
+    return lambda eps: -(np.asarray(eps, dtype=float) / 4.0) * erf(np.asarray(eps, dtype=float) / width)
+
+
+def moments_for_gapped_ground_state(scale: float, width: float) -> int:
+    """Even M = 8·a/width for the series of `gapped_ground_state_density(width)` (may exceed MAX_MOMENTS)."""
+    m = max(32, int(np.ceil(8.0 * scale / width)))
+    return m + (m & 1)
+
+
+def free_energy_series(mu_trace: np.ndarray, scale: float, temperature: float, damping: bool = False,
+                       density=None) -> float:
+    """F from trace moments μ_m ≈ Tr T_m(H/scale); `density` replaces f_T(ε) (see gapped_ground_state_density)."""
     n = len(mu_trace)
-    coeff = chebyshev_coefficients(lambda x: _f_density(scale * x, temperature), n)
+    coeff = chebyshev_coefficients((lambda x: density(scale * x)) if density is not None
+                                   else (lambda x: _f_density(scale * x, temperature)), n)
     if damping:
         coeff = coeff * jackson_kernel(n)
     return float(np.dot(coeff, mu_trace))

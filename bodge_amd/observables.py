@@ -9,8 +9,8 @@ Routing (all device-side; there is no CPU path):
 * chebyshev  kernel-polynomial expansion on the BSR matrix, O(N·M): the
            recurrence kernel advances R start vectors together; exact trace
            (unit vectors of the electron rows, x2 by particle-hole symmetry) up to
-           4N = EXACT_TRACE_LIMIT, stochastic trace beyond.  T = 0 is expanded at the
-           surrogate temperature gap/20 when the spectrum is gapped.
+           4N = EXACT_TRACE_LIMIT, stochastic trace beyond.  T = 0 on a gapped spectrum expands
+           the smoothed density -(ε/4)·erf(5ε/gap).
 
 `method="auto"` picks, by estimated run time, between the dense eigensolver
 (4N <= DENSE_AUTO_LIMIT: the library-free Jacobi kernels; rocSOLVER up to
@@ -28,7 +28,7 @@ from .backend import VEC_RADEMACHER, VEC_Z4
 
 DENSE_AUTO_LIMIT = 2048  # largest 4N served by the own Jacobi kernels (kJacobiLimit in the library)
 DENSE_AUTO_LIMIT_T0 = 16384  # largest 4N method="auto" ever sends to a dense eigensolver
-GAP_SURROGATE_RATIO = 20.0  # T = 0 is expanded at T = gap / this (see free_energy)
+GAP_SURROGATE_RATIO = 5.0  # T = 0: the kink of -|ε|/4 is smoothed over gap / this (see free_energy)
 EXACT_TRACE_LIMIT = 65536  # largest 4N for which trace="auto" is exact (128x128 sites: ~2 s at T = 0.1)
 
 
@@ -99,8 +99,8 @@ def _gap_estimate(system) -> float:
 def _auto_method(system, temperature: float, moments, scale) -> str:
     """Dense or Chebyshev for `free_energy(method="auto")`, by estimated run time.
 
-    T = 0: dense within reach of the own Jacobi kernels; above, the Chebyshev expansion at the
-    surrogate temperature gap/20 (see `free_energy`) when the spectrum is gapped enough, else the
+    T = 0: dense within reach of the own Jacobi kernels; above, the Chebyshev expansion of the
+    smoothed density -(ε/4)·erf(5ε/gap) (see `free_energy`) when the spectrum is gapped enough, else the
     dense library.  Matrices without the particle-hole form must go dense.  Otherwise the two
     routes are priced with measured constants (profiles/r01_wall_table.log): the Jacobi kernels
     cost ≈ 6e-11·(4N)³ s (0.25 s at 4N = 1600), rocSOLVER ≈ 2e-12·(4N)³ s plus its
@@ -114,12 +114,12 @@ def _auto_method(system, temperature: float, moments, scale) -> str:
         return "dense"
     a = _scale_of(system) if scale is None else float(scale)
     if temperature == 0:
-        # beyond the own Jacobi kernels: Chebyshev at T = gap/20 if the spectrum is gapped enough
+        # beyond the own Jacobi kernels: Chebyshev on the smoothed density if the spectrum is gapped enough
         # for that expansion to converge within the moment cap, the dense library otherwise
         if dim <= DENSE_AUTO_LIMIT or moments is not None:
             return "dense"
         gap = _gap_estimate(system)
-        gapped = gap > 0 and np.pi * (gap / GAP_SURROGATE_RATIO) / a > 11 * np.log(10.0) / cheb.MAX_MOMENTS
+        gapped = gap > 0 and cheb.moments_for_gapped_ground_state(a, gap / GAP_SURROGATE_RATIO) <= cheb.MAX_MOMENTS
         return "chebyshev" if gapped else "dense"
     m = cheb.moments_for_free_energy(a, temperature) if moments is None else int(moments)
     batches = -(-(dim // 2) // 64) if dim <= EXACT_TRACE_LIMIT else 1  # electron rows only
@@ -153,9 +153,10 @@ def free_energy(
     moments  Chebyshev order M (even); default from the analyticity strip of f at T
     trace    "exact" (all 4N unit vectors), "stochastic", or "auto"
     vectors  number of random vectors for the stochastic trace (default 64)
-    gap_surrogate  at T = 0 with the Chebyshev method and no explicit `moments`: expand f at
-             T = gap/20 instead (gap from `lowest_eigenvalues`), which differs from f_0 by ~1e-14 on a
-             gapped spectrum but converges geometrically; False keeps the plain T = 0 coefficients
+    gap_surrogate  at T = 0 with the Chebyshev method and no explicit `moments`: expand
+             -(ε/4)·erf(ε/δ), δ = gap/5 (gap from `lowest_eigenvalues`), which differs from -|ε|/4 by
+             ~1e-13 on a gapped spectrum and converges faster than geometrically (8·a/δ moments);
+             False keeps the plain T = 0 coefficients
     devices  optional list of GPU ordinals of THIS process, e.g. `devices=[0, 1, 2, 3]` or
              `range(8)`: H is replicated on each, the start vectors (or the unit vectors of an exact
              trace) are shared out over them, one host thread drives each GPU, and the moments are
@@ -205,20 +206,26 @@ def free_energy(
         raise ValueError("decomposition='slab' shares the lattice planes out over the ranks of a communicator: pass comm=")
     scale = _scale_of(system) if scale is None else float(scale)
     series_temperature = temperature
+    density = None  # (None: f_T at `temperature`)
     if temperature == 0 and moments is None and gap_surrogate and decomposition != "slab":
-        # f_0(ε) = -|ε|/4 has a kink at ε = 0, but a gapped spectrum never samples it: for T ≪ gap
-        # f_T - f_0 = -(T/2) log1p(e^{-|ε|/T}) ≤ (T/2) e^{-gap/T} on the spectrum, and f_T is analytic.
-        # With T = gap/20 the difference is ~1e-14 relative (20x20 README model: 8e-15 of the dense
-        # value with 16384 moments, against 3e-9 for the T = 0 coefficients; gap/10 would leave
-        # 5e-10) and the series converges geometrically.  The Lanczos estimate approaches the gap
-        # from above, to 1e-3.  A gapless spectrum keeps the plain T = 0 series.
+        # f_0(ε) = -|ε|/4 has a kink at ε = 0, but a gapped spectrum never samples it: expand
+        # -(ε/4)·erf(ε/δ) with δ = gap/5 instead, which differs from f_0 by ≤ (gap/4)·erfc(5) = 4e-13·gap
+        # per level on |ε| ≥ gap and is entire - 8·a/δ moments leave ≲ 1e-13 of F (20x20 README model:
+        # 1e-15 of the dense value at 6144 moments, where f_T at T = gap/20, the surrogate of round 1,
+        # still has 2e-10 and needs 22 000 for 1e-11; cheb.gapped_ground_state_density).  The Lanczos
+        # estimate approaches the gap from above, to 1e-3.  A gapless spectrum keeps the plain T = 0 series.
         gap = _gap_estimate(system)
         if gap > 1e-9 * scale:
-            series_temperature = gap / GAP_SURROGATE_RATIO
-    if series_temperature != temperature:
-        _warn(f"free_energy(0.0) on a {dim}x{dim} matrix is beyond the dense eigensolver: evaluated by the Chebyshev "
-              f"expansion at the surrogate temperature gap/{GAP_SURROGATE_RATIO:g} = {series_temperature:.3g} "
-              "(agrees with T = 0 to ~1e-14 relative on a gapped spectrum; method='dense' forces the reference's algorithm)")
+            width = gap / GAP_SURROGATE_RATIO
+            density = cheb.gapped_ground_state_density(width)
+            moments = cheb.moments_for_gapped_ground_state(scale, width)
+            if moments > cheb.MAX_MOMENTS:
+                _warn(f"free_energy(0.0): gap/scale = {gap / scale:.1e} asks for {moments} Chebyshev moments; capped at "
+                      f"{cheb.MAX_MOMENTS} (pass moments=... to override, or method='dense')")
+                moments = cheb.MAX_MOMENTS
+            _warn(f"free_energy(0.0) on a {dim}x{dim} matrix is beyond the dense eigensolver: evaluated by the Chebyshev "
+                  f"expansion of -(ε/4)·erf(ε/δ), δ = gap/{GAP_SURROGATE_RATIO:g} = {width:.3g} "
+                  "(agrees with -|ε|/4 to ~1e-13 relative on a gapped spectrum; method='dense' forces the reference's algorithm)")
     if moments is None:
         moments = cheb.moments_for_free_energy(scale, series_temperature)
     moments += moments & 1
@@ -242,7 +249,7 @@ def free_energy(
                 d, e = solver.dots_unit(scale, steps, rows[lo : lo + width])
                 mu_local += cheb.dots_to_moments(d, e).sum(axis=1)
             mu = comm.allreduce_sum(mu_local) / 0.5  # the hole rows contribute the same again (see _electron_rows)
-            return cheb.free_energy_series(mu, scale, series_temperature, damping=damping)
+            return cheb.free_energy_series(mu, scale, series_temperature, damping=damping, density=density)
         if trace == "stochastic":
             kind = {"rademacher": VEC_RADEMACHER, "z4": VEC_Z4}[vector_kind]
             total = 64 if vectors is None else int(vectors)
@@ -250,7 +257,7 @@ def free_energy(
         else:
             raise RuntimeError(f"Trace mode '{trace}' is not supported")
         mu = comm.allreduce_sum(cheb.dots_to_moments(d, e).sum(axis=1)) / total
-        return cheb.free_energy_series(mu, scale, series_temperature, damping=damping)
+        return cheb.free_energy_series(mu, scale, series_temperature, damping=damping, density=density)
 
     if devices is not None:
         if trace == "exact":
@@ -265,7 +272,7 @@ def free_energy(
                       "vectors (4N beyond the exact trace); free_energy_stochastic() reports its standard error")
         else:
             raise RuntimeError(f"Trace mode '{trace}' is not supported")
-        return cheb.free_energy_series(mu, scale, series_temperature, damping=damping)
+        return cheb.free_energy_series(mu, scale, series_temperature, damping=damping, density=density)
 
     solver = system._solver()
 
@@ -284,7 +291,8 @@ def free_energy(
             # the caller asked for "the free energy" and gets an estimate: say so, with its standard error
             d, e = solver.dots_random(scale, moments // 2, count, seed=seed, first_id=first, kind=kind)
             per_vector_mu = cheb.dots_to_moments(d, e)
-            coeff = cheb.chebyshev_coefficients(lambda x: cheb._f_density(scale * x, series_temperature), moments)
+            coeff = cheb.chebyshev_coefficients((lambda x: density(scale * x)) if density is not None else
+                                                (lambda x: cheb._f_density(scale * x, series_temperature)), moments)
             per_vector = coeff @ per_vector_mu
             sigma = float(np.std(per_vector, ddof=1) / np.sqrt(total)) if total > 1 else float("nan")
             _warn(f"free_energy() on a {dim}x{dim} matrix is beyond the exact trace (4N <= {EXACT_TRACE_LIMIT}): this is a "
@@ -300,7 +308,7 @@ def free_energy(
             mu = mu / total
     else:
         raise RuntimeError(f"Trace mode '{trace}' is not supported")
-    return cheb.free_energy_series(mu, scale, series_temperature, damping=damping)
+    return cheb.free_energy_series(mu, scale, series_temperature, damping=damping, density=density)
 
 
 def _device_mirrors(system, devices):

@@ -535,13 +535,14 @@ def test_free_energy_default_moment_rule_reaches_1e10(api, golden):
 
 @pytest.mark.parametrize("name", ["swave20_zeeman", "snf"])
 def test_zero_temperature_chebyshev_on_a_gapped_spectrum(api, golden, name):
-    """T = 0 beyond dense reach: |ε| is not analytic, but on a gapped spectrum the expansion of f at
-    T = gap/20 (gap from Lanczos) reproduces the dense T = 0 value; the plain T = 0 coefficients
-    with the same number of moments do not."""
+    """T = 0 beyond dense reach: |ε| is not analytic, but on a gapped spectrum the expansion of
+    -(ε/4)·erf(ε/δ), δ = gap/5 (gap from Lanczos / the dense solver), reproduces the dense T = 0 value
+    - to 1e-12 with 8·a/δ moments, a quarter of what the finite-temperature surrogate of round 1
+    needed for 1e-10; the plain T = 0 coefficients with the same number of moments do not."""
     system = _build(api, name)
     exact = golden.free_energy(name, 0.0)
     value = system.free_energy(0.0, method="chebyshev")
-    assert np.isclose(value, exact, rtol=1e-10, atol=0)
+    assert np.isclose(value, exact, rtol=1e-12, atol=0)
     plain = system.free_energy(0.0, method="chebyshev", gap_surrogate=False)
     assert abs(plain - exact) > abs(value - exact) and np.isclose(plain, exact, rtol=1e-6)
 
@@ -947,7 +948,7 @@ def test_default_call_warns_when_it_is_not_the_reference_computation(api, monkey
         system.free_energy(0.5, method="chebyshev", trace="stochastic")
         system.free_energy(0.5, method="dense")
     monkeypatch.setattr(observables, "DENSE_AUTO_LIMIT", 1000)
-    with pytest.warns(RuntimeWarning, match="surrogate temperature"):
+    with pytest.warns(RuntimeWarning, match="beyond the dense eigensolver: evaluated by the Chebyshev"):
         zero = system.free_energy(0.0, trace="exact")
     assert abs(zero / system.free_energy(0.0, method="dense") - 1) < 1e-10
 

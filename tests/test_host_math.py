@@ -54,6 +54,27 @@ def test_zero_temperature_series_converges_algebraically(api, golden):
     assert abs(damped / exact - 1) < 1e-2
 
 
+@pytest.mark.parametrize("name", ["swave20_zeeman", "swave20", "snf", "complex235", "chain128"])
+def test_gapped_ground_state_series_from_exact_moments(api, golden, name):
+    """T = 0 on a gapped spectrum: the expansion of -(ε/4)·erf(ε/δ), δ = gap/5, with the rule's
+    8·a/δ moments returns -½ Σ_{ε>0} ε to 1e-12 - the finite-temperature surrogate f_T at T = gap/20
+    (round 1) is two orders less accurate with four times the moments, the plain |ε| series eight."""
+    _, vals, _, scale = _spectrum(api, name)
+    positive = vals[vals > 0]
+    exact, gap = -0.5 * positive.sum(), float(positive.min())
+    width = gap / 5.0
+    m = chebyshev.moments_for_gapped_ground_state(scale, width)
+    assert m % 2 == 0 and m >= 8 * scale / width
+    mu = _trace_moments(vals, scale, 4 * m)
+    value = chebyshev.free_energy_series(mu[:m], scale, 0.0, density=chebyshev.gapped_ground_state_density(width))
+    assert abs(value / exact - 1) <= 1e-12
+    old_surrogate = chebyshev.free_energy_series(mu[:m], scale, gap / 20.0)
+    plain = chebyshev.free_energy_series(mu[:m], scale, 0.0)
+    assert abs(old_surrogate / exact - 1) > 10 * abs(value / exact - 1) and abs(plain / exact - 1) > 1e-9
+    if name == "swave20_zeeman":
+        assert np.isclose(exact, golden.free_energy(name, 0.0), rtol=1e-12)
+
+
 def test_resolvent_series_from_exact_moments(api, golden):
     system, vals, vecs, scale = _spectrum(api, "ldos16")
     site, energies = systems.CATALOG["ldos16"]["ldos"][0]
