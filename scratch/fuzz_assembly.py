@@ -51,7 +51,7 @@ def run(seed, native):
     return shape, out
 
 bad = 0
-for seed in range(400):
+for seed in range(int(__import__("os").environ.get("FUZZ_FIRST", "0")), int(__import__("os").environ.get("FUZZ_FIRST", "0")) + 400):
     sa, a = run(seed, True); sb, b = run(seed, False)
     assert sa == sb and len(a) == len(b)
     for (ea, da, ta, pa, ga), (eb, db, tb, pb, gb) in zip(a, b):
