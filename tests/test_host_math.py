@@ -130,3 +130,19 @@ def test_trace_form_needs_a_symmetric_spectrum(api, golden):
     for name in ("swave20", "complex235", "dwave8", "pwave31", "chain128"):
         spec = systems.CATALOG[name]
         assert spec["build"](api, **spec["kwargs"]).has_symmetric_spectrum(1e-12), name
+
+
+def test_smoothed_density_and_krylov_cut():
+    """Two small host helpers: the smoothed T = 0 density against scipy's erf, and the cut of a Lanczos
+    tridiagonal matrix at the first round-off-sized β (exhausted Krylov space)."""
+    from scipy.special import erf
+
+    from bodge_amd.observables import _krylov_length
+
+    x = np.linspace(-7.0, 7.0, 20001)
+    density = chebyshev.gapped_ground_state_density(0.013)
+    assert np.abs(density(x) - (-(x / 4) * erf(x / 0.013))).max() <= 1e-15
+    assert np.abs(density(x[np.abs(x) >= 0.065]) + np.abs(x[np.abs(x) >= 0.065]) / 4).max() <= 1e-13  # = -|ε|/4 beyond 5 widths
+    assert chebyshev.moments_for_gapped_ground_state(7.2, 0.0105) == 5486 and chebyshev.moments_for_gapped_ground_state(1.0, 10.0) == 32
+    beta = np.array([3.0, 2.5, 2.9, 1e-9, 4.0, 3.0])
+    assert _krylov_length(beta, scale2=25.0) == 4 and _krylov_length(beta[:3], scale2=25.0) == 3
