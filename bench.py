@@ -50,17 +50,44 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
 
-def build_system(shape, model="swave", zeeman=0.05, gap=0.1, mu=3.0):
-    """Synthetic Hamiltonians of SURVEY §8d: "swave" = README model (+Zeeman), "dwave" = config 4."""
+def build_system(shape, model="swave", zeeman=0.05, gap=0.1, mu=3.0, seed=11):
+    """Synthetic Hamiltonians of SURVEY §8d: "swave" = README model (+Zeeman), "dwave" = config 4;
+    "potential" / "texture" = the s-wave model with position-dependent on-site terms (a random
+    potential and gap amplitude: real; an exchange field of varying direction: complex blocks) -
+    10^6 distinct diagonal blocks, what per-site fills (ref hamiltonian.py:102-118) make of it; "peierls" =
+    the s-wave model with a uniform phase on the x bonds (translation invariant, genuinely complex).
+    The Hermiticity test of the closing `with` block is made on the host: the process must not touch
+    the GPU before the CPU baseline has forked its workers."""
     import bodge_amd as ba
 
     lattice = ba.CubicLattice(tuple(shape))
     system = ba.Hamiltonian(lattice)
+    system.hermiticity_check = "host"
+    rng = np.random.default_rng(seed)
+    sites = lattice.size
     with system as (H, Δ):
         if model == "swave":
             H.set_sites(mu * ba.σ0 - zeeman * ba.σ3)
             Δ.set_sites(-gap * ba.jσ2)
             H.set_bonds(-1.0 * ba.σ0)
+        elif model == "potential":
+            H.set_sites((mu + rng.uniform(-0.5, 0.5, sites))[:, None, None] * ba.σ0 - zeeman * ba.σ3)
+            Δ.set_sites(-rng.uniform(0.5 * gap, 1.5 * gap, sites)[:, None, None] * ba.jσ2)
+            H.set_bonds(-1.0 * ba.σ0)
+        elif model == "texture":
+            th, ph = rng.uniform(0, np.pi, sites)[:, None, None], rng.uniform(0, 2 * np.pi, sites)[:, None, None]
+            H.set_sites(mu * ba.σ0 - 0.3 * (np.sin(th) * np.cos(ph) * ba.σ1 + np.sin(th) * np.sin(ph) * ba.σ2 + np.cos(th) * ba.σ3))
+            Δ.set_sites(-gap * ba.jσ2)
+            H.set_bonds(-1.0 * ba.σ0)
+        elif model == "peierls":
+            pairs = lattice.bond_array(axis=0, coords=True)  # directed x bonds: a phase one way, its conjugate back
+            phase = np.where(pairs[:, 1, 0] > pairs[:, 0, 0], np.exp(0.3j), np.exp(-0.3j))
+            H.set_sites(mu * ba.σ0 - zeeman * ba.σ3)
+            Δ.set_sites(-gap * ba.jσ2)
+            H.set_bonds(-phase[:, None, None] * ba.σ0, axis=0)
+            for axis in (1, 2):
+                if shape[axis] > 1:
+                    H.set_bonds(-1.0 * ba.σ0, axis=axis)
         elif model == "dwave":
             pairs = lattice.bond_array(coords=True)
             H.set_sites(mu * ba.σ0)

@@ -45,6 +45,8 @@ class Perf(C.Structure):
         ("steps_per_launch", C.c_int32),
         ("rolling", C.c_int32),
         ("dict_skipped", C.c_int32),
+        ("onsite_streamed", C.c_int32),
+        ("reserved", C.c_int32),
     ]
 
 
@@ -91,6 +93,7 @@ SIGNATURES = {
     "bdg_perf_query": (C.c_int, [_handle, C.POINTER(Perf)]),
     "bdg_set_lattice_shape": (C.c_int, [_handle, C.c_int32, C.c_int32, C.c_int32]),
     "bdg_set_lanes_per_row": (C.c_int, [_handle, C.c_int32]),
+    "bdg_set_option": (C.c_int, [C.c_char_p, C.c_char_p]),
     "bdg_comm_unique_id": (C.c_int, [_u8p]),
     "bdg_host_fill_terms": (C.c_int, [_f64p, C.c_int64, _i64p, C.c_int64, _f64p, C.c_int, C.c_int, _u8p]),
     "bdg_host_scan_blocks": (C.c_int, [_f64p, _i32p, C.c_int64, _u8p, C.POINTER(C.c_int64), C.POINTER(C.c_double),
@@ -163,3 +166,28 @@ def as_i64p(array: np.ndarray):
 
 def as_u8p(array: np.ndarray):
     return array.ctypes.data_as(_u8p)
+
+
+def set_option(name: str, value) -> None:
+    """Override one BODGE_AMD_* switch of the library for this process (`None` removes the override).
+
+    The library looks here before the environment variable of the same name; unlike changing
+    `os.environ` this is safe while other host threads are inside library calls."""
+    check(load().bdg_set_option(name.encode(), None if value is None else str(value).encode()))
+
+
+class options:
+    """`with backend.options(BODGE_AMD_SWEEP="0", ...):` - switches set for the block, removed after it."""
+
+    def __init__(self, **values):
+        self._values = values
+
+    def __enter__(self):
+        for name, value in self._values.items():
+            set_option(name, value)
+        return self
+
+    def __exit__(self, *exc):
+        for name in self._values:
+            set_option(name, None)
+        return False

@@ -111,44 +111,72 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     // Distinct blocks (exact, bitwise).  Gives up as soon as there are too many to be useful.
     // A lattice matrix repeats a handful of blocks, mostly in runs: the four most recent ones are
     // compared directly before the hash map is asked.
+    // Second attempt if that fails on a square matrix: the distinct OFF-diagonal blocks only.  Site-
+    // dependent on-site terms (a disorder potential, a self-consistent gap, a magnetic texture) make
+    // every diagonal block different while the bonds still repeat a few; the diagonal blocks are then
+    // left out of the dictionary (word id kStreamedId) and must each be exactly Hermitian and
+    // particle-hole symmetric, so that 12 doubles describe them (kernels.hpp, mac_onsite).
     constexpr int kMaxDistinct = 256;  // table index shares a 32-bit word with the 24-bit column
+    constexpr unsigned kStreamedId = 0xFEu;
     int dict_skipped = 0;
+    bool onsite_streamed = false;
     std::vector<int> ids;
     std::vector<double> distinct;  // n_unique x 32 doubles
     {
         const char* env = knob::raw("BODGE_AMD_DICT");
         bool wanted = !(env && env[0] == '0') && nnzb > 0 && ncols <= (1 << 24);
         dict_skipped = (env && env[0] == '0') ? 3 : ncols > (1 << 24) ? 2 : 0;
-        if (wanted) {
+        auto onsite_packable = [](const double* blk) {  // A = A^†, C = B^†, D = -conj(A), all exactly
+            auto re = [&](int r, int c) { return blk[2 * (4 * r + c)]; };
+            auto im = [&](int r, int c) { return blk[2 * (4 * r + c) + 1]; };
+            if (im(0, 0) != 0.0 || im(1, 1) != 0.0 || re(1, 0) != re(0, 1) || im(1, 0) != -im(0, 1)) return false;
+            for (int i = 0; i < 2; ++i)
+                for (int j = 0; j < 2; ++j) {
+                    if (re(2 + i, j) != re(j, 2 + i) || im(2 + i, j) != -im(j, 2 + i)) return false;   // C = B^†
+                    if (re(2 + i, 2 + j) != -re(i, j) || im(2 + i, 2 + j) != im(i, j)) return false;   // D = -A*
+                }
+            return true;
+        };
+        auto dedupe = [&](bool skip_diagonal, int limit) -> bool {
             std::unordered_map<std::string_view, int> seen;
             const double* recent_key[4] = {nullptr, nullptr, nullptr, nullptr};
             int recent_id[4] = {0, 0, 0, 0};
             int recent_next = 0;
-            ids.resize((size_t)nnzb);
-            for (int64_t k = 0; k < nnzb; ++k) {
-                const double* block = data + 32 * k;
-                int id = -1;
-                for (int m = 0; m < 4 && id < 0; ++m)
-                    if (recent_key[m] && memcmp(recent_key[m], block, 256) == 0) id = recent_id[m];
-                if (id < 0) {
-                    std::string_view key(reinterpret_cast<const char*>(block), 256);
-                    auto it = seen.find(key);
-                    if (it == seen.end()) {
-                        if ((int)seen.size() == kMaxDistinct) {
-                            wanted = false;
-                            dict_skipped = 1;
-                            break;
-                        }
-                        it = seen.emplace(key, (int)seen.size()).first;
-                        distinct.insert(distinct.end(), block, block + 32);
+            ids.assign((size_t)nnzb, 0);
+            distinct.clear();
+            for (int64_t i = 0; i < nb; ++i)
+                for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) {
+                    const double* block = data + 32 * k;
+                    if (skip_diagonal && indices[k] == i) {
+                        if (!onsite_packable(block)) return false;
+                        ids[(size_t)k] = (int)((unsigned)indices[k] | (kStreamedId << 24));
+                        continue;
                     }
-                    id = it->second;
-                    recent_key[recent_next] = block;
-                    recent_id[recent_next] = id;
-                    recent_next = (recent_next + 1) & 3;
+                    int id = -1;
+                    for (int m = 0; m < 4 && id < 0; ++m)
+                        if (recent_key[m] && memcmp(recent_key[m], block, 256) == 0) id = recent_id[m];
+                    if (id < 0) {
+                        std::string_view key(reinterpret_cast<const char*>(block), 256);
+                        auto it = seen.find(key);
+                        if (it == seen.end()) {
+                            if ((int)seen.size() == limit) return false;
+                            it = seen.emplace(key, (int)seen.size()).first;
+                            distinct.insert(distinct.end(), block, block + 32);
+                        }
+                        id = it->second;
+                        recent_key[recent_next] = block;
+                        recent_id[recent_next] = id;
+                        recent_next = (recent_next + 1) & 3;
+                    }
+                    ids[(size_t)k] = (int)((unsigned)indices[k] | ((unsigned)id << 24));
                 }
-                ids[(size_t)k] = (int)((unsigned)indices[k] | ((unsigned)id << 24));
-            }
+            return true;
+        };
+        if (wanted && !dedupe(false, kMaxDistinct)) {
+            dict_skipped = 1;
+            const char* os_env = knob::raw("BODGE_AMD_ONSITE_STREAM");
+            wanted = ncols == nb && !(os_env && os_env[0] == '0') && dedupe(true, (int)kStreamedId) && !distinct.empty();
+            onsite_streamed = wanted;
         }
         if (!wanted) {
             ids.clear();
@@ -180,7 +208,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     };
     bool is_real = true, is_ph = true;
     double gershgorin = 0.0;
-    if (!ids.empty()) {
+    if (!ids.empty() && !onsite_streamed) {
         const size_t n_distinct = distinct.size() / 32;
         std::vector<double> sums(4 * n_distinct);
         for (size_t d = 0; d < n_distinct; ++d) {
@@ -234,6 +262,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
                 if (indices[k] >= nb) sys->row_needs_halo[(size_t)i] = 1;
     }
     sys->dict_skipped = dict_skipped;
+    sys->onsite_streamed = onsite_streamed;
     sys->is_real = is_real;
     sys->is_ph = is_ph;
     sys->gershgorin = gershgorin;
@@ -414,6 +443,7 @@ int bdg_destroy(bdg_system* sys) {
     sys->blocks.release();
     for (auto& buf : sys->packed) buf.release();
     for (auto& buf : sys->dict_table) buf.release();
+    for (auto& buf : sys->onsite) buf.release();
     sys->dict_ids.release();
     sys->dict_diagonal.release();
     sys->dict_full.release();
@@ -462,6 +492,12 @@ int bdg_set_lanes_per_row(bdg_system* sys, int32_t lanes) {
     if (!sys) return fail(BDG_EINVAL, "null system handle");
     if (lanes != 0 && !step_kernel(mode_info(false, false), lanes)) return fail(BDG_EINVAL, "lanes must be 4, 8, 16, 32 or 64");
     sys->lanes_override = lanes;
+    return BDG_OK;
+}
+
+int bdg_set_option(const char* name, const char* value) {
+    if (!name || strncmp(name, "BODGE_AMD_", 10) != 0) return fail(BDG_EINVAL, "option names begin with BODGE_AMD_");
+    knob::set(name, value);
     return BDG_OK;
 }
 

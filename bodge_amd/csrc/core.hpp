@@ -111,6 +111,12 @@ struct bdg_system {
     int n_unique = 0;
     int dict_skipped = 0;  // why there is no dictionary: 0 = there is one, 1 = > 256 distinct blocks,
                            // 2 = more than 2^24 block columns (the packed word holds 24 bits), 3 = switched off
+    // Position-dependent on-site terms: the diagonal blocks are all different, the bond blocks few.  Then
+    // the dictionary above holds the distinct OFF-diagonal blocks only, the words of the diagonal blocks
+    // carry kStreamedId, and the three-step sweep streams a packed per-site record instead
+    // (cheb_sweep3<..., OS>); every other kernel family streams all blocks of such a matrix.
+    bool onsite_streamed = false;
+    DeviceBuffer<double2> onsite[2];  // [0] complex (6 x 16 B per site), [1] real (4 x 16 B); built on first use
     DeviceBuffer<int> dict_ids;
     DeviceBuffer<int> dict_diagonal;      // per distinct block: 1 = diagonal as a 4x4 matrix (stencil kernels)
     DeviceBuffer<double2> dict_full;      // n_unique x 16 complex entries

@@ -377,6 +377,34 @@ struct ComplexPHMode {
         cfms_conj(acc[2], blk[0], x[2]);  // -conj(A00)
         cfms_conj(acc[3], blk[3], x[3]);  // -conj(A11)
     }
+    // Streamed on-site blocks (sweep.hpp, cheb_sweep3 with OS): a diagonal block of H is Hermitian as
+    // well as particle-hole symmetric, A = A^†, C = B^†, so 12 doubles describe it:
+    //   slot 0 = (Re A00, Re A11), slot 1 = A01, slots 2..5 = B00 B01 B10 B11      (96 B instead of 192)
+    // (checked exactly, block by block, at upload).  The products are mac_row's, in mac_row's order,
+    // on the same numbers: conjugation and negation are exact, so the results are the same bits.
+    static constexpr int kOnsiteSlots = 6;
+    static constexpr int kOnsiteStride = 7;
+    __device__ static inline double2 cj(const double2 m) { return make_double2(m.x, -m.y); }
+    __device__ static inline void mac_onsite(double2 acc[4], const double2* os, const double2 x[4]) {
+        const double2 d = os[0], a01 = os[1], b00 = os[2], b01 = os[3], b10 = os[4], b11 = os[5];
+        const double2 a00 = make_double2(d.x, 0.0), a11 = make_double2(d.y, 0.0), a10 = cj(a01);
+        cfma(acc[0], a00, x[0]);
+        cfma(acc[0], a01, x[1]);
+        cfma(acc[0], b00, x[2]);
+        cfma(acc[0], b01, x[3]);
+        cfma(acc[2], cj(b00), x[0]);
+        cfma(acc[2], cj(b10), x[1]);
+        cfms_conj(acc[2], a00, x[2]);
+        cfms_conj(acc[2], a01, x[3]);
+        cfma(acc[1], a10, x[0]);
+        cfma(acc[1], a11, x[1]);
+        cfma(acc[1], b10, x[2]);
+        cfma(acc[1], b11, x[3]);
+        cfma(acc[3], cj(b01), x[0]);
+        cfma(acc[3], cj(b11), x[1]);
+        cfms_conj(acc[3], a10, x[2]);
+        cfms_conj(acc[3], a11, x[3]);
+    }
     __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
         ComplexMode::dots(dot, c, n);
     }
@@ -409,6 +437,29 @@ struct RealPHMode {
         rfma(acc[1], blk[1].y, x[1]);   // A11
         rfma(acc[2], -blk[0].x, x[2]);  // -A00
         rfma(acc[3], -blk[1].y, x[3]);  // -A11
+    }
+    // Streamed on-site blocks (see ComplexPHMode): A symmetric, C = B^T, 8 doubles
+    //   slot 0 = (A00, A01), slot 1 = (A11, 0), slot 2 = (B00, B01), slot 3 = (B10, B11)   (64 B instead of 96)
+    static constexpr int kOnsiteSlots = 4;
+    static constexpr int kOnsiteStride = 5;
+    __device__ static inline void mac_onsite(double2 acc[4], const double2* os, const double2 x[4]) {
+        const double2 s0 = os[0], s1 = os[1], s2 = os[2], s3 = os[3];
+        rfma(acc[0], s0.x, x[0]);
+        rfma(acc[0], s0.y, x[1]);
+        rfma(acc[0], s2.x, x[2]);
+        rfma(acc[0], s2.y, x[3]);
+        rfma(acc[2], s2.x, x[0]);
+        rfma(acc[2], s3.x, x[1]);
+        rfma(acc[2], -s0.x, x[2]);
+        rfma(acc[2], -s0.y, x[3]);
+        rfma(acc[1], s0.y, x[0]);
+        rfma(acc[1], s1.x, x[1]);
+        rfma(acc[1], s3.x, x[2]);
+        rfma(acc[1], s3.y, x[3]);
+        rfma(acc[3], s2.y, x[0]);
+        rfma(acc[3], s3.y, x[1]);
+        rfma(acc[3], -s0.y, x[2]);
+        rfma(acc[3], -s1.x, x[3]);
     }
     __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
         RealMode::dots(dot, c, n);
@@ -911,6 +962,35 @@ __global__ void pack_blocks(const double2* __restrict__ blocks, void* __restrict
         const double2 v = blocks[k * 16 + packed_source(entries, (int)(idx % entries))];
         if (real_out) static_cast<double*>(out)[idx] = v.x;
         else static_cast<double2*>(out)[idx] = v;
+    }
+}
+
+// Packed on-site (diagonal) blocks for the sweep kernel that streams them (Mode::mac_onsite):
+// one record per block row, zeros where the row stores no diagonal block.  Square matrices whose
+// diagonal blocks were verified Hermitian + particle-hole symmetric at upload.
+__global__ void pack_onsite(const int* __restrict__ indptr, const int* __restrict__ indices,
+                            const double2* __restrict__ blocks, int nb, int real_out, double2* __restrict__ out) {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const double2 zero = make_double2(0.0, 0.0);
+        double2 a00 = zero, a01 = zero, a11 = zero, b00 = zero, b01 = zero, b10 = zero, b11 = zero;
+        for (int k = indptr[i]; k < indptr[i + 1]; ++k)
+            if (indices[k] == i) {
+                const double2* blk = blocks + (size_t)k * 16;
+                a00 = blk[0], a01 = blk[1], a11 = blk[5];
+                b00 = blk[2], b01 = blk[3], b10 = blk[6], b11 = blk[7];
+            }
+        if (real_out) {
+            double2* rec = out + (size_t)i * 4;
+            rec[0] = make_double2(a00.x, a01.x);
+            rec[1] = make_double2(a11.x, 0.0);
+            rec[2] = make_double2(b00.x, b01.x);
+            rec[3] = make_double2(b10.x, b11.x);
+        } else {
+            double2* rec = out + (size_t)i * 6;
+            rec[0] = make_double2(a00.x, a11.x);
+            rec[1] = a01;
+            rec[2] = b00, rec[3] = b01, rec[4] = b10, rec[5] = b11;
+        }
     }
 }
 

@@ -1,7 +1,10 @@
 // knobs.hpp - every run-time switch of the library, in one place.
 //
-// All of them are environment variables read at the point of use through knob::raw (so a test can
-// change one between two calls); none is needed in normal use - the defaults are the product, the
+// All of them are read at the point of use through knob::raw: first the table of overrides set
+// with bdg_set_option (what the tests and bench.py use - calling setenv while another host thread
+// of a `devices=[...]` run sits in getenv is undefined behaviour in glibc, and the library itself
+// never modifies the environment), then the environment variable of the same name (read-only:
+// convenient from a shell).  None is needed in normal use - the defaults are the product, the
 // switches exist for the parity tests (every kernel form against every other) and for the A/B
 // measurements behind DESIGN.md's tables.  "=0" disables, any other value enables, unless stated.
 //
@@ -35,7 +38,49 @@
 #pragma once
 
 #include <cstdlib>
+#include <deque>
+#include <mutex>
+#include <shared_mutex>
+#include <string>
+#include <unordered_map>
 
 namespace knob {
-inline const char* raw(const char* name) { return std::getenv(name); }
+
+// Overrides: name -> value, or name -> nullptr for "behave as if the variable were unset".
+// Values live in a pool that is never freed, so a pointer handed out stays valid even if the
+// option is changed while a call on another thread is still looking at it.
+struct Table {
+    std::shared_mutex mutex;
+    std::unordered_map<std::string, const char*> entries;
+    std::deque<std::string> pool;
+};
+inline Table& table() {
+    static Table* t = new Table();  // (leaked on purpose: detached prefetch threads may outlive main)
+    return *t;
+}
+
+// value = nullptr removes the override (the environment variable, if any, shows again)
+inline void set(const char* name, const char* value) {
+    Table& t = table();
+    std::unique_lock<std::shared_mutex> lock(t.mutex);
+    if (!value) {
+        t.entries.erase(name);
+        return;
+    }
+    t.pool.emplace_back(value);
+    t.entries[name] = t.pool.back().c_str();
+}
+
+inline const char* raw(const char* name) {
+    Table& t = table();
+    {
+        std::shared_lock<std::shared_mutex> lock(t.mutex);
+        if (!t.entries.empty()) {
+            auto it = t.entries.find(name);
+            if (it != t.entries.end()) return it->second;
+        }
+    }
+    return std::getenv(name);
+}
+
 }  // namespace knob

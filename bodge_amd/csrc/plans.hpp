@@ -141,11 +141,17 @@ StepKernel dict_for(const ModeInfo& mode, int rl) {
 }
 
 constexpr size_t kDictLdsLimit = 32 * 1024;  // bytes of LDS the block table may take per workgroup
+// ... and when the on-site blocks are streamed (cheb_sweep3 OS): two workgroups per CU of four waves,
+// each wave with 12 KB of hand-over rows and a 3.75 / 5.25 KB ring of on-site blocks, leave this much
+constexpr size_t kStreamedTableLimit = 10 * 1024;
+
+size_t table_limit(const bdg_system* sys) { return sys->onsite_streamed ? kStreamedTableLimit : kDictLdsLimit; }
 
 // Dictionary kernel if the matrix has few enough distinct blocks for the table to sit in LDS.
 StepKernel dict_kernel(const bdg_system* sys, const ModeInfo& mode, int rl) {
     const char* env = knob::raw("BODGE_AMD_DICT");
     if (env && env[0] == '0') return nullptr;
+    if (sys->onsite_streamed) return nullptr;  // (the table lacks the diagonal blocks: only the three-step sweep can use it)
     if (sys->n_unique <= 0 || (size_t)sys->n_unique * mode.stride * sizeof(double2) > kDictLdsLimit)
         return nullptr;
     if (sys->max_row_blocks <= 3) return dict_for<3>(mode, rl);
@@ -278,6 +284,19 @@ int ensure_blocks(bdg_system* sys, const ModeInfo& mode, const void** out) {
         const int grid = (int)std::min<int64_t>(8192, (total + 255) / 256 + 1);
         bdg::pack_blocks<<<grid, 256, 0, sys->stream>>>(sys->blocks.ptr, buf.ptr, sys->nnzb, entries,
                                                         mode.real ? 1 : 0);
+        HIP_TRY(hipGetLastError());
+    }
+    *out = buf.ptr;
+    return BDG_OK;
+}
+
+// Packed on-site records for the sweep that streams them (kernels.hpp pack_onsite; built once per arithmetic).
+int ensure_onsite(bdg_system* sys, bool real, const double2** out) {
+    DeviceBuffer<double2>& buf = sys->onsite[real ? 1 : 0];
+    if (!buf.ptr) {
+        if (int rc = buf.reserve((size_t)sys->nb * (real ? RealPHMode::kOnsiteSlots : ComplexPHMode::kOnsiteSlots))) return rc;
+        bdg::pack_onsite<<<(unsigned)std::min<int64_t>(4096, (sys->nb + 255) / 256), 256, 0, sys->stream>>>(
+            sys->indptr.ptr, sys->indices.ptr, sys->blocks.ptr, (int)sys->nb, real ? 1 : 0, buf.ptr);
         HIP_TRY(hipGetLastError());
     }
     *out = buf.ptr;
@@ -422,6 +441,16 @@ SweepKernel sweep3_gen_kernel(const ModeInfo& mode, int lanes) {
     return sweep3_gen_kernel_for<ComplexMode>(lanes);
 }
 
+// cheb_sweep3 with streamed on-site blocks: particle-hole modes, 4 lanes per site
+SweepKernel sweep3_streamed_kernel(const ModeInfo& mode, bool reverse, bool gen) {
+    if (!mode.ph) return nullptr;
+    if (mode.real)
+        return gen ? bdg::cheb_sweep3<RealPHMode, 4, false, true, true>
+                   : reverse ? bdg::cheb_sweep3<RealPHMode, 4, true, false, true> : bdg::cheb_sweep3<RealPHMode, 4, false, false, true>;
+    return gen ? bdg::cheb_sweep3<ComplexPHMode, 4, false, true, true>
+               : reverse ? bdg::cheb_sweep3<ComplexPHMode, 4, true, false, true> : bdg::cheb_sweep3<ComplexPHMode, 4, false, false, true>;
+}
+
 SweepKernel sweep3_kernel(const ModeInfo& mode, int lanes, bool reverse) {
     switch (mode.id) {
         case 1: return sweep3_kernel_for<RealMode>(lanes, reverse);
@@ -463,7 +492,7 @@ int ensure_stencil(bdg_system* sys, int* kind) {
                             (int64_t)sys->shape[0] * plane == sys->nb;
         const bool three_d = sys->shape[1] > 1 && sys->shape[2] > 1;
         if (shaped && sys->ncols == sys->nb && sys->n_unique > 0 && sys->n_unique < (int)bdg::kNoBlock &&
-            sys->max_row_blocks <= (three_d ? 7 : 5) && sys->nnzb > 0) {
+            sys->max_row_blocks <= (three_d ? 7 : 5) && sys->nnzb > 0 && !(three_d && sys->onsite_streamed)) {
             if (int rc = sys->stencil.reserve((size_t)sys->nb)) return rc;
             DeviceBuffer<int> bad;
             if (int rc = bad.reserve(3)) return rc;
@@ -478,7 +507,7 @@ int ensure_stencil(bdg_system* sys, int* kind) {
                 else
                     bdg::build_stencil<<<grid, 256, 0, sys->stream>>>(sys->indptr.ptr, sys->dict_ids.ptr,
                                                                        sys->dict_diagonal.ptr, (int)sys->nb, (int)plane,
-                                                                       sys->stencil.ptr, bad.ptr);
+                                                                       sys->onsite_streamed ? 1 : 0, sys->stencil.ptr, bad.ptr);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(host_bad, bad.ptr, 3 * sizeof(int), hipMemcpyDeviceToHost, sys->stream));
                 HIP_TRY(hipStreamSynchronize(sys->stream));
@@ -518,13 +547,21 @@ int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, int* kind
 int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth, SweepPlan* plan) {
     plan->lanes = lanes;
     plan->depth = depth;
-    plan->kernel = depth == 3 ? sweep3_kernel(mode, lanes, false) : sweep_kernel(mode, lanes, false);
-    plan->kernel_reverse = depth == 3 ? sweep3_kernel(mode, lanes, true) : sweep_kernel(mode, lanes, true);
-    plan->kernel_gen = depth == 3 ? sweep3_gen_kernel(mode, lanes) : nullptr;
+    const bool streamed = sys->onsite_streamed;
+    if (streamed && (lanes != 4 || depth != 3 || !mode.ph))
+        return fail(BDG_EINVAL, "streamed on-site blocks need the three-step sweep with 4 lanes per site and particle-hole packed blocks");
+    plan->kernel = streamed ? sweep3_streamed_kernel(mode, false, false)
+                            : depth == 3 ? sweep3_kernel(mode, lanes, false) : sweep_kernel(mode, lanes, false);
+    plan->kernel_reverse = streamed ? sweep3_streamed_kernel(mode, true, false)
+                                    : depth == 3 ? sweep3_kernel(mode, lanes, true) : sweep_kernel(mode, lanes, true);
+    plan->kernel_gen = streamed ? sweep3_streamed_kernel(mode, false, true) : depth == 3 ? sweep3_gen_kernel(mode, lanes) : nullptr;
     if (!plan->kernel) return fail(BDG_EINVAL, "the sweep kernel has 1, 2 or 4 lanes per site, not %d", lanes);
     const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
-    if (table > kDictLdsLimit) return fail(BDG_EINVAL, "block table too large for the sweep kernel");
-    const size_t rows = (size_t)bdg::kSweepWaves * depth * bdg::kWave * 4 * sizeof(double2);
+    if (table > table_limit(sys)) return fail(BDG_EINVAL, "block table too large for the sweep kernel");
+    size_t rows = (size_t)bdg::kSweepWaves * depth * bdg::kWave * 4 * sizeof(double2);
+    if (streamed)  // ring of three planes of on-site records per wave
+        rows += (size_t)bdg::kSweepWaves * 3 * (bdg::kWave / lanes) *
+                (mode.real ? RealPHMode::kOnsiteStride : ComplexPHMode::kOnsiteStride) * sizeof(double2);
     plan->lds_bytes = table + rows;
     if (plan->lds_bytes > 64 * 1024)
         for (SweepKernel k : {plan->kernel, plan->kernel_reverse, plan->kernel_gen})
@@ -540,6 +577,8 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     a = bdg::SweepArgs{};
     a.stencil = sys->stencil.ptr;
     if (int rc = ensure_dict_table(sys, mode, &a.dict_table)) return rc;
+    if (streamed)
+        if (int rc = ensure_onsite(sys, mode.real, &a.onsite)) return rc;
     a.n_unique = sys->n_unique;
     a.nb = (int)sys->nb;
     a.plane = (int)plane;
@@ -564,8 +603,11 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
 // Algorithmic HBM bytes of one two-step sweep: one 8-byte stencil word per site, the block table
 // once, and four passes over 4 x RL 16-byte payloads per site (read t_n, t_{n-1}; write t_{n+1},
 // t_{n+2}).  The halo slots and segment-end planes the waves recompute are NOT counted.
+// With streamed on-site blocks each site adds its packed record (64 B real / 96 B complex), read once.
 double sweep_bytes(const bdg_system* sys, const ModeInfo& mode, int lanes) {
-    return 8.0 * (double)sys->nb + (mode.block_bytes - 4.0) * sys->n_unique +
+    const double onsite = !sys->onsite_streamed ? 0.0
+                          : 16.0 * (mode.real ? RealPHMode::kOnsiteSlots : ComplexPHMode::kOnsiteSlots);
+    return (8.0 + onsite) * (double)sys->nb + (mode.block_bytes - 4.0) * sys->n_unique +
            4.0 * (4.0 * lanes * sizeof(double2)) * (double)sys->nb;
 }
 
@@ -576,7 +618,8 @@ double sweep_bytes(const bdg_system* sys, const ModeInfo& mode, int lanes) {
 // first streams from that cache instead of HBM.  BODGE_AMD_SWEEP_LANES overrides.
 // Steps per sweep: 3 (cheb_sweep3, 4 lanes per site only) moves 4/9 of the one-step kernels'
 // bytes against 2/3 for 2.  BODGE_AMD_SWEEP_STEPS=2|3 overrides.
-int sweep_depth_for(int lanes) {
+int sweep_depth_for(const bdg_system* sys, int lanes) {
+    if (sys->onsite_streamed) return 3;  // (the only form that streams on-site blocks)
     int depth = lanes >= 2 ? 3 : 2;
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_STEPS")) {
         const int forced = atoi(env);
@@ -590,6 +633,7 @@ int sweep_depth_for(int lanes) {
 // shorter x-segments.  Measured on 1000x1000, 8 real vectors: 2 lanes 106.6 k vector-steps/s,
 // 4 lanes 99.9 k (profiles/r02_sweep_experiments.log).
 int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane) {
+    if (sys->onsite_streamed) return 4;  // 16 site slots per wave: the ring of on-site records fits beside the rows
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_LANES")) {
         const int forced = atoi(env);
         if (forced == 1 || forced == 2 || forced == 4) return forced;

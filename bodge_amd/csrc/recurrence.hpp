@@ -71,7 +71,8 @@ struct Batch {
             if (int rc = sweep_wanted(sys, start.kind == StartKind::Random, col_scalars, &stencil_kind)) return rc;
         // (the stencil kernels keep the whole block table in LDS; a matrix with many distinct blocks in a
         // wide arithmetic mode can exceed that: it takes the one-step kernels, which then stream its blocks)
-        if ((size_t)sys->n_unique * mode.stride * sizeof(double2) > kDictLdsLimit) stencil_kind = 0;
+        if ((size_t)sys->n_unique * mode.stride * sizeof(double2) > table_limit(sys)) stencil_kind = 0;
+        if (sys->onsite_streamed && !mode.ph) stencil_kind = 0;  // (packed on-site records assume the Nambu form)
         if (stencil_kind == 1) {
             const int lanes = sweep_lanes_for(sys, n_active, per_lane);
             if (n_active <= lanes * per_lane) {
@@ -102,7 +103,7 @@ struct Batch {
             plan.mode = mode;
             plan.dictionary = true;
             args = bdg::StepArgs{};
-            if (int rc = make_sweep_plan(sys, mode, rl, sweep_depth_for(rl), &splan)) return rc;
+            if (int rc = make_sweep_plan(sys, mode, rl, sweep_depth_for(sys, rl), &splan)) return rc;
         } else if (roll) {
             // (as for the sweeps: no one-step plan; the table was seen to fit its LDS budget above)
             plan = StepPlan{};
@@ -545,6 +546,7 @@ struct Batch {
         p.steps_per_launch = sweep ? splan.depth : 1;
         p.rolling = roll ? 1 : 0;
         p.dict_skipped = sys->dict_skipped;
+        p.onsite_streamed = sweep && sys->onsite_streamed ? 1 : 0;
         p.lanes_per_row = rl;
         p.vectors_per_launch = rv;
         p.real_arithmetic = real ? 1 : 0;

@@ -55,6 +55,7 @@ struct SweepArgs {
                              // (bytes 0..4 of the 8-byte word, kNoBlock = not stored)
     const void* dict_table;  // the distinct blocks, packed for the mode
     int n_unique;
+    const double2* onsite;   // cheb_sweep3<..., OS>: packed on-site block of every row (Mode::kOnsiteSlots x 16 B)
     const double2* cur;      // t_n
     const double2* prev;     // t_{n-1}; nullptr = zero (first sweep of a run: t_{-1} = 0 is not read)
     double2* out1;           // t_{n+1}
@@ -91,8 +92,10 @@ struct SweepArgs {
 // position 0 inside a plane, plane lx-1 <-> plane 0) are the same neighbours seen across the
 // seam; they take the slots of the -1 / +1 / -P / +P neighbours they are, and bad[1] / bad[2]
 // tell the kernels to close the plane / the stack of planes into rings.
+// `onsite_streamed`: the words of the diagonal blocks carry no table id (the sweep reads those blocks
+// from the per-site stream); their slot is only marked present.
 __global__ void build_stencil(const int* __restrict__ indptr, const int* __restrict__ words,
-                              const int* __restrict__ diagonal, int nb, int plane,
+                              const int* __restrict__ diagonal, int nb, int plane, int onsite_streamed,
                               uint2* __restrict__ stencil, int* __restrict__ bad) {
     const int lx = nb / plane;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
@@ -123,6 +126,7 @@ __global__ void build_stencil(const int* __restrict__ indptr, const int* __restr
                 atomicOr(bad + 2, 1);
             }
             if (slot < 0 || (w >> 24) == kNoBlock) ok = false;
+            else if (onsite_streamed && slot == 2) id[slot] = 0;
             else {
                 id[slot] = w >> 24;
                 if (diagonal[w >> 24]) mask |= 1u << slot;
@@ -393,25 +397,49 @@ constexpr int sweep3_owned(int rl) { return kWave / rl - 6; }
 // a pure function of (seed, vector, scalar row) (K3), so the sweep makes the planes of t_0 it needs
 // in registers - the halo slots and segment-end planes included - and the 128 MB of t_0 are neither
 // written by a fill kernel nor read back: a 40-moment call (7 sweeps per lane group) is 7 % shorter.
-template <typename Mode, int RL, bool REV, bool GEN = false>
+//
+// OS ("on-site blocks streamed"): position-dependent on-site terms - a disorder potential, a
+// self-consistent gap, a magnetic texture (reference hamiltonian.py:102-118 filled per site) - make
+// every diagonal block distinct and defeat the dictionary, while the bond blocks still come from a
+// handful of distinct ones.  Then only the bonds sit in the LDS table; the diagonal block of every
+// site is read from a per-site stream in HBM exactly once per launch (Mode::kOnsiteSlots x 16 B,
+// non-temporal, whole-wave contiguous loads one plane ahead of their first use) into a wave-private
+// LDS ring of three planes, because step j of iteration k works on plane k-j+1: plane k's blocks
+// serve step 1 now, step 2 in the next iteration and step 3 in the one after.  Only with 4 lanes
+// per site (16 slots: the ring is 3 x 16 x kOnsiteStride slots per wave) and the particle-hole modes.
+template <typename Mode, bool OS>
+constexpr int sweep3_ring_slots(int slots) {
+    if constexpr (OS) return 3 * slots * Mode::kOnsiteStride;
+    else return 0;
+}
+template <typename Mode, bool OS>
+constexpr int sweep3_onsite_pieces() {
+    if constexpr (OS) return Mode::kOnsiteSlots;
+    else return 0;
+}
+
+template <typename Mode, int RL, bool REV, bool GEN = false, bool OS = false>
 __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
     extern __shared__ double2 lds[];
     constexpr int SLOTS = kWave / RL;
     constexpr int OWNED3 = SLOTS - 6;
     constexpr int SPB = Mode::kSlotsPerBlock;
     constexpr int STRIDE = Mode::kBlockStride;
+    constexpr int RING = sweep3_ring_slots<Mode, OS>(SLOTS);  // LDS slots of the on-site ring (0 without OS)
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int s = lane / RL;
     const int r = lane % RL;
 
-    // LDS: [table][per wave: three rows of 64 lanes x 4 entries: level 0 plane k, level 1 plane k-1, level 2 plane k-2]
+    // LDS: [table][per wave: three rows of 64 lanes x 4 entries: level 0 plane k, level 1 plane k-1, level 2 plane k-2;
+    //               OS: + ring of three planes of on-site blocks]
     const double2* table = static_cast<const double2*>(a.dict_table);
     for (int e = threadIdx.x; e < a.n_unique * SPB; e += kBlockThreads)
         lds[(e / SPB) * STRIDE + (e % SPB)] = table[e];
-    double2* row_0 = lds + a.n_unique * STRIDE + wave * (3 * kWave * 4);
+    double2* row_0 = lds + a.n_unique * STRIDE + wave * (3 * kWave * 4 + RING);
     double2* row_1 = row_0 + kWave * 4;
     double2* row_2 = row_1 + kWave * 4;
+    [[maybe_unused]] double2* os_ring = row_2 + kWave * 4;
     __syncthreads();
 
     const int n_units = a.n_cols * a.n_segs;
@@ -523,8 +551,13 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
         };
         // acc = Σ_offsets block * x in CSR order (-P, -1, 0, +1, +P); `before` / `after` are the planes
         // behind / ahead of the march, `mid` the lane's own entries, `row` the hand-over row of the level
+        // step j (1-based) runs on plane k-j+1 and is needed on planes [x0-(steps-j), x1+(steps-j))
+        const int k_first = x0 - (steps - 1), k_last = x1 + steps - 2;
+        [[maybe_unused]] auto ring_entry = [&](int kk) { return os_ring + ((kk - k_first) % 3) * (RING / 3); };
+
+        // (`kk` = marching index of the plane the step works on: selects the ring entry of its on-site blocks)
         auto apply = [&](uint2 w, const double2 before[4], const double2* row, const double2 mid[4],
-                         const double2 after[4], double2 acc[4]) {
+                         const double2 after[4], double2 acc[4], [[maybe_unused]] int kk) {
             double2 x[4];
             if (rev) mac(w, 0, after, acc);
             else mac(w, 0, before, acc);
@@ -533,7 +566,11 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
                 for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane - RL, be)];
                 mac(w, 1, x, acc);
             }
-            mac(w, 2, mid, acc);
+            if constexpr (OS) {
+                if (id_of(w, 2) != kNoBlock) Mode::mac_onsite(acc, ring_entry(kk) + s * Mode::kOnsiteStride, mid);
+            } else {
+                mac(w, 2, mid, acc);
+            }
             if (id_of(w, 3) != kNoBlock) {
 #pragma unroll
                 for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane + RL, be)];
@@ -543,8 +580,37 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
             else mac(w, 4, after, acc);
         };
 
-        // step j (1-based) runs on plane k-j+1 and is needed on planes [x0-(steps-j), x1+(steps-j))
-        const int k_first = x0 - (steps - 1), k_last = x1 + steps - 2;
+        // OS: the wave's window of on-site records of one plane is contiguous in memory (SLOTS x
+        // kOnsiteSlots 16-byte pieces; with periodic planes the halo slots wrap, so the address is
+        // taken per piece): piece e of the window belongs to slot e / kOnsiteSlots.
+        constexpr int OSL = OS ? (SLOTS * sweep3_onsite_pieces<Mode, OS>() + kWave - 1) / kWave : 1;  // pieces per lane
+        [[maybe_unused]] auto load_onsite = [&](int k, bool wanted, double2 out[OSL]) {
+            if constexpr (OS) {
+                constexpr int PIECES = Mode::kOnsiteSlots;
+                k = ring(act(k));
+#pragma unroll
+                for (int j = 0; j < OSL; ++j) {
+                    const int e = lane + j * kWave, slot = e / PIECES, part = e - slot * PIECES;
+                    const int pe = col * OWNED3 - 3 + slot;
+                    const bool in_e = pe >= 0 && pe < a.plane;
+                    const int pwe = in_e ? pe : ((pe % a.plane) + a.plane) % a.plane;
+                    out[j] = zero;
+                    if (wanted && slot < SLOTS && (in_e || a.wrap_p) && k >= 0 && k < a.lx)
+                        out[j] = load_stream(a.onsite + ((size_t)k * a.plane + pwe) * PIECES + part);
+                }
+            }
+        };
+        [[maybe_unused]] auto put_onsite = [&](int kk, const double2 v[OSL]) {
+            if constexpr (OS) {
+                constexpr int PIECES = Mode::kOnsiteSlots;
+                double2* dst = ring_entry(kk);
+#pragma unroll
+                for (int j = 0; j < OSL; ++j) {
+                    const int e = lane + j * kWave, slot = e / PIECES, part = e - slot * PIECES;
+                    if (slot < SLOTS) dst[slot * Mode::kOnsiteStride + part] = v[j];
+                }
+            }
+        };
 
         // ---- prologue
         // Rolling state.  t_n: `cn_m` = plane k-1; two buffers hold planes k and k+1 and swap roles
@@ -562,11 +628,18 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
         for (int al = 0; al < 4; ++al) c1_m[al] = c2_m[al] = zero;
         put_own(row_1, c1_m);  // the rows still hold the previous unit's planes
         put_own(row_2, c1_m);
+        if constexpr (OS) {  // on-site blocks of the first plane (the later ones arrive one iteration ahead)
+            double2 first_os[OSL];
+            load_onsite(k_first, true, first_os);
+            put_onsite(k_first, first_os);
+        }
 
         // one iteration: `centre` holds plane k on entry and plane k+2 (in flight) on exit, `after` plane k+1
         auto iterate = [&](int k, double2 (&centre)[4], const double2 (&after)[4]) {
             const bool more = k < k_last;
             const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFu);
+            [[maybe_unused]] double2 nx_os[OSL];
+            load_onsite(k + 1, more, nx_os);
             put_own(row_0, centre);
             wave_sync();
             cur_plane(k + 2, valid && more, centre);
@@ -580,7 +653,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
 #pragma unroll
                 for (int al = 0; al < 4; ++al) acc[al] = zero;
                 own_of(row_0, mid);
-                apply(ids_0, cn_m, row_0, mid, after, acc);
+                apply(ids_0, cn_m, row_0, mid, after, acc, k);
 #pragma unroll
                 for (int al = 0; al < 4; ++al) {
                     new1[al].x = fma(a.coef1, acc[al].x, -pv[al].x);
@@ -601,7 +674,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
 #pragma unroll
                 for (int al = 0; al < 4; ++al) acc[al] = zero;
                 own_of(row_1, mid);
-                apply(ids_1, c1_m, row_1, mid, new1, acc);
+                apply(ids_1, c1_m, row_1, mid, new1, acc, k - 1);
 #pragma unroll
                 for (int al = 0; al < 4; ++al) {
                     new2[al].x = fma(a.coef2, acc[al].x, -cn_m[al].x);
@@ -621,7 +694,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
 #pragma unroll
                 for (int al = 0; al < 4; ++al) acc[al] = zero;
                 own_of(row_2, mid);
-                apply(ids_2, c2_m, row_2, mid, new2, acc);
+                apply(ids_2, c2_m, row_2, mid, new2, acc, k - 2);
 #pragma unroll
                 for (int al = 0; al < 4; ++al) {
                     new3[al].x = fma(a.coef2, acc[al].x, -c1_m[al].x);
@@ -639,6 +712,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
             wave_sync();
             put_own(row_1, new1);  // level 1, plane k
             put_own(row_2, new2);  // level 2, plane k-1
+            put_onsite(k + 1, nx_os);  // (OS) takes the ring entry of plane k-2, which step 3 has just finished with
             ids_2 = ids_1;
             ids_1 = ids_0;
             ids_0 = nx_ids;

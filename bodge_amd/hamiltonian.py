@@ -202,6 +202,10 @@ class Hamiltonian:
         self._device_revision = -1
         self._memo: dict = {}
         self._recheck_all = False  # set when a Hermiticity check failed: the next one covers everything
+        # Where the Hermiticity test of a closing `with` block runs: "auto" = on the GPU for large
+        # fills when one is present, "host" = always on the host (a process that must not touch the
+        # GPU yet, e.g. before forking CPU workers), "device" = always on the GPU.
+        self.hermiticity_check = "auto"
         self._memo_revision = -1
 
     @property
@@ -292,7 +296,10 @@ class Hamiltonian:
         # unless that earlier check failed and left the matrix in a non-Hermitian state.
         touched = touched.view(bool)
         everything = self._recheck_all or bool(touched.all())
-        if int(np.count_nonzero(touched)) >= DEVICE_HERMITICITY_MIN_BLOCKS and _gpu_present():
+        if self.hermiticity_check not in ("auto", "host", "device"):
+            raise ValueError("hermiticity_check must be 'auto', 'host' or 'device'")
+        large = int(np.count_nonzero(touched)) >= DEVICE_HERMITICITY_MIN_BLOCKS
+        if self.hermiticity_check == "device" or (self.hermiticity_check == "auto" and large and _gpu_present()):
             # large fills: the matrix goes to the GPU now (the observables need it there anyway)
             # and is compared with its conjugate transpose on the device, block against block
             defect = self._solver().hermiticity_defect()

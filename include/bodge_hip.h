@@ -59,10 +59,15 @@ typedef struct bdg_perf {
     int32_t strip_rows;    /* strip width of the tile order in block rows, 0 = natural order */
     int32_t ph_packed;     /* 1 = particle-hole packed blocks (12 of 16 entries stored)      */
     int32_t dict_blocks;   /* >0 = dictionary form: number of distinct blocks in the table   */
-    int32_t steps_per_launch; /* 2 = two recurrence steps per sweep of the vectors (lattice stencils), else 1 */
+    int32_t steps_per_launch; /* recurrence steps one launch makes: 3 or 2 = multi-step sweeps of a 2-D lattice
+                                 stencil (cheb_sweep3 / cheb_sweep), else 1 */
     int32_t rolling;       /* 1 = 3-D stencil kernel with the x-neighbours in registers (cheb_roll3) */
     int32_t dict_skipped;  /* why the matrix has no block dictionary: 0 = it has one, 1 = more than 256
                               distinct blocks, 2 = more than 2^24 block columns, 3 = BODGE_AMD_DICT=0 */
+    int32_t onsite_streamed; /* 1 = position-dependent on-site blocks: the diagonal block of every site is
+                                streamed from HBM once per launch, only the bond blocks sit in the table
+                                (dict_blocks then counts the distinct bond blocks)                      */
+    int32_t reserved;      /* keeps the struct a multiple of 8 bytes */
 } bdg_perf;
 
 const char* bdg_last_error(void);
@@ -245,6 +250,15 @@ int bdg_set_lattice_shape(bdg_system* sys, int32_t lx, int32_t ly, int32_t lz);
 
 /* Tuning override for experiments: lanes per block row (0 = automatic). */
 int bdg_set_lanes_per_row(bdg_system* sys, int32_t lanes);
+
+/*
+ * Process-wide override of one of the library's run-time switches (the BODGE_AMD_* names listed
+ * in csrc/knobs.hpp and DESIGN.md's appendix): `value` replaces what the environment variable of
+ * that name says, value = NULL removes the override.  Thread safe, unlike setenv() next to the
+ * getenv() of a running call; tests and bench.py select kernel forms this way.  The defaults
+ * are the product: nothing needs to be set in normal use.
+ */
+int bdg_set_option(const char* name, const char* value);
 
 /*
  * RCCL communicator, one rank per process/GPU.  Rank 0 calls

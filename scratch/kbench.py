@@ -6,8 +6,8 @@ import os, sys, time
 sys.path.insert(0, ".")
 import numpy as np
 import bench
-from bodge_amd import chebyshev
-from bodge_amd.solver import DeviceSolver
+from bodge_amd import backend, chebyshev
+from bodge_amd.solver import DeviceSolver, VEC_RADEMACHER, VEC_Z4
 
 args = [a for a in sys.argv[1:] if not a.startswith("--")]
 opts = dict(zip(sys.argv[1:], sys.argv[2:]))
@@ -16,6 +16,7 @@ vectors = int(opts.get("--vectors", "8"))
 rounds = int(opts.get("--rounds", "5"))
 steps = int(opts.get("--steps", "40"))
 model = opts.get("--model", "swave")
+kind = VEC_Z4 if opts.get("--kind", "rademacher") == "z4" else VEC_RADEMACHER
 variants = []
 for a in args:
     name, _, envs = a.partition("=")
@@ -28,15 +29,13 @@ solver.set_lattice_shape(shape)
 results = {name: [] for name, _ in variants}
 for rnd in range(rounds + 1):
     for name, env in variants:
-        for k, v in env.items():
-            os.environ[k] = v
-        solver.dots_random(scale, steps, vectors, seed=rnd)
-        p = solver.perf()
-        for k in env:
-            del os.environ[k]
+        with backend.options(**env):
+            solver.dots_random(scale, steps, vectors, seed=rnd, kind=kind)
+            p = solver.perf()
         if rnd:
             results[name].append((p["kernel_ms"] / p["launches"], p["bytes_per_launch"], p))
 for name, _ in variants:
     ms = np.array([r[0] for r in results[name]]); b = results[name][0][1]; p = results[name][0][2]
     print(f"{name:28s} median {np.median(ms):.4f} ms  min {ms.min():.4f}  -> {b/np.median(ms)/1e6:7.1f} GB/s (best {b/ms.min()/1e6:7.1f})"
-          f"  grid {p['grid']} lds {p['lds_bytes']} rl {p['lanes_per_row']} real {p['real_arithmetic']} pipe {p['pipelined']}")
+          f"  grid {p['grid']} lds {p['lds_bytes']} rl {p['lanes_per_row']} real {p['real_arithmetic']} pipe {p['pipelined']}"
+          f" steps/launch {p['steps_per_launch']} onsite {p['onsite_streamed']} -> {vectors * p['steps_per_launch'] / np.median(ms) :.1f} k vector-steps/s")

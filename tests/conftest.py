@@ -61,6 +61,41 @@ def hip_library():
     return backend.load()
 
 
+class Knobs:
+    """Run-time switches of the library for one test, through `bdg_set_option` (a process-wide
+    override table inside the library) and never through `os.environ`: `setenv` next to the
+    `getenv` of a library call running on another host thread is undefined behaviour."""
+
+    def __init__(self):
+        from bodge_amd import backend
+
+        self._backend = backend
+        self._names = set()
+
+    def set(self, name, value):
+        self._backend.set_option(name, value)
+        self._names.add(name)
+
+    def unset(self, name):
+        self._backend.set_option(name, None)
+        self._names.discard(name)
+
+    def update(self, values):
+        for name, value in values.items():
+            self.set(name, value)
+
+    def clear(self):
+        for name in list(self._names):
+            self.unset(name)
+
+
+@pytest.fixture
+def knobs(hip_library):
+    table = Knobs()
+    yield table
+    table.clear()
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _dense_library_prefetch(request):
     """On a GPU box, start reading the 931 MB rocSOLVER object at session start (background file

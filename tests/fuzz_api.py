@@ -8,19 +8,16 @@ import numpy as np
 import bodge_amd as ba
 import systems
 from oracle import dense_ref, cheb_ref
+from bodge_amd import backend
 from bodge_amd.solver import DeviceSolver
 
 def run(seed: int = 0, n_cases: int = 100, size: str | None = None, lanczos: bool = True) -> int:
-    """Returns the number of failing cases (each printed).  Environment switches set on the way are undone."""
-    saved = dict(os.environ)
-    try:
-        import warnings
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            return _run(seed, n_cases, size, lanczos)
-    finally:
-        os.environ.clear()
-        os.environ.update(saved)
+    """Returns the number of failing cases (each printed).  Library switches are set through
+    backend.options (bdg_set_option) and removed again, never through os.environ."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return _run(seed, n_cases, size, lanczos)
 
 
 def _run(seed, n_cases, size, lanczos) -> int:
@@ -124,9 +121,8 @@ def _run(seed, n_cases, size, lanczos) -> int:
             alone = system.ldos(other, energies)
             check(both.shape == (3, len(energies)) and np.allclose(both[0], got, rtol=1e-10, atol=1e-12) and np.allclose(both[2], got, rtol=1e-10, atol=1e-12)
                   and np.allclose(both[1], alone, rtol=1e-10, atol=1e-12), "ldos multi-site", case, f"{tag} {site} {other}")
-            os.environ["BODGE_AMD_NO_BAND"] = "1"
-            whole = system.ldos(site, energies)
-            del os.environ["BODGE_AMD_NO_BAND"]
+            with backend.options(BODGE_AMD_NO_BAND="1"):
+                whole = system.ldos(site, energies)
             check(np.allclose(whole, got, rtol=1e-10, atol=1e-12), "ldos band-limited vs whole", case, f"{tag} {np.abs(whole - got).max()}")
         # slab group vs whole
         if shape[0] >= 4:

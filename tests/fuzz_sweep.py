@@ -5,20 +5,16 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests")]  # (also importable outside pytest)
 import numpy as np
 import bodge_amd as ba
-from bodge_amd import chebyshev
+from bodge_amd import backend, chebyshev
 from bodge_amd.solver import DeviceSolver, VEC_RADEMACHER, VEC_Z4
 
 def run(seed: int = 0, n_cases: int = 100, size: str | None = None, lanczos: bool = True) -> int:
-    """Returns the number of failing cases (each printed).  Environment switches set on the way are undone."""
-    saved = dict(os.environ)
-    try:
-        import warnings
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            return _run(seed, n_cases, size, lanczos)
-    finally:
-        os.environ.clear()
-        os.environ.update(saved)
+    """Returns the number of failing cases (each printed).  Library switches are set through
+    backend.options (bdg_set_option) and removed again, never through os.environ."""
+    import warnings
+    with warnings.catch_warnings():
+        warnings.simplefilter("ignore")
+        return _run(seed, n_cases, size, lanczos)
 
 
 def _run(seed, n_cases, size, lanczos) -> int:
@@ -65,13 +61,11 @@ def _run(seed, n_cases, size, lanczos) -> int:
         disorder_has_dict = True
         with DeviceSolver(indptr, indices, data) as dev:
             dev.set_lattice_shape(shape)
-            os.environ["BODGE_AMD_SWEEP"] = "0"
-            one = dev.dots_random(scale, steps, vectors, seed=case, kind=kind)
-            os.environ["BODGE_AMD_SWEEP"] = "1"
-            os.environ.update(env)
-            got = dev.dots_random(scale, steps, vectors, seed=case, kind=kind)
-            perf = dev.perf()
-            for k in env: del os.environ[k]
+            with backend.options(BODGE_AMD_SWEEP="0"):
+                one = dev.dots_random(scale, steps, vectors, seed=case, kind=kind)
+            with backend.options(BODGE_AMD_SWEEP="1", **env):
+                got = dev.dots_random(scale, steps, vectors, seed=case, kind=kind)
+                perf = dev.perf()
         n = 4 * lat.size
         err = max(np.abs(got[0] - one[0]).max(), np.abs(got[1] - one[1]).max()) / n
         tag = f"case {case}: {shape} {model} steps={steps} vectors={vectors} kind={kind} {env} -> steps/launch {perf['steps_per_launch']} rolling {perf['rolling']}"

@@ -39,13 +39,12 @@ def big(api, hip_library):
 
 
 def _with_env(solver, env, *args, **kwargs):
-    os.environ.update(env)
-    try:
+    """dots_random under library switches (set through bdg_set_option for the call, not os.environ)."""
+    from bodge_amd import backend
+
+    with backend.options(**env):
         out = solver.dots_random(*args, **kwargs)
         return out, solver.perf()
-    finally:
-        for k in env:
-            del os.environ[k]
 
 
 def test_first_steps_match_oracle_at_full_size(big):
@@ -309,6 +308,101 @@ def test_complex_hamiltonian_at_full_size(api, hip_library):
     for out in (got, streamed):
         assert np.allclose(out[0], ref[0], rtol=0, atol=1e-12 * n) and np.allclose(out[1], ref[1], rtol=0, atol=1e-12 * n)
     assert np.allclose(got[0][0], n, rtol=1e-15)  # |v|^2 = 4N exactly for Z4 vectors
+
+
+def test_complex_hamiltonian_full_length_at_full_size(api, hip_library):
+    """The reference's own dtype on the headline kernel, at full size AND full length: the Peierls-phase
+    matrix of the test above (1000 x 1000, H_ij = -e^{±iφ} σ0 on the x bonds), M = 512, 4 Z4 vectors.
+    Default route = cheb_sweep3<ComplexPHMode> (three steps per sweep, complex arithmetic), then the
+    one-step dictionary and streamed kernels; every d_n, e_n against the C/OpenMP restatement in
+    complex arithmetic on the same vectors (itself pinned to the numpy/scipy restatement on 2 vectors
+    x 8 steps) within 1e-12 * 4N, F within 1e-10 relative (F as ref hamiltonian.py:305-321)."""
+    from bodge_amd import chebyshev
+    from bodge_amd.solver import DeviceSolver
+    from oracle import cheb_c
+
+    lattice = api.CubicLattice((1000, 1000, 1))
+    system = api.Hamiltonian(lattice)
+    pairs = lattice.bond_array(axis=0, coords=True)
+    phase = np.where(pairs[:, 1, 0] > pairs[:, 0, 0], np.exp(0.3j), np.exp(-0.3j))
+    with system as (H, Δ):
+        H.set_sites(3.0 * api.σ0 - 0.05 * api.σ3)
+        Δ.set_sites(-0.1 * api.jσ2)
+        H.set_bonds(-phase[:, None, None] * api.σ0, axis=0)
+        H.set_bonds(-1.0 * api.σ0, axis=1)
+    indptr, indices, data = system.bsr_arrays()
+    scale = chebyshev.spectral_bound(indptr, data)
+    bsr = system.matrix("bsr")
+    n, moments, vectors, temperature = bsr.shape[0], 512, 4, 0.5
+    start = cheb_ref.random_block(n, 3, range(vectors), cheb_ref.VEC_Z4)
+    d2, e2 = cheb_ref.recurrence_dots(bsr, scale, 16, start[:, :2])
+    cheb_c.set_threads(min(16, os.cpu_count() or 1))
+    d_ref, e_ref = cheb_c.recurrence_dots(bsr, scale, moments, start, real=False)
+    assert np.allclose(d_ref[:8, :2], d2, rtol=0, atol=1e-12 * n) and np.allclose(e_ref[:8, :2], e2, rtol=0, atol=1e-12 * n)
+    f_ref = chebyshev.free_energy_series(chebyshev.dots_to_moments(d_ref, e_ref).mean(axis=1), scale, temperature)
+    with DeviceSolver(indptr, indices, data) as solver:
+        solver.set_lattice_shape(lattice.shape)
+        for env, expect in [({}, {"steps_per_launch": 3}),
+                            ({"BODGE_AMD_SWEEP": "0"}, {"steps_per_launch": 1, "pipelined": 0}),
+                            ({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0"}, {"steps_per_launch": 1, "dict_blocks": 0})]:
+            (d, e), perf = _with_env(solver, env, scale, moments // 2, vectors, seed=3, kind=cheb_ref.VEC_Z4)
+            assert perf["real_arithmetic"] == 0 and all(perf[k] == v for k, v in expect.items()), (env, perf)
+            assert (perf["dict_blocks"] > 0) == ("BODGE_AMD_DICT" not in env)
+            assert np.abs(d - d_ref).max() <= 1e-12 * n and np.abs(e - e_ref).max() <= 1e-12 * n, env
+            f_gpu = chebyshev.free_energy_series(chebyshev.dots_to_moments(d, e).mean(axis=1), scale, temperature)
+            assert abs(f_gpu - f_ref) <= 1e-10 * abs(f_ref), env
+
+
+@pytest.mark.parametrize("kind", ["potential", "texture"])
+def test_position_dependent_onsite_terms_full_length_at_full_size(api, hip_library, kind):
+    """1000 x 1000 with a different on-site block at every site (10^6 distinct blocks - no dictionary),
+    M = 512: the three-step sweep that streams the on-site blocks (cheb_sweep3 OS, sweep.hpp) against
+    the C/OpenMP restatement on the same vectors, every d_n, e_n within 1e-12 * 4N and F within 1e-10
+    relative; then the one-step streamed-blocks kernel, same gate.  "potential": random potential and
+    gap amplitude, real arithmetic, 8 Rademacher vectors; "texture": an exchange field whose direction
+    varies from site to site (σ1, σ2, σ3 components: complex blocks), 4 Z4 vectors."""
+    from bodge_amd import chebyshev
+    from bodge_amd.solver import DeviceSolver
+    from oracle import cheb_c
+
+    lattice = api.CubicLattice((1000, 1000, 1))
+    system = api.Hamiltonian(lattice)
+    rng = np.random.default_rng(11)
+    sites = lattice.size
+    with system as (H, Δ):
+        if kind == "potential":
+            H.set_sites((3.0 + rng.uniform(-0.5, 0.5, sites))[:, None, None] * api.σ0 - 0.05 * api.σ3)
+            Δ.set_sites(-rng.uniform(0.05, 0.15, sites)[:, None, None] * api.jσ2)
+        else:
+            th, ph = rng.uniform(0, np.pi, sites)[:, None, None], rng.uniform(0, 2 * np.pi, sites)[:, None, None]
+            H.set_sites(3.0 * api.σ0 - 0.3 * (np.sin(th) * np.cos(ph) * api.σ1 + np.sin(th) * np.sin(ph) * api.σ2 + np.cos(th) * api.σ3))
+            Δ.set_sites(-0.1 * api.jσ2)
+        H.set_bonds(-1.0 * api.σ0)
+    indptr, indices, data = system.bsr_arrays()
+    scale = chebyshev.spectral_bound(indptr, data)
+    bsr = system.matrix("bsr")
+    real = kind == "potential"
+    assert (np.abs(data.imag).max() == 0) == real
+    n, moments, temperature = bsr.shape[0], 512, 0.5
+    vectors, vec_kind = (8, cheb_ref.VEC_RADEMACHER) if real else (4, cheb_ref.VEC_Z4)
+    start = cheb_ref.random_block(n, 4, range(vectors), vec_kind)
+    d2, e2 = cheb_ref.recurrence_dots(bsr, scale, 16, start[:, :2])
+    cheb_c.set_threads(min(16, os.cpu_count() or 1))
+    d_ref, e_ref = cheb_c.recurrence_dots(bsr, scale, moments, start, real=real)
+    assert np.allclose(d_ref[:8, :2], d2, rtol=0, atol=1e-12 * n) and np.allclose(e_ref[:8, :2], e2, rtol=0, atol=1e-12 * n)
+    f_ref = chebyshev.free_energy_series(chebyshev.dots_to_moments(d_ref, e_ref).mean(axis=1), scale, temperature)
+    with DeviceSolver(indptr, indices, data) as solver:
+        solver.set_lattice_shape(lattice.shape)
+        (d, e), perf = _with_env(solver, {}, scale, moments // 2, vectors, seed=4, kind=vec_kind)
+        assert perf["onsite_streamed"] == 1 and perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == 4, perf
+        assert perf["real_arithmetic"] == (1 if real else 0) and perf["dict_blocks"] == 2 and perf["dict_skipped"] == 1
+        assert perf["launches"] == 4 * 21 + 2  # one lane group: four chunks of 63 steps, then 3 + 1
+        (d1, e1), perf1 = _with_env(solver, {"BODGE_AMD_SWEEP": "0"}, scale, moments // 2, vectors, seed=4, kind=vec_kind)
+        assert perf1["onsite_streamed"] == 0 and perf1["steps_per_launch"] == 1 and perf1["dict_blocks"] == 0
+    for got_d, got_e in ((d, e), (d1, e1)):
+        assert np.abs(got_d - d_ref).max() <= 1e-12 * n and np.abs(got_e - e_ref).max() <= 1e-12 * n
+        f_gpu = chebyshev.free_energy_series(chebyshev.dots_to_moments(got_d, got_e).mean(axis=1), scale, temperature)
+        assert abs(f_gpu - f_ref) <= 1e-10 * abs(f_ref)
 
 
 def test_periodic_lattice_at_full_size_sweeps_match_one_step_kernels(api, hip_library):

@@ -19,12 +19,12 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.fixture(autouse=True, params=["dictionary", "streamed"])
-def block_storage(request, monkeypatch):
+def block_storage(request, knobs):
     """Every test runs twice: with the block dictionary (used whenever a matrix has few distinct
     blocks, i.e. for most lattice systems here) and with it disabled, so that the streamed
     (pipelined / generic) kernels keep their coverage."""
     if request.param == "streamed":
-        monkeypatch.setenv("BODGE_AMD_DICT", "0")
+        knobs.set("BODGE_AMD_DICT", "0")
     return request.param
 
 
@@ -146,7 +146,7 @@ def test_unit_vector_moments_match_oracle(api, solver_cls):
 
 
 @pytest.mark.parametrize("name,n_vectors", [("dwave8", 5), ("swave20", 8), ("swave20", 64), ("chain128", 3)])
-def test_real_arithmetic_equals_complex_arithmetic(api, solver_cls, monkeypatch, name, n_vectors):
+def test_real_arithmetic_equals_complex_arithmetic(api, solver_cls, knobs, name, n_vectors):
     """imag(H) == 0 and ±1 start vectors select the real-valued kernels; they must agree with
     the complex kernels (forced with BODGE_AMD_REAL=0) and with the oracle."""
     system = _build(api, name)
@@ -158,7 +158,7 @@ def test_real_arithmetic_equals_complex_arithmetic(api, solver_cls, monkeypatch,
         fast = dev.dots_random(scale, steps, n_vectors, seed=4)
         assert dev.perf()["real_arithmetic"] == int(real_h)
         unit_fast = dev.moments_unit(scale, 2 * steps, np.array([1, 6, 11]))
-        monkeypatch.setenv("BODGE_AMD_REAL", "0")
+        knobs.set("BODGE_AMD_REAL", "0")
         slow = dev.dots_random(scale, steps, n_vectors, seed=4)
         assert dev.perf()["real_arithmetic"] == 0
         unit_slow = dev.moments_unit(scale, 2 * steps, np.array([1, 6, 11]))
@@ -187,7 +187,7 @@ def _plain_lattice_system(api, shape, complex_terms):
     ((3, 500, 1), 64, cheb_ref.VEC_Z4, False),          # 4-row tiles, many strips
     ((7, 90, 1), 5, cheb_ref.VEC_RADEMACHER, False),    # generic (RL=4) kernel, 64-row tiles
 ])
-def test_strip_ordered_tiles_do_not_change_results(api, solver_cls, monkeypatch, shape, n_vectors, kind,
+def test_strip_ordered_tiles_do_not_change_results(api, solver_cls, knobs, shape, n_vectors, kind,
                                                     complex_terms):
     """The geometry hint only permutes the order in which row tiles are processed."""
     system = _plain_lattice_system(api, shape, complex_terms)
@@ -199,7 +199,7 @@ def test_strip_ordered_tiles_do_not_change_results(api, solver_cls, monkeypatch,
         natural = dev.dots_random(scale, 12, n_vectors, seed=2, kind=kind)
         assert dev.perf()["strip_rows"] == 0
         dev.set_lattice_shape(shape)
-        monkeypatch.setenv("BODGE_AMD_L2_BUDGET", "4096")  # absurdly small: forces the narrowest strips
+        knobs.set("BODGE_AMD_L2_BUDGET", "4096")  # absurdly small: forces the narrowest strips
         strips = dev.dots_random(scale, 12, n_vectors, seed=2, kind=kind)
         assert 0 < dev.perf()["strip_rows"] < shape[1] * shape[2]
         with pytest.raises(ValueError):
@@ -269,7 +269,7 @@ def _sweep_system(api, shape, kind):
     ((10, 6, 8), "peierls", cheb_ref.VEC_Z4),            # 3-D complex
     ((8, 5, 6), "periodic", cheb_ref.VEC_RADEMACHER),    # 3-D with wrap blocks: falls back
 ])
-def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_cls, monkeypatch, block_storage,
+def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_cls, knobs, block_storage,
                                                                         shape, kind, vec_kind):
     """K7 / K8 (sweep.hpp) forced on small lattices: every d_n, e_n against the CPU oracle and against
     the one-step kernels on the same vectors, for even and odd step counts (the odd tail of a
@@ -297,17 +297,17 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
                                       (1, 3, {}), (2, per_group, {}),  # runs shorter than one sweep
                                       (4, 3, {"BODGE_AMD_NO_DIAGONAL_BLOCKS": "1"})]:  # (read at upload: no effect here, see below)
             ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 5, range(vectors), vec_kind))
-            monkeypatch.setenv("BODGE_AMD_SWEEP", "0")
+            knobs.set("BODGE_AMD_SWEEP", "0")
             one = dev.dots_random(scale, steps, vectors, seed=5, kind=vec_kind)
             assert dev.perf()["steps_per_launch"] == 1
-            monkeypatch.setenv("BODGE_AMD_SWEEP", "1")
+            knobs.set("BODGE_AMD_SWEEP", "1")
             for key, value in extra.items():
-                monkeypatch.setenv(key, value)
+                knobs.set(key, value)
             got = dev.dots_random(scale, steps, vectors, seed=5, kind=vec_kind)
             perf = dev.perf()
             again = dev.dots_random(scale, steps, vectors, seed=5, kind=vec_kind)
             for key in extra:
-                monkeypatch.delenv(key)
+                knobs.unset(key)
             stencil = is_stencil and block_storage == "dictionary"  # (the stencil forms read the block dictionary)
             swept, rolled = stencil and not three_d, stencil and three_d
             lanes = int(extra.get("BODGE_AMD_SWEEP_LANES", 4)) if swept else 4  # (default below 4.5e5 sites: 4 lanes per site)
@@ -331,17 +331,162 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
                 assert np.abs(got[0] - other[0]).max() <= 1e-12 * n and np.abs(got[1] - other[1]).max() <= 1e-12 * n
     # blocks that are diagonal as 4x4 matrices (plain hopping) take a 4-MAC path in K7/K8; with the
     # flag withheld at upload every block takes the general 16-MAC path: same numbers
-    monkeypatch.setenv("BODGE_AMD_NO_DIAGONAL_BLOCKS", "1")
-    monkeypatch.setenv("BODGE_AMD_SWEEP", "1")
+    knobs.set("BODGE_AMD_NO_DIAGONAL_BLOCKS", "1")
+    knobs.set("BODGE_AMD_SWEEP", "1")
     with solver_cls.from_hamiltonian(system) as dev:
         general = dev.dots_random(scale, 6, per_group, seed=5, kind=vec_kind)
-    monkeypatch.delenv("BODGE_AMD_NO_DIAGONAL_BLOCKS")
+    knobs.unset("BODGE_AMD_NO_DIAGONAL_BLOCKS")
     with solver_cls.from_hamiltonian(system) as dev:
         flagged = dev.dots_random(scale, 6, per_group, seed=5, kind=vec_kind)
     assert np.abs(general[0] - flagged[0]).max() <= 1e-13 * n and np.abs(general[1] - flagged[1]).max() <= 1e-13 * n
 
 
-def test_stencil_kernels_step_aside_when_the_block_table_exceeds_lds(api, solver_cls, monkeypatch, block_storage):
+def _position_dependent_system(api, shape, kind, seed=0, periodic=False):
+    """Lattices whose ON-SITE terms differ from site to site (> 256 distinct diagonal blocks) over a
+    few distinct bond blocks - what a disorder potential, a self-consistent gap Δ(r) or a magnetic
+    texture makes of the reference's per-site fills (ref hamiltonian.py:102-118, tests/test_physics.py:
+    342-387): "potential" real, "texture" complex (σ2 component), "gap" real with d-wave bonds."""
+    lattice = api.CubicLattice(shape)
+    system = api.Hamiltonian(lattice)
+    rng = np.random.default_rng(seed)
+    n = lattice.size
+    with system as (H, Δ):
+        if kind == "potential":
+            v = rng.uniform(-0.5, 0.5, n)[:, None, None]
+            g = rng.uniform(0.05, 0.15, n)[:, None, None]
+            H.set_sites((3.0 + v) * api.σ0 - 0.05 * api.σ3)
+            Δ.set_sites(-g * api.jσ2)
+            H.set_bonds(-1.0 * api.σ0)
+        elif kind == "texture":  # exchange field rotating in space: σ1, σ2, σ3 components
+            th, ph = rng.uniform(0, np.pi, n)[:, None, None], rng.uniform(0, 2 * np.pi, n)[:, None, None]
+            H.set_sites(3.0 * api.σ0 - 0.3 * (np.sin(th) * np.cos(ph) * api.σ1 + np.sin(th) * np.sin(ph) * api.σ2 + np.cos(th) * api.σ3))
+            Δ.set_sites(-0.1 * api.jσ2)
+            H.set_bonds(-1.0 * api.σ0, axis=0)
+            axis = 1 if shape[1] > 1 else 2
+            pairs = lattice.bond_array(axis=axis, coords=True)  # directed: a phase one way, its conjugate back
+            hop = np.where(pairs[:, 1, axis] > pairs[:, 0, axis], -0.9 + 0.1j, -0.9 - 0.1j)[:, None, None]
+            H.set_bonds(hop * api.σ0 + 0.05 * api.σ3, axis=axis)
+        elif kind == "gap":
+            pairs = lattice.bond_array(coords=True)
+            v = rng.uniform(-0.5, 0.5, n)[:, None, None]
+            H.set_sites((3.0 + v) * api.σ0)
+            H.set_bonds(-1.0 * api.σ0)
+            Δ.set_bonds(-0.1 * api.dwave()(pairs[:, 0], pairs[:, 1]))
+        else:
+            raise ValueError(kind)
+        if periodic:  # (an axis of extent 1 has its "edge" coincide with the site itself: left alone)
+            for axis in range(3):
+                if shape[axis] > 1:
+                    H.set_edges(-0.8 * api.σ0 + 0.1 * api.σ3, axis=axis)
+    return system
+
+
+@pytest.mark.parametrize("shape,kind,vec_kind,periodic", [
+    ((48, 50, 1), "potential", cheb_ref.VEC_RADEMACHER, False),  # real arithmetic, 8 vectors per launch
+    ((33, 61, 1), "texture", cheb_ref.VEC_Z4, False),            # complex blocks and vectors, odd sizes, ragged window
+    ((40, 37, 1), "gap", cheb_ref.VEC_RADEMACHER, False),        # pairing on the bonds
+    ((30, 1, 44), "potential", cheb_ref.VEC_Z4, False),          # complex vectors on a real matrix, (Lx, 1, Lz)
+    ((30, 32, 1), "potential", cheb_ref.VEC_RADEMACHER, True),   # torus: halo slots wrap, on-site records fetched per piece
+    ((21, 30, 1), "texture", cheb_ref.VEC_Z4, True),
+])
+def test_three_step_sweep_with_streamed_onsite_blocks(api, solver_cls, knobs, block_storage, shape, kind, vec_kind, periodic):
+    """cheb_sweep3<..., OS> (sweep.hpp): matrices with more than 256 distinct blocks whose bonds repeat a
+    few - the bond blocks sit in the LDS table, the diagonal block of every site is streamed once per
+    launch into a three-plane LDS ring.  Every d_n, e_n against the CPU oracle and against the
+    one-step (streamed-blocks) kernels on the same vectors; step counts that end a run on 1, 2 and 3
+    steps, partial lane groups, several batches, both marching directions, GEN on and off."""
+    system = _position_dependent_system(api, shape, kind, periodic=periodic)
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    n = bsr.shape[0]
+    complex_run = vec_kind == cheb_ref.VEC_Z4 or kind == "texture"
+    per_group = 4 if complex_run else 8
+    with solver_cls.from_hamiltonian(system) as dev:
+        for steps, vectors, extra in [(9, per_group, {}), (7, 3, {}), (8, per_group + 3, {"BODGE_AMD_SWEEP_ZIGZAG": "0"}),
+                                      (6, 2, {"BODGE_AMD_ALTERNATE": "0", "BODGE_AMD_SWEEP_SEGMENTS": "3"}),
+                                      (9, per_group, {"BODGE_AMD_SWEEP_GEN": "0"}),
+                                      (1, 3, {}), (2, per_group, {}), (13, 2 * per_group, {"BODGE_AMD_SWEEP_SEGMENTS": "2"})]:
+            ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 5, range(vectors), vec_kind))
+            knobs.set("BODGE_AMD_SWEEP", "0")
+            one = dev.dots_random(scale, steps, vectors, seed=5, kind=vec_kind)
+            perf1 = dev.perf()
+            assert perf1["steps_per_launch"] == 1 and perf1["dict_blocks"] == 0 and perf1["onsite_streamed"] == 0
+            knobs.set("BODGE_AMD_SWEEP", "1")
+            knobs.update(extra)
+            got = dev.dots_random(scale, steps, vectors, seed=5, kind=vec_kind)
+            perf = dev.perf()
+            again = dev.dots_random(scale, steps, vectors, seed=5, kind=vec_kind)
+            for key in extra:
+                knobs.unset(key)
+            if block_storage == "dictionary":
+                assert perf["onsite_streamed"] == 1 and perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == 4, perf
+                assert 0 < perf["dict_blocks"] <= 16 and perf["real_arithmetic"] == (0 if complex_run else 1)
+                assert perf["launches"] == -(-vectors // per_group) * -(-steps // 3)
+            else:  # BODGE_AMD_DICT=0: no dictionary of any kind, one step per launch
+                assert perf["onsite_streamed"] == 0 and perf["steps_per_launch"] == 1
+            assert np.array_equal(got[0], again[0]) and np.array_equal(got[1], again[1])
+            if "BODGE_AMD_SWEEP_GEN" in extra:
+                assert np.array_equal(got[0], first[0]) and np.array_equal(got[1], first[1])
+            if not extra and steps == 9:
+                first = got
+            for other in (ref, one):
+                assert np.abs(got[0] - other[0]).max() <= 1e-12 * n and np.abs(got[1] - other[1]).max() <= 1e-12 * n
+
+
+def test_streamed_onsite_blocks_need_exactly_hermitian_diagonal_blocks_and_few_bond_blocks(api, solver_cls, knobs, block_storage):
+    """The packed on-site record assumes A = A^†, C = B^† to the last bit.  A diagonal block that is
+    Hermitian only to 1e-9 (it passes the reference's 1e-6 test, ref hamiltonian.py:121-122), a missing
+    diagonal block, and bonds with more than 254 distinct blocks: results stay right, and only the
+    middle case may still take the streamed-on-site sweep."""
+    shape = (40, 36, 1)
+    rng = np.random.default_rng(3)
+    n_sites = shape[0] * shape[1]
+    knobs.set("BODGE_AMD_SWEEP", "1")
+
+    def run(system):
+        bsr = system.matrix("bsr")
+        scale = cheb_ref.spectral_bound(bsr)
+        ref = cheb_ref.recurrence_dots(bsr, scale, 14, cheb_ref.random_block(bsr.shape[0], 2, range(4), cheb_ref.VEC_Z4))
+        with solver_cls.from_hamiltonian(system) as dev:
+            got = dev.dots_random(scale, 7, 4, seed=2, kind=cheb_ref.VEC_Z4)
+            perf = dev.perf()
+        assert np.abs(got[0] - ref[0]).max() <= 1e-12 * bsr.shape[0] and np.abs(got[1] - ref[1]).max() <= 1e-12 * bsr.shape[0]
+        return perf
+
+    lattice = api.CubicLattice(shape)
+    v = rng.uniform(-0.5, 0.5, n_sites)[:, None, None]
+    # (a) anti-Hermitian dust on the diagonal blocks: not packable, one-step kernels
+    system = api.Hamiltonian(lattice)
+    with system as (H, Δ):
+        H.set_sites((3.0 + v) * api.σ0 + 1e-9j * api.σ1)
+        Δ.set_sites(-0.1 * api.jσ2)
+        H.set_bonds(-1.0 * api.σ0)
+    perf = run(system)
+    assert perf["onsite_streamed"] == 0 and perf["steps_per_launch"] == 1
+    # (b) a few sites without any on-site term: their diagonal block is not stored at all
+    system = api.Hamiltonian(lattice)
+    with system as (H, Δ):
+        keep = (rng.random(n_sites) > 0.02)[:, None, None]
+        H.set_sites(np.where(keep, (3.0 + v) * api.σ0, 0.0 * api.σ0))
+        Δ.set_sites(np.where(keep, -0.1 * api.jσ2, 0.0 * api.jσ2))
+        H.set_bonds(-1.0 * api.σ0)
+    assert system.bsr_arrays()[1].size < 5 * n_sites - 2 * (shape[0] + shape[1])
+    perf = run(system)
+    assert perf["onsite_streamed"] == (1 if block_storage == "dictionary" else 0)
+    # (c) every bond different as well: nothing to put in a table
+    system = api.Hamiltonian(lattice)
+    with system as (H, Δ):
+        H.set_sites((3.0 + v) * api.σ0)
+        Δ.set_sites(-0.1 * api.jσ2)
+        pairs = lattice.bond_array()  # directed pairs: the hopping must be the same both ways
+        lo, hi = pairs.min(axis=1), pairs.max(axis=1)
+        t = (0.8 + 0.4 * ((lo * 7919 + hi * 104729) % 1009) / 1009.0)[:, None, None]
+        H.set_bonds(-t * api.σ0)
+    perf = run(system)
+    assert perf["onsite_streamed"] == 0 and perf["steps_per_launch"] == 1
+
+
+def test_stencil_kernels_step_aside_when_the_block_table_exceeds_lds(api, solver_cls, knobs, block_storage):
     """192 sites with random on-site terms: 193 distinct blocks - a dictionary, but in complex arithmetic
     its table (13 LDS slots per block) is beyond the 32 KB the kernels give it.  Asked for the stencil
     kernels, such a matrix must take the one-step kernels (found by scratch/fuzz_sweep.py: it raised)."""
@@ -355,7 +500,7 @@ def test_stencil_kernels_step_aside_when_the_block_table_exceeds_lds(api, solver
     bsr = system.matrix("bsr")
     scale = cheb_ref.spectral_bound(bsr)
     n = bsr.shape[0]
-    monkeypatch.setenv("BODGE_AMD_SWEEP", "1")
+    knobs.set("BODGE_AMD_SWEEP", "1")
     with solver_cls.from_hamiltonian(system) as dev:
         for kind, expect_sweep in ((cheb_ref.VEC_Z4, False), (cheb_ref.VEC_RADEMACHER, block_storage == "dictionary")):
             got = dev.dots_random(scale, 7, 5, seed=2, kind=kind)
@@ -365,7 +510,7 @@ def test_stencil_kernels_step_aside_when_the_block_table_exceeds_lds(api, solver
 
 
 @pytest.mark.parametrize("sweep", ["0", "1"])
-def test_batches_of_one_call_enqueued_back_to_back_change_no_bit(api, solver_cls, monkeypatch, sweep):
+def test_batches_of_one_call_enqueued_back_to_back_change_no_bit(api, solver_cls, knobs, sweep):
     """A call with more vectors than one launch carries is cut into batches; whole matrices enqueue
     them back to back (own timing events, own piece of the pinned result buffer) and wait once.
     Same numbers as one batch at a time, for random and for unit starts, ragged last batch included."""
@@ -373,12 +518,12 @@ def test_batches_of_one_call_enqueued_back_to_back_change_no_bit(api, solver_cls
     bsr = system.matrix("bsr")
     scale = cheb_ref.spectral_bound(bsr)
     rows = np.arange(0, 4 * 64 * 48, 97)[:70]  # 70 unit vectors: two batches of the one-step kernels
-    monkeypatch.setenv("BODGE_AMD_SWEEP", sweep)
-    monkeypatch.setenv("BODGE_AMD_BATCH", "32")
+    knobs.set("BODGE_AMD_SWEEP", sweep)
+    knobs.set("BODGE_AMD_BATCH", "32")
     with solver_cls.from_hamiltonian(system) as dev:
         queued = dev.dots_random(scale, 7, 27, seed=3), dev.dots_unit(scale, 6, rows)
         launches = dev.perf()["launches"]
-        monkeypatch.setenv("BODGE_AMD_NO_BATCH_PIPELINE", "1")
+        knobs.set("BODGE_AMD_NO_BATCH_PIPELINE", "1")
         single = dev.dots_random(scale, 7, 27, seed=3), dev.dots_unit(scale, 6, rows)
         assert dev.perf()["launches"] == launches
     for a, b in zip(queued, single):
@@ -393,7 +538,7 @@ def test_batches_of_one_call_enqueued_back_to_back_change_no_bit(api, solver_cls
     ("swave20", 9, cheb_ref.VEC_RADEMACHER),    # real
     ("dwave8", 64, cheb_ref.VEC_RADEMACHER),    # real, 3-D
 ])
-def test_particle_hole_packed_storage_is_exact(api, solver_cls, monkeypatch, name, n_vectors, kind):
+def test_particle_hole_packed_storage_is_exact(api, solver_cls, knobs, name, n_vectors, kind):
     """Blocks built by the Hamiltonian have the form [[A,B],[C,-A*]]; storing 12 of 16 entries
     must give bit-identical dot products (same products, same order)."""
     system = _build(api, name)
@@ -401,13 +546,13 @@ def test_particle_hole_packed_storage_is_exact(api, solver_cls, monkeypatch, nam
     with solver_cls.from_hamiltonian(system) as dev:
         packed = dev.dots_random(scale, 16, n_vectors, seed=3, kind=kind)
         assert dev.perf()["ph_packed"] == 1
-        monkeypatch.setenv("BODGE_AMD_PH", "0")
+        knobs.set("BODGE_AMD_PH", "0")
         full = dev.dots_random(scale, 16, n_vectors, seed=3, kind=kind)
         assert dev.perf()["ph_packed"] == 0
     assert np.array_equal(packed[0], full[0]) and np.array_equal(packed[1], full[1])
 
 
-def test_dictionary_form_matches_streamed_form(api, solver_cls, monkeypatch, block_storage):
+def test_dictionary_form_matches_streamed_form(api, solver_cls, knobs, block_storage):
     """Few distinct blocks -> table in LDS + 8 B per stored block; must agree with the streamed
     kernels to round-off (same products per row; only the cross-workgroup sum order differs)."""
     if block_storage == "streamed":
@@ -420,10 +565,10 @@ def test_dictionary_form_matches_streamed_form(api, solver_cls, monkeypatch, blo
             table = dev.dots_random(scale, 16, n_vectors, seed=3, kind=kind)
             n_unique = dev.perf()["dict_blocks"]
             assert 0 < n_unique < 64, name
-            monkeypatch.setenv("BODGE_AMD_DICT", "0")
+            knobs.set("BODGE_AMD_DICT", "0")
             streamed = dev.dots_random(scale, 16, n_vectors, seed=3, kind=kind)
             assert dev.perf()["dict_blocks"] == 0
-            monkeypatch.delenv("BODGE_AMD_DICT")
+            knobs.unset("BODGE_AMD_DICT")
         assert np.allclose(table[0], streamed[0], rtol=1e-13, atol=0)
         assert np.allclose(table[1], streamed[1], rtol=1e-12, atol=1e-12 * system.shape[0])
     # every block distinct: the dictionary is not built and the streamed kernels run
@@ -1023,11 +1168,11 @@ def test_lowest_eigenpairs_of_a_tiny_matrix(api):
 
 
 @pytest.mark.parametrize("name", ["swave30_zeeman", "peierls30"])
-def test_own_jacobi_kernels_reach_4096_rows(api, golden, monkeypatch, name):
+def test_own_jacobi_kernels_reach_4096_rows(api, golden, knobs, name):
     """Between 4N = 2048 and 4096 the own one-sided Jacobi kernels (16 elements per thread) serve
     for as long as the rocSOLVER object has not arrived from cold storage; forced here.  n = 3600,
     real and complex, against the reference's own spectra: eigenvalues 1e-10, residual 1e-9."""
-    monkeypatch.setenv("BODGE_AMD_EIGH", "jacobi")
+    knobs.set("BODGE_AMD_EIGH", "jacobi")
     system = _build(api, name)
     vals, vecs = system.diagonalize(format="raw")
     ref = golden.eigenvalues(name)

@@ -50,14 +50,14 @@ def _build(api, name):
 # BASELINE config 5's feasible ladder: goldens are the reference's own
 # diagonalize() / free_energy() on these systems (tests/golden/make_golden.py)
 @pytest.mark.parametrize("name,driver", [("swave30_zeeman", "dsyevd"), ("peierls30", "zheevd"), ("chain300", "dsyevd")])
-def test_dense_ladder_above_the_jacobi_limit_matches_reference(api, golden, monkeypatch, dense_library, name, driver):
+def test_dense_ladder_above_the_jacobi_limit_matches_reference(api, golden, knobs, dense_library, name, driver):
     """n = 3600 real (dsyevd, the driver BASELINE config 5 names), n = 3600 complex (zheevd), and the
     literal "300" chain (n = 1200, sent to rocSOLVER here as well): eigenvalues within 1e-10 of the
     reference's, eigen-equation residual <= 1e-9, orthonormal finite vectors, reference shapes,
     and F(T) from the same spectrum within 1e-10 relative."""
     # pin the library route: 4N = 1200 would use the own Jacobi kernels, and so would 4N = 3600 while the
     # library is still cold (tests/test_gpu_parity.py::test_own_jacobi_kernels_reach_4096_rows covers those)
-    monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")
+    knobs.set("BODGE_AMD_EIGH", "rocsolver")
     system = _build(api, name)
     dim = system.shape[0]
     data = system._data
@@ -81,23 +81,23 @@ def test_dense_ladder_above_the_jacobi_limit_matches_reference(api, golden, monk
 
 
 @pytest.mark.parametrize("name", ["complex235", "barrier"])
-def test_rocsolver_route_forced_on_small_systems(api, golden, monkeypatch, dense_library, name):
+def test_rocsolver_route_forced_on_small_systems(api, golden, knobs, dense_library, name):
     """The library route taken for 4N > 2048, forced here on small systems: dsyevd when imag(H) = 0
     (barrier), zheevd otherwise (complex235).  Handing a real matrix to the Hermitian D&C driver
     (never done by default) shows its NaN-eigenvector defect; the default driver choice then
     notices on the device and repairs with the Jacobi driver."""
-    monkeypatch.setenv("BODGE_AMD_EIGH", "evd")
+    knobs.set("BODGE_AMD_EIGH", "evd")
     system = _build(api, name)
     dense = np.asarray(system.matrix("dense"))
     vals, vecs = system.diagonalize(format="raw")
     assert np.allclose(vals, golden.eigenvalues(name), rtol=0, atol=1e-10)
     assert np.isfinite(vecs).all() and np.allclose(dense @ vecs, vecs * vals, atol=1e-9)
     if name == "barrier":
-        monkeypatch.setenv("BODGE_AMD_EIGH_REAL", "0")
+        knobs.set("BODGE_AMD_EIGH_REAL", "0")
         vals1, vecs1 = system.diagonalize(format="raw")
         assert np.allclose(vals1, golden.eigenvalues(name), rtol=0, atol=1e-10)
         defect = bool(np.isnan(vecs1).any())  # seen on ROCm 7.2; a fixed library passes too
-        monkeypatch.setenv("BODGE_AMD_EIGH", "rocsolver")
+        knobs.set("BODGE_AMD_EIGH", "rocsolver")
         vals2, vecs2 = system.diagonalize(format="raw")
         assert np.isfinite(vecs2).all() and np.allclose(dense @ vecs2, vecs2 * vals2, atol=1e-9)
         assert defect or np.allclose(dense @ vecs1, vecs1 * vals1, atol=1e-9)
@@ -118,15 +118,11 @@ def test_slab_with_rccl_self_exchange(api, solver_cls, rccl_library):
     scale = cheb_ref.spectral_bound(bsr)
     comm = Communicator(0, 1, 0, Communicator.new_unique_id())
     ref = cheb_ref.recurrence_dots(bsr, scale, 32, cheb_ref.random_block(bsr.shape[0], 8, range(5), cheb_ref.VEC_Z4))
-    import os
+    from bodge_amd import backend
 
     for overlap in ("1", "0"):  # exchange hidden behind the interior rows / exchange then compute
-        os.environ["BODGE_AMD_OVERLAP"] = overlap
-        try:
-            with solver_cls.from_slab_plan(plan, comm=comm) as dev:
-                got = dev.dots_random(scale, 16, 5, seed=8, kind=cheb_ref.VEC_Z4)
-        finally:
-            del os.environ["BODGE_AMD_OVERLAP"]
+        with backend.options(BODGE_AMD_OVERLAP=overlap), solver_cls.from_slab_plan(plan, comm=comm) as dev:
+            got = dev.dots_random(scale, 16, 5, seed=8, kind=cheb_ref.VEC_Z4)
         assert np.allclose(got[0], ref[0], rtol=0, atol=1e-12 * bsr.shape[0])
         assert np.allclose(got[1], ref[1], rtol=0, atol=1e-12 * bsr.shape[0])
     comm.close()
