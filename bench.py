@@ -30,8 +30,13 @@ config.collective and config.rccl_ranks always say what actually ran.
 The default kernel on this workload is the three-steps-per-sweep form (bodge_amd/csrc/sweep.hpp,
 cheb_sweep3): one launch advances every vector by THREE recurrence steps, so K steps are about
 K/3 launches and `roofline` is per launch of that kernel; the two-step and one-step kernels are
-timed beside it (`two_step_kernels`, `one_step_kernels`, `streamed_blocks_kernels`,
-`complex128_kernels`).
+timed beside it (`two_step_kernels`, `one_step_kernels`, and with the block dictionary and / or
+real arithmetic switched off `streamed_blocks_one_step_kernels`, `complex128_one_step_kernels`,
+`complex128_sweep_kernels`).  Two more matrices of the same size are assembled and timed at N = 1:
+a random on-site potential and gap amplitude (`streamed_blocks_kernels`: 10^6 distinct diagonal
+blocks, real) and an exchange field of varying direction (`complex128_kernels`: the same, complex
+blocks) - position-dependent Hamiltonians, which take the three-step sweep that streams the
+on-site blocks.  None of these is ever `value`.
 """
 
 from __future__ import annotations
@@ -184,24 +189,28 @@ def cpu_baseline(system, scale, r_local, kind, seconds):
     short = max(2.0, seconds / 4)
     real = (not bsr.data.imag.any()) and kind == cheb_ref.VEC_RADEMACHER
     start = cheb_ref.random_block(bsr.shape[0], 0, range(r_local), kind)
+    # thread sweep; matrix and vectors placed by first touch from the compute threads (NUMA)
+    sweep = {}
     best = None
-    for threads in sorted({min(16, usable), min(64, usable)}):
+    for threads in sorted({min(t, usable) for t in (16, 64, 128, usable)}):
         cheb_c.set_threads(threads)
-        rate, steps, _ = cheb_c.time_recurrence(bsr, scale, start, seconds=short, real=real)
+        rate, steps, _ = cheb_c.time_recurrence(bsr, scale, start, seconds=max(1.5, short / 2), real=real, numa=True)
+        sweep[str(threads)] = rate
         if best is None or rate > best[0]:
             best = (rate, steps, threads)
-    extra = {}
+    gbps = best[0] / r_local * cheb_c.step_bytes(bsr, r_local, real) / 1e9
+    extra = {"c_openmp_thread_sweep_steps_per_s": sweep, "c_openmp_achieved_GBps": gbps}
     if real:
         cheb_c.set_threads(best[2])
-        extra["c_openmp_complex128_steps_per_s"] = cheb_c.time_recurrence(bsr, scale, start, seconds=short)[0]
+        extra["c_openmp_complex128_steps_per_s"] = cheb_c.time_recurrence(bsr, scale, start, seconds=short / 2, numa=True)[0]
     # the numpy/scipy restatement the parity tests use: one core, its variants, and the whole host
-    # (P forked workers with one vector each on the shared matrix, BASELINE.md §5 ii)
-    extra["scipy_bsr_1core_steps_per_s"] = cheb_ref.time_recurrence(bsr, scale, r_local, seconds=short, kind=kind)[0]
-    extra["scipy_csr_1core_steps_per_s"] = cheb_ref.time_recurrence(bsr, scale, r_local, seconds=short, kind=kind, fmt="csr")[0]
+    # (P forked workers with one vector each on the shared matrix, P = physical cores, BASELINE.md §5 ii)
+    extra["scipy_bsr_1core_steps_per_s"] = cheb_ref.time_recurrence(bsr, scale, r_local, seconds=short / 2, kind=kind)[0]
+    extra["scipy_csr_1core_steps_per_s"] = cheb_ref.time_recurrence(bsr, scale, r_local, seconds=short / 2, kind=kind, fmt="csr")[0]
     if real:
         extra["scipy_csr_real_1core_steps_per_s"] = cheb_ref.time_recurrence(
-            bsr, scale, r_local, seconds=short, kind=kind, fmt="csr", real=True)[0]
-    workers = max(1, min(16, usable))
+            bsr, scale, r_local, seconds=short / 2, kind=kind, fmt="csr", real=True)[0]
+    workers = max(1, min(physical_cores(usable), 128))
     extra["scipy_bsr_whole_host_steps_per_s"] = cheb_ref.time_recurrence_processes(bsr, scale, 1, workers, seconds=short)
     extra["scipy_bsr_whole_host_processes"] = workers
     return {
@@ -210,11 +219,26 @@ def cpu_baseline(system, scale, r_local, kind, seconds):
         "cores": best[2],
         "kind": "port",
         "sample": f"{best[1]} timed block-steps of the same {r_local} vectors on the same H: C + OpenMP "
-                  f"restatement (oracle/cheb_c.c), {'float64' if real else 'complex128'} arithmetic, "
-                  f"{best[2]} threads (host: {logical} logical cores, {usable} usable by this process)",
+                  f"restatement (oracle/cheb_c.c), {'float64' if real else 'complex128'} arithmetic, best of "
+                  f"{sorted(int(t) for t in sweep)} threads = {best[2]} (host: {logical} logical cores, {usable} usable by this "
+                  f"process; threads unpinned, pages of matrix and vectors placed by first touch from the compute "
+                  f"threads; {gbps:.0f} GB/s of algorithmic traffic)",
         "other_cpu_variants": extra,
     }
 
+
+def physical_cores(usable: int) -> int:
+    """Distinct (package, core) pairs among the CPUs this process may use (SMT siblings count once)."""
+    try:
+        cpus = sorted(os.sched_getaffinity(0))
+        seen = set()
+        for cpu in cpus:
+            base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+            with open(base + "physical_package_id") as a, open(base + "core_id") as b:
+                seen.add((a.read().strip(), b.read().strip()))
+        return max(1, len(seen))
+    except OSError:
+        return max(1, usable // 2)
 
 def main():
     ap = argparse.ArgumentParser()
@@ -244,7 +268,7 @@ def main():
             sys.exit("bench.py --gpus N>1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
 
-    from bodge_amd import backend, build, chebyshev
+    from bodge_amd import backend, build, chebyshev, solver as solver_module
     from bodge_amd.solver import VEC_RADEMACHER, VEC_Z4, Communicator, DeviceSolver
 
     # rank 0 (re)builds a missing or stale library; the others wait for a current one
@@ -257,6 +281,15 @@ def main():
         build.build_library()
     if store is not None:
         store.barrier()
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    t_rccl = time.perf_counter()
+    if world > 1:
+        # The first RCCL call reads a 573 MB shared object; from cold storage that takes minutes.  Start the
+        # read now (file I/O on a background thread of the library, no GPU call) so that it overlaps with the
+        # host assembly and the upload, and share the host's cores between the ranks of this node.
+        backend.load()
+        solver_module.prefetch_rccl_library()
+        backend.set_option("BODGE_AMD_HOST_THREADS", max(1, min(32, usable // world)))
 
     shape = [int(v) for v in args.lattice.split(",")]
     kind = VEC_RADEMACHER if args.vector_kind == "rademacher" else VEC_Z4
@@ -266,6 +299,7 @@ def main():
     indptr, indices, data = system.bsr_arrays()
     scale = chebyshev.spectral_bound(indptr, data)
     t_build = time.perf_counter() - t0
+    assert not system._devices, "the host assembly must not create a device mirror (CPU baseline forks workers next)"
 
     cpu_record = None
     if args.cpu_seconds > 0 and args.gpus == 1 and rank == 0:
@@ -273,7 +307,13 @@ def main():
 
     backend.load()
     backend.require_device()
+    t_wait = time.perf_counter()
+    if world > 1:  # progress lines while the shared object arrives (a silent wait looks like a hang)
+        while not solver_module.rccl_library_ready(20.0):
+            print(f"rank {rank}: waiting for librccl.so to arrive from storage, {time.perf_counter() - t_rccl:.0f} s so far",
+                  file=sys.stderr, flush=True)
     comm, collective = make_communicator(Communicator, world, rank, args.mode, args.allow_gloo, store)
+    rccl_load_s = {"since_prefetch_start": time.perf_counter() - t_rccl, "waited_after_assembly": time.perf_counter() - t_wait} if world > 1 else None
     rccl = isinstance(comm, Communicator)
     # what RCCL itself spans: rank count and the PCI bus id of every rank's device
     rccl_ranks, rank_devices = 0, [None] * world
@@ -325,7 +365,7 @@ def main():
     def kernel_label(pf):
         mode = f"{'Real' if pf['real_arithmetic'] else 'Complex'}{'PH' if pf['ph_packed'] else ''}Mode"
         if pf["steps_per_launch"] == 3:
-            return f"cheb_sweep3<{mode},{pf['lanes_per_row']}>"
+            return f"cheb_sweep3<{mode},{pf['lanes_per_row']}{',onsite-streamed' if pf['onsite_streamed'] else ''}>"
         if pf["steps_per_launch"] == 2:
             return f"cheb_sweep<{mode},{pf['lanes_per_row']}>"
         if pf["rolling"]:
@@ -336,25 +376,51 @@ def main():
     # Further passes with optimisations switched off, reported beside the headline and never as
     # `value`: one recurrence step per launch, blocks streamed from HBM instead of the LDS
     # dictionary, and complex arithmetic (the reference's own dtype).
-    def alternative(env):
-        os.environ.update(env)
-        try:
-            _, dt, pf = timed(args.steps)
-        finally:
-            for k in env:
-                del os.environ[k]
+    def launch_record(pf, dt, vectors, steps, lattice_shape):
         launch = pf["kernel_ms"] / max(1, pf["launches"])
         return {
-            "value": total_vectors * args.steps / dt,
+            "value": vectors * steps / dt,
             "unit": "steps/s",
             "kernel": kernel_label(pf),
             "launch_ms": launch,
             "steps_per_launch": pf["steps_per_launch"],
+            "vectors_per_launch": pf["vectors_per_launch"],
             "bytes_per_launch": pf["bytes_per_launch"],
             "achieved_GBps": pf["bytes_per_launch"] / (launch * 1e-3) / 1e9,
             "frac": pf["bytes_per_launch"] / (launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
-            "traffic": measured_traffic(kernel_label(pf), shape, r_local),
+            "traffic": measured_traffic(kernel_label(pf), lattice_shape, vectors),
         }
+
+    def alternative(env):
+        with backend.options(**env):  # (library switches for this pass only; bdg_set_option, not os.environ)
+            _, dt, pf = timed(args.steps)
+        return launch_record(pf, dt, total_vectors, args.steps, shape)
+
+    def other_matrix(model, vec_kind):
+        """A second Hamiltonian of the same lattice through the same call (N = 1 only): its default
+        route, and the one-step kernels on it beside that."""
+        other = build_system(shape, model)
+        o_indptr, o_indices, o_data = other.bsr_arrays()
+        o_scale = chebyshev.spectral_bound(o_indptr, o_data)
+        with DeviceSolver(o_indptr, o_indices, o_data, device=device) as dev:
+            dev.set_lattice_shape(shape)
+            out = {}
+            for name, env in (("default", {}), ("one_step", {"BODGE_AMD_SWEEP": "0"})):
+                with backend.options(**env):
+                    # (these passes start from an idle GPU - the matrix has just been assembled on the host - and the
+                    # sweep kernels feel the shader clock for ~50 ms: a longer warm-up than the headline's W steps)
+                    dev.moments_random(o_scale, 2 * max(args.warmup, 63), r_local, seed=0, kind=vec_kind)
+                    t_start = time.perf_counter()
+                    dev.moments_random(o_scale, 2 * args.steps, r_local, seed=0, kind=vec_kind)
+                    dt = time.perf_counter() - t_start
+                    out[name] = launch_record(dev.perf(), dt, r_local, args.steps, shape)
+            pf = dev.perf()
+        record = out["default"]
+        record["one_step"] = out["one_step"]
+        record["workload"] = {"potential": "random on-site potential and gap amplitude (10^6 distinct diagonal blocks), real",
+                              "texture": "exchange field of varying direction on every site (10^6 distinct diagonal blocks), complex"}[model]
+        record["distinct_blocks_total"] = "> 256" if pf["dict_skipped"] == 1 else pf["dict_blocks"]
+        return record
 
     # Order: the comparison passes run first, the headline last.  The multi-step sweep kernels are
     # sensitive to the shader clock, which takes ~50 ms of continuous load to settle after idle
@@ -364,9 +430,12 @@ def main():
     if args.warmup > 0:
         run(args.warmup)
     probe = solver.perf()  # which kernel family the default route takes on this matrix
-    complex_pass = (alternative({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"})
-                    if probe["real_arithmetic"] else None)
-    streamed_pass = alternative({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0"}) if probe["dict_blocks"] else None
+    position_pass = other_matrix("potential", VEC_RADEMACHER) if world == 1 and args.model == "swave" else None
+    texture_pass = other_matrix("texture", VEC_Z4) if world == 1 and args.model == "swave" else None
+    complex_one_step = (alternative({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"})
+                        if probe["real_arithmetic"] else None)
+    complex_sweep = alternative({"BODGE_AMD_REAL": "0"}) if probe["real_arithmetic"] and probe["steps_per_launch"] >= 2 else None
+    streamed_one_step = alternative({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0"}) if probe["dict_blocks"] else None
     one_step_pass = alternative({"BODGE_AMD_SWEEP": "0"}) if probe["steps_per_launch"] >= 2 or probe["rolling"] else None
     two_step_pass = alternative({"BODGE_AMD_SWEEP_STEPS": "2"}) if probe["steps_per_launch"] == 3 else None
     if args.warmup > 0:
@@ -415,6 +484,8 @@ def main():
             "collective": collective,
             "rccl_ranks": rccl_ranks,        # ncclCommCount of the communicator the moments were reduced over (0 = none)
             "rank_devices": rank_devices,    # PCI bus id of every rank's GPU, gathered over that communicator
+            "rccl_load_s": rccl_load_s,      # N > 1: librccl.so read (started before the host assembly) + communicator creation
+            "host_threads_per_rank": max(1, min(32, usable // world)) if world > 1 else None,
         },
         "roofline": {
             "bound": "hbm",
@@ -435,15 +506,18 @@ def main():
             "strip_rows": perf["strip_rows"],
             "distinct_blocks": perf["dict_blocks"],
         },
-        "pass_order": "comparison passes (complex128, streamed, one-step, two-step) first, then W warm-up steps and the K "
-                      "timed steps of the headline kernel",
+        "pass_order": "comparison passes (other matrices, complex128, streamed, one-step, two-step) first, then W warm-up "
+                      "steps and the K timed steps of the headline kernel",
         "free_energy_wall_s": elapsed,
         "free_energy_estimate": free_energy,
         "host_assembly_s": t_build,
         "two_step_kernels": two_step_pass,
         "one_step_kernels": one_step_pass,
-        "streamed_blocks_kernels": streamed_pass,
-        "complex128_kernels": complex_pass,
+        "streamed_blocks_kernels": position_pass,
+        "complex128_kernels": texture_pass,
+        "complex128_sweep_kernels": complex_sweep,
+        "streamed_blocks_one_step_kernels": streamed_one_step,
+        "complex128_one_step_kernels": complex_one_step,
         "cpu_baseline": cpu_record,
     }
     print(json.dumps(record), flush=True)

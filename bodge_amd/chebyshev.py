@@ -53,7 +53,7 @@ def spectral_bound(indptr: np.ndarray, data: np.ndarray, pad: float = 1.01) -> f
         return 1.0
     bound = _native_row_sum_max(indptr, data)
     if bound is not None:
-        return pad * bound if bound > 0 else 1.0
+        return pad * bound if (bound > 0 or np.isnan(bound)) else 1.0  # (NaN entries give NaN, as the numpy form below does)
     if np.iscomplexobj(data) and not data.imag.any():
         per_block = np.abs(data.real).sum(axis=2)  # same numbers as |z|, without the hypot pass
     else:
@@ -112,8 +112,10 @@ def gapped_ground_state_density(width: float):
 
     On a spectrum with |ε| ≥ gap the two differ by (|ε|/4)·erfc(|ε|/width) ≤ (gap/4)·erfc(gap/width),
     4e-13·gap for width = gap/5, and the smoothed function is entire: its Chebyshev series converges
-    faster than geometrically, M = 8·a/width moments leave ≲ 1e-13 of F (measured on four spectra,
-    DESIGN.md §2), a quarter of what f_T at T = gap/20 needs for 1e-11."""
+    faster than geometrically.  Pointwise on the gapped part of [-a, a] the truncated series is within
+    1e-13 (absolute, per level) of -|ε|/4 at M = 10·a/width - 6e-11 at 8·a/width, 8e-13 at 9·a/width,
+    tests/test_host_math.py - a third of what f_T at T = gap/20 needs for 1e-11; the error of F itself
+    is usually smaller still, because the four measured spectra cancel part of it."""
     import math
 
     erf = np.vectorize(math.erf, otypes=[float])  # (scipy.special costs seconds to import from a cold disk)
@@ -121,8 +123,8 @@ def gapped_ground_state_density(width: float):
 
 
 def moments_for_gapped_ground_state(scale: float, width: float) -> int:
-    """Even M = 8·a/width for the series of `gapped_ground_state_density(width)` (may exceed MAX_MOMENTS)."""
-    m = max(32, int(np.ceil(8.0 * scale / width)))
+    """Even M = 10·a/width for the series of `gapped_ground_state_density(width)` (may exceed MAX_MOMENTS)."""
+    m = max(32, int(np.ceil(10.0 * scale / width)))
     return m + (m & 1)
 
 

@@ -773,7 +773,7 @@ int bdg_hermiticity_defect(bdg_system* sys, double* defect_out) {
     if (!sys || !defect_out) return fail(BDG_EINVAL, "null argument");
     if (sys->ncols != sys->nb) return fail(BDG_EINVAL, "bdg_hermiticity_defect needs a whole (square) matrix, not a slab");
     HIP_TRY(hipSetDevice(sys->device));
-    const int grid = (int)std::min<int64_t>(2048, (sys->nb + 255) / 256);
+    const int grid = (int)std::min<int64_t>(4096, (sys->nb + 15) / 16);  // 16 block rows per workgroup and pass
     DeviceBuffer<double> partial;
     if (int rc = partial.reserve((size_t)grid)) return rc;
     std::vector<double> host((size_t)grid);

@@ -1366,15 +1366,20 @@ __global__ __launch_bounds__(256) void jacobi_eigenvalues(const T* __restrict__ 
 
 // max |H - H^†| over the stored entries (reference hamiltonian.py:121-122, `M - M.getH()`): block
 // (i, j) against the conjugate transpose of block (j, i), found by binary search in the sorted
-// row j; a block without a stored partner counts with its own magnitude.  One thread per block
-// row, one partial maximum per workgroup.
+// row j; a block without a stored partner counts with its own magnitude.  Sixteen lanes per block
+// row, one per block element: a block is one 256-byte run read by 16 adjacent lanes, its partner
+// the same 256 bytes read transposed (same cache lines), so the matrix crosses the fabric about
+// twice (2.1 x measured; the thread-per-row form of round 2 fetched it 7 x).  One partial maximum
+// per workgroup.
 __global__ __launch_bounds__(256) void hermiticity_defect(const int* __restrict__ indptr,
                                                           const int* __restrict__ indices,
                                                           const double2* __restrict__ blocks, int nb,
                                                           double* __restrict__ partial) {
     __shared__ double red[256];
+    const int el = threadIdx.x & 15, twin = (el & 3) * 4 + (el >> 2);
+    const int rows_per_pass = gridDim.x * (blockDim.x >> 4);
     double worst = 0.0;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x)
+    for (int i = blockIdx.x * (blockDim.x >> 4) + (threadIdx.x >> 4); i < nb; i += rows_per_pass)
         for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
             const int j = indices[k];
             int lo = indptr[j], hi = indptr[j + 1] - 1, m = -1;
@@ -1388,15 +1393,13 @@ __global__ __launch_bounds__(256) void hermiticity_defect(const int* __restrict_
                 if (c < i) lo = mid + 1;
                 else hi = mid - 1;
             }
-            for (int el = 0; el < 16; ++el) {
-                const double2 a = blocks[(size_t)k * 16 + el];
-                double2 b = make_double2(0.0, 0.0);
-                if (m >= 0) {
-                    const double2 t = blocks[(size_t)m * 16 + (el & 3) * 4 + (el >> 2)];
-                    b = make_double2(t.x, -t.y);
-                }
-                worst = fmax(worst, hypot(a.x - b.x, a.y - b.y));
+            const double2 a = load_stream(blocks + (size_t)k * 16 + el);
+            double2 b = make_double2(0.0, 0.0);
+            if (m >= 0) {
+                const double2 t = blocks[(size_t)m * 16 + twin];
+                b = make_double2(t.x, -t.y);
             }
+            worst = fmax(worst, hypot(a.x - b.x, a.y - b.y));
         }
     red[threadIdx.x] = worst;
     __syncthreads();

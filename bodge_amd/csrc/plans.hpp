@@ -616,8 +616,8 @@ double sweep_bytes(const bdg_system* sys, const ModeInfo& mode, int lanes) {
 // run are a quarter the size, and when they then fit the 256 MB Infinity Cache together
 // (4 x 64 B x sites + the stencil words <= ~252 MB: up to ~10^6 sites) every launch after the
 // first streams from that cache instead of HBM.  BODGE_AMD_SWEEP_LANES overrides.
-// Steps per sweep: 3 (cheb_sweep3, 4 lanes per site only) moves 4/9 of the one-step kernels'
-// bytes against 2/3 for 2.  BODGE_AMD_SWEEP_STEPS=2|3 overrides.
+// Steps per sweep: 3 (cheb_sweep3, with 2 or 4 lanes per site) moves 4/9 of the one-step kernels'
+// bytes against 2/3 for 2 (cheb_sweep, which also runs with 1 lane).  BODGE_AMD_SWEEP_STEPS=2|3 overrides.
 int sweep_depth_for(const bdg_system* sys, int lanes) {
     if (sys->onsite_streamed) return 3;  // (the only form that streams on-site blocks)
     int depth = lanes >= 2 ? 3 : 2;

@@ -638,8 +638,6 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
         auto iterate = [&](int k, double2 (&centre)[4], const double2 (&after)[4]) {
             const bool more = k < k_last;
             const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFu);
-            [[maybe_unused]] double2 nx_os[OSL];
-            load_onsite(k + 1, more, nx_os);
             put_own(row_0, centre);
             wave_sync();
             cur_plane(k + 2, valid && more, centre);
@@ -687,6 +685,11 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
                     if (steps == 3) store_plane(a.out1, k - 1, new2);
                 }
             }
+
+            // (OS) on-site records of plane k+1: asked for here rather than at the top of the iteration - they are
+            // not needed before its end, and 4-8 registers held across steps 1 and 2 are 4-8 registers spilled
+            [[maybe_unused]] double2 nx_os[OSL];
+            load_onsite(k + 1, more, nx_os);
 
             // ---- step 3 on plane k-2: level 3 = c2 H level2 - level1       (row_2 = level 2, plane k-2)
             if (steps >= 3 && owned && k - 2 >= x0 && k - 2 < x1) {

@@ -155,7 +155,7 @@ def free_energy(
     vectors  number of random vectors for the stochastic trace (default 64)
     gap_surrogate  at T = 0 with the Chebyshev method and no explicit `moments`: expand
              -(ε/4)·erf(ε/δ), δ = gap/5 (gap from `lowest_eigenvalues`), which differs from -|ε|/4 by
-             ~1e-13 on a gapped spectrum and converges faster than geometrically (8·a/δ moments);
+             1e-13 per level on a gapped spectrum and converges faster than geometrically (10·a/δ moments);
              False keeps the plain T = 0 coefficients
     devices  optional list of GPU ordinals of THIS process, e.g. `devices=[0, 1, 2, 3]` or
              `range(8)`: H is replicated on each, the start vectors (or the unit vectors of an exact
@@ -210,7 +210,7 @@ def free_energy(
     if temperature == 0 and moments is None and gap_surrogate and decomposition != "slab":
         # f_0(ε) = -|ε|/4 has a kink at ε = 0, but a gapped spectrum never samples it: expand
         # -(ε/4)·erf(ε/δ) with δ = gap/5 instead, which differs from f_0 by ≤ (gap/4)·erfc(5) = 4e-13·gap
-        # per level on |ε| ≥ gap and is entire - 8·a/δ moments leave ≲ 1e-13 of F (20x20 README model:
+        # per level on |ε| ≥ gap and is entire - 10·a/δ moments are within 1e-13 per level (20x20 README model:
         # 1e-15 of the dense value at 6144 moments, where f_T at T = gap/20, the surrogate of round 1,
         # still has 2e-10 and needs 22 000 for 1e-11; cheb.gapped_ground_state_density).  The Lanczos
         # estimate approaches the gap from above, to 1e-3.  A gapless spectrum keeps the plain T = 0 series.
@@ -225,7 +225,7 @@ def free_energy(
                 moments = cheb.MAX_MOMENTS
             _warn(f"free_energy(0.0) on a {dim}x{dim} matrix is beyond the dense eigensolver: evaluated by the Chebyshev "
                   f"expansion of -(ε/4)·erf(ε/δ), δ = gap/{GAP_SURROGATE_RATIO:g} = {width:.3g} "
-                  "(agrees with -|ε|/4 to ~1e-13 relative on a gapped spectrum; method='dense' forces the reference's algorithm)")
+                  "(within 1e-13 per level of -|ε|/4 on a gapped spectrum; method='dense' forces the reference's algorithm)")
     if moments is None:
         moments = cheb.moments_for_free_energy(scale, series_temperature)
     moments += moments & 1
@@ -644,7 +644,9 @@ def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8
         gram = cand.conj() @ cand.T
         weight, mix = np.linalg.eigh(gram)
         keep = weight > 1e-4 * weight[-1]
-        basis = (mix[:, keep] / np.sqrt(weight[keep])).T.conj() @ cand  # rows orthonormal... (rank = multiplicity)
+        # gram[i, j] = <c_i|c_j>, so b_m = Σ_i c_i mix[i, m] / sqrt(w_m) are orthonormal (no conjugate on
+        # mix: with it the rows are orthonormal only when the Gram matrix is real - ADVICE r2)
+        basis = (mix[:, keep] / np.sqrt(weight[keep])).T @ cand  # (rank = multiplicity)
         basis = np.linalg.qr(basis.T)[0].T  # tidy up round-off
         h_basis = np.stack([solver.spmv(v) for v in basis])
         small = basis.conj() @ h_basis.T

@@ -4,7 +4,11 @@ What it is for: before `ncclCommInitRank` every rank needs rank 0's 128-byte RCC
 and a launcher script may want a few scalars agreed between ranks before any GPU call.  Rank 0
 serves a small dictionary on `MASTER_ADDR`, the other ranks are clients; `get` blocks until the
 key exists.  Nothing touches the file system, so there is nothing stale to find after a crashed
-run, nothing another user can plant, and the ranks may sit on different nodes.
+run, and the ranks may sit on different nodes.  The server binds to MASTER_ADDR only (127.0.0.1 for
+a one-node launch), keys are write-once (a second `set` of an existing key is refused), and every
+message carries the launch's nonce - which keeps launches apart, but is NOT a secret (run id, port
+and parent pid can be read by any local user): this is a rendezvous among cooperating processes of
+one user on a trusted node, not an authenticated channel.
 
 Port: the launcher's own store owns MASTER_PORT, so this one listens on a port derived from it
 (MASTER_PORT + 1 + k for the first k in 0..31 that can be bound).  Every request carries the
@@ -43,9 +47,11 @@ class _Handler(socketserver.StreamRequestHandler):
                 reply = {"ok": False, "error": "wrong launch"}
             elif msg.get("op") == "set":
                 with server.changed:
-                    server.table[msg["key"]] = msg["value"]
-                    server.changed.notify_all()
-                reply = {"ok": True}
+                    fresh = msg["key"] not in server.table  # write-once: nobody overwrites an id or a gathered value
+                    if fresh:
+                        server.table[msg["key"]] = msg["value"]
+                        server.changed.notify_all()
+                reply = {"ok": fresh, "error": "" if fresh else "key already set"}
             elif msg.get("op") == "get":
                 deadline = time.time() + float(msg.get("timeout", 300.0))
                 with server.changed:
@@ -87,7 +93,7 @@ class Store:
         last = None
         for k in range(PORT_CANDIDATES):
             try:
-                server = _Server(("", self.base_port + k), _Handler)
+                server = _Server((self._bind_address(), self.base_port + k), _Handler)
             except OSError as exc:
                 last = exc
                 continue
@@ -97,12 +103,24 @@ class Store:
             return
         raise RuntimeError(f"rendezvous: no free port in {self.base_port}..{self.base_port + PORT_CANDIDATES - 1}: {last}")
 
+    def _bind_address(self) -> str:
+        """The interface MASTER_ADDR names; all interfaces only if it does not resolve to a local one."""
+        try:
+            probe = socket.socket(socket.AF_INET, socket.SOCK_STREAM)
+            try:
+                probe.bind((self.addr, 0))
+            finally:
+                probe.close()
+            return self.addr
+        except OSError:
+            return ""
+
     def _connect(self) -> None:
         deadline = time.time() + self.timeout
         while True:
             for k in range(PORT_CANDIDATES):
                 try:
-                    sock = socket.create_connection((self.addr, self.base_port + k), timeout=2.0)
+                    sock = socket.create_connection((self.addr, self.base_port + k), timeout=0.5 if self.addr.startswith("127.") else 2.0)
                 except OSError:
                     continue
                 sock.settimeout(None)

@@ -18,15 +18,30 @@
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
+#else
+static int omp_get_thread_num(void) { return 0; }
+static int omp_get_num_threads(void) { return 1; }
+static int omp_get_max_threads(void) { return 1; }
 #endif
 
-int cheb_c_threads(void) {
-#ifdef _OPENMP
-    return omp_get_max_threads();
-#else
-    return 1;
-#endif
+/*
+ * Dot products: every thread sums its (static, contiguous) range of block rows into its own slot
+ * and the slots are added in thread order afterwards - for a given thread count the result is
+ * the same bits on every run (an `omp critical` in arrival order is not).
+ *
+ * NUMA: the block rows are cut with schedule(static), the same cut in every call.  Arrays that
+ * were first written through cheb_c_copy_rows (one memcpy per block row by the thread that will
+ * later process that row) therefore have their pages on the memory node that thread ran on (threads
+ * are not pinned - see cheb_c.py - but busy threads are rarely migrated).  Without the placed copy
+ * every page sits on the node of the Python thread that filled the numpy array, and a 256-thread
+ * host runs at the bandwidth of one node.
+ */
+void cheb_c_copy_rows(int64_t nb, const int64_t* row_begin /* nb + 1 byte offsets */, const char* src, char* dst) {
+#pragma omp parallel for schedule(static)
+    for (int64_t i = 0; i < nb; ++i) memcpy(dst + row_begin[i], src + row_begin[i], (size_t)(row_begin[i + 1] - row_begin[i]));
 }
+
+int cheb_c_threads(void) { return omp_get_max_threads(); }
 
 void cheb_c_set_threads(int n) {
 #ifdef _OPENMP
@@ -40,12 +55,15 @@ void cheb_c_set_threads(int n) {
 void cheb_c_step_complex(int64_t nb, const int32_t* indptr, const int32_t* indices, const double* blocks,
                          int R, double coef, const double* cur, double* prev /* in: t_prev, out: t_next */,
                          double* d_out, double* e_out) {
-    double* d_acc = (double*)calloc((size_t)R, sizeof(double));
-    double* e_acc = (double*)calloc((size_t)R, sizeof(double));
+    const int max_threads = omp_get_max_threads();
+    double* slots = (double*)calloc((size_t)max_threads * 2 * (size_t)R, sizeof(double));  /* [thread][{d, e}][R] */
+    int used_threads = 1;
 #pragma omp parallel
     {
-        double* d_loc = (double*)calloc((size_t)R, sizeof(double));
-        double* e_loc = (double*)calloc((size_t)R, sizeof(double));
+        double* d_loc = slots + (size_t)omp_get_thread_num() * 2 * (size_t)R;
+        double* e_loc = d_loc + R;
+#pragma omp single
+        used_threads = omp_get_num_threads();
         double* acc = (double*)malloc(sizeof(double) * 8 * (size_t)R);
 #pragma omp for schedule(static)
         for (int64_t i = 0; i < nb; ++i) {
@@ -77,30 +95,29 @@ void cheb_c_step_complex(int64_t nb, const int32_t* indptr, const int32_t* indic
                 }
             }
         }
-#pragma omp critical
-        for (int r = 0; r < R; ++r) {
-            d_acc[r] += d_loc[r];
-            e_acc[r] += e_loc[r];
-        }
-        free(d_loc);
-        free(e_loc);
         free(acc);
     }
-    memcpy(d_out, d_acc, sizeof(double) * (size_t)R);
-    memcpy(e_out, e_acc, sizeof(double) * (size_t)R);
-    free(d_acc);
-    free(e_acc);
+    for (int r = 0; r < R; ++r) d_out[r] = e_out[r] = 0.0;
+    for (int t = 0; t < used_threads; ++t) /* thread order: reproducible */
+        for (int r = 0; r < R; ++r) {
+            d_out[r] += slots[(size_t)t * 2 * R + r];
+            e_out[r] += slots[(size_t)t * 2 * R + R + r];
+        }
+    free(slots);
 }
 
 /* real: blocks_re[k][4][4] doubles, vectors (4*nb, R) doubles */
 void cheb_c_step_real(int64_t nb, const int32_t* indptr, const int32_t* indices, const double* blocks_re,
                       int R, double coef, const double* cur, double* prev, double* d_out, double* e_out) {
-    double* d_acc = (double*)calloc((size_t)R, sizeof(double));
-    double* e_acc = (double*)calloc((size_t)R, sizeof(double));
+    const int max_threads = omp_get_max_threads();
+    double* slots = (double*)calloc((size_t)max_threads * 2 * (size_t)R, sizeof(double));  /* [thread][{d, e}][R] */
+    int used_threads = 1;
 #pragma omp parallel
     {
-        double* d_loc = (double*)calloc((size_t)R, sizeof(double));
-        double* e_loc = (double*)calloc((size_t)R, sizeof(double));
+        double* d_loc = slots + (size_t)omp_get_thread_num() * 2 * (size_t)R;
+        double* e_loc = d_loc + R;
+#pragma omp single
+        used_threads = omp_get_num_threads();
         double* acc = (double*)malloc(sizeof(double) * 4 * (size_t)R);
 #pragma omp for schedule(static)
         for (int64_t i = 0; i < nb; ++i) {
@@ -128,17 +145,13 @@ void cheb_c_step_real(int64_t nb, const int32_t* indptr, const int32_t* indices,
                 }
             }
         }
-#pragma omp critical
-        for (int r = 0; r < R; ++r) {
-            d_acc[r] += d_loc[r];
-            e_acc[r] += e_loc[r];
-        }
-        free(d_loc);
-        free(e_loc);
         free(acc);
     }
-    memcpy(d_out, d_acc, sizeof(double) * (size_t)R);
-    memcpy(e_out, e_acc, sizeof(double) * (size_t)R);
-    free(d_acc);
-    free(e_acc);
+    for (int r = 0; r < R; ++r) d_out[r] = e_out[r] = 0.0;
+    for (int t = 0; t < used_threads; ++t) /* thread order: reproducible */
+        for (int r = 0; r < R; ++r) {
+            d_out[r] += slots[(size_t)t * 2 * R + r];
+            e_out[r] += slots[(size_t)t * 2 * R + R + r];
+        }
+    free(slots);
 }

@@ -37,7 +37,12 @@ def load():
     global _lib
     if _lib is None:
         build()
+        # (No OMP_PROC_BIND here: libgomp would pin the calling Python thread to one core as well, and
+        # every BLAS thread and forked worker of the process inherits that mask - measured 10x slower
+        # test runs.  Threads stay unpinned; the scheduler keeps busy threads where they are.)
         _lib = C.CDLL(LIBRARY)
+        _lib.cheb_c_copy_rows.restype = None
+        _lib.cheb_c_copy_rows.argtypes = [C.c_int64, C.POINTER(C.c_int64), C.c_void_p, C.c_void_p]
         f64p, i32p = C.POINTER(C.c_double), C.POINTER(C.c_int32)
         for name in ("cheb_c_step_complex", "cheb_c_step_real"):
             fn = getattr(_lib, name)
@@ -60,10 +65,23 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t))
 
 
-class Recurrence:
-    """State of one run: t_cur, t_prev as (4N, R) arrays; `step(coef)` advances in place."""
+def _placed_copy(lib, source: np.ndarray, row_begin: np.ndarray) -> np.ndarray:
+    """Copy of `source` whose pages are first written by the OpenMP threads that will process the
+    corresponding block rows (row i = bytes row_begin[i] .. row_begin[i+1]): NUMA first touch."""
+    source = np.ascontiguousarray(source)
+    out = np.empty_like(source)  # large: fresh, untouched pages from mmap
+    begin = np.ascontiguousarray(row_begin, dtype=np.int64)
+    lib.cheb_c_copy_rows(len(begin) - 1, begin.ctypes.data_as(C.POINTER(C.c_int64)), source.ctypes.data, out.ctypes.data)
+    return out
 
-    def __init__(self, bsr, start: np.ndarray, real: bool = False):
+
+class Recurrence:
+    """State of one run: t_cur, t_prev as (4N, R) arrays; `step(coef)` advances in place.
+
+    `numa` = place the pages of the matrix and the vectors by first touch from the compute threads
+    (used by the CPU baseline of bench.py; the values are the same either way)."""
+
+    def __init__(self, bsr, start: np.ndarray, real: bool = False, numa: bool = False):
         self.lib = load()
         self.nb = bsr.shape[0] // 4
         self.indptr = np.ascontiguousarray(bsr.indptr, dtype=np.int32)
@@ -77,6 +95,15 @@ class Recurrence:
             self.cur = np.array(start, dtype=np.complex128, order="C")  # private copy: steps overwrite it
         self.prev = np.zeros_like(self.cur)
         self.R = self.cur.shape[1]
+        self.numa = bool(numa)
+        if numa:
+            block_rows = self.indptr.astype(np.int64)
+            per_block = self.blocks[0].nbytes if len(self.blocks) else 0
+            self.blocks = _placed_copy(self.lib, self.blocks, block_rows * per_block)
+            self.indices = _placed_copy(self.lib, self.indices, block_rows * 4)
+            vec_rows = np.arange(self.nb + 1, dtype=np.int64) * (4 * self.cur.strides[0])
+            self.cur = _placed_copy(self.lib, self.cur, vec_rows)
+            self.prev = _placed_copy(self.lib, self.prev, vec_rows)
 
     def step(self, coef: float):
         d, e = np.empty(self.R), np.empty(self.R)
@@ -99,9 +126,17 @@ def recurrence_dots(bsr, scale: float, n_moments: int, start: np.ndarray, real: 
     return d, e
 
 
-def time_recurrence(bsr, scale, start, seconds: float = 8.0, real: bool = False, warmup: int = 2):
+def step_bytes(bsr, n_vectors: int, real: bool) -> float:
+    """Bytes one block-step of this restatement moves at the least: every stored block and index
+    once, and per (scalar row, vector) read t_n, read t_{n-1}, write t_{n+1} (SURVEY §8d's count
+    for the storage actually used here: full 16-entry blocks, float64 or complex128)."""
+    element = 8.0 if real else 16.0
+    return (16 * element + 4) * bsr.indices.size + 4.0 * (bsr.shape[0] // 4 + 1) + 3 * element * bsr.shape[0] * n_vectors
+
+
+def time_recurrence(bsr, scale, start, seconds: float = 8.0, real: bool = False, warmup: int = 2, numa: bool = False):
     """(vector_steps_per_second, block_steps_timed, threads) of the OpenMP recurrence on this host."""
-    run = Recurrence(bsr, start, real)
+    run = Recurrence(bsr, start, real, numa=numa)
     run.step(1.0 / scale)
     done, t0 = 0, None
     while True:

@@ -243,8 +243,12 @@ def time_recurrence(bsr, scale, n_vectors, seconds=10.0, seed=0, kind=VEC_RADEMA
     return timed * n_vectors / elapsed, timed
 
 
+_shared_matrix = None  # set before the pool forks: the workers inherit it (copy-on-write), nothing is pickled
+
+
 def _worker(args):
-    mat, scale, n_vectors, seconds, seed = args
+    scale, n_vectors, seconds, seed = args
+    mat = _shared_matrix
     start = random_block(mat.shape[0], seed, range(n_vectors), VEC_RADEMACHER)
     timed, elapsed = _recurrence_loop(mat, scale, start, seconds, 1)
     return timed * n_vectors / elapsed
@@ -255,7 +259,12 @@ def time_recurrence_processes(bsr, scale, n_vectors, n_processes, seconds=8.0):
     the shared (copy-on-write) matrix.  Returns summed vector-steps per second."""
     import multiprocessing as mp
 
-    ctx = mp.get_context("fork")
-    with ctx.Pool(n_processes) as pool:
-        rates = pool.map(_worker, [(bsr, scale, n_vectors, seconds, 100 + p) for p in range(n_processes)])
+    global _shared_matrix
+    _shared_matrix = bsr
+    try:
+        ctx = mp.get_context("fork")
+        with ctx.Pool(n_processes) as pool:
+            rates = pool.map(_worker, [(scale, n_vectors, seconds, 100 + p) for p in range(n_processes)], chunksize=1)
+    finally:
+        _shared_matrix = None
     return float(sum(rates))

@@ -8,7 +8,7 @@ no arithmetic).  Nothing from the reference is written into this repository -
 the outputs are numbers: free energies, eigenvalue arrays, LDOS arrays and, for
 the small systems flagged `triple`, the BSR arrays the reference assembled.
 
-    python3 tests/golden/make_golden.py
+    python3 tests/golden/make_golden.py [--only name ...]     (--only: add / refresh these systems, keep the rest)
 """
 
 from __future__ import annotations
@@ -44,7 +44,15 @@ def main():
     import systems
 
     scalars, arrays = {}, {}
+    only = sys.argv[sys.argv.index("--only") + 1:] if "--only" in sys.argv else None
+    if only:  # keep what is recorded for the other systems
+        with open(os.path.join(HERE, "reference_values.json")) as fh:
+            scalars = json.load(fh)
+        with np.load(os.path.join(HERE, "reference_arrays.npz")) as old:
+            arrays = {key: old[key] for key in old.files if key.split("/")[0] not in only}
     for name, spec in systems.CATALOG.items():
+        if only and name not in only:
+            continue
         system = spec["build"](ref, **spec["kwargs"])
         entry = {"shape": list(system.lattice.shape)}
         skeleton = system._matrix

@@ -225,6 +225,8 @@ CATALOG = {
     "swave30_zeeman": dict(build=swave_square, kwargs=dict(L=30, zeeman=0.05), temps=[0.0, 0.1, 0.5], spectrum=True),
     "peierls30": dict(build=peierls_square, kwargs={}, temps=[0.0, 0.1, 0.5], spectrum=True),
     "chain300": dict(build=swave_chain, kwargs={}, temps=[0.0, 0.1, 0.5], spectrum=True),
+    # next rung: n = 10^4 (the reference's dense eigh takes minutes per call on the build host: one temperature)
+    "swave50_zeeman": dict(build=swave_square, kwargs=dict(L=50, zeeman=0.05), temps=[0.5], spectrum=True),
     "chain128": dict(
         build=field_chain,
         kwargs={},

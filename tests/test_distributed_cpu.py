@@ -144,3 +144,40 @@ def test_bench_refuses_to_report_without_rccl(tmp_path):
     proc = subprocess.run(cmd, cwd=ROOT, env=dict(os.environ), capture_output=True, text=True, timeout=540)
     assert proc.returncode != 0
     assert "could not be created on every rank" in proc.stderr and not os.listdir(tmp_path)
+
+
+def test_rendezvous_store_binds_to_the_master_address_and_keys_are_write_once():
+    """the store listens on MASTER_ADDR only (loopback for a one-node launch) and refuses
+    a second `set` of a key, so a stray peer can neither reach it from outside nor replace an id."""
+    import threading
+
+    from bodge_amd.rendezvous import Store
+
+    port = _free_port()
+    stores = {}
+
+    def rank(r):
+        stores[r] = Store(r, 2, addr="127.0.0.1", base_port=port, nonce="test-launch", timeout=30.0)
+
+    threads = [threading.Thread(target=rank, args=(r,)) for r in (0, 1)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    server = stores[0]._server
+    assert server.server_address[0] == "127.0.0.1"
+    stores[0].set("id", b"abc")
+    assert stores[1].get("id", 5.0) == b"abc"
+    with pytest.raises(RuntimeError):
+        stores[1].set("id", b"evil")
+    assert stores[0].get("id", 5.0) == b"abc"
+    gathered = {}
+    workers = [threading.Thread(target=lambda r=r: gathered.__setitem__(r, stores[r].gather(bytes([r])))) for r in (0, 1)]
+    for t in workers:
+        t.start()
+    for t in workers:
+        t.join()
+    assert gathered[0] == gathered[1] == [b"\x00", b"\x01"]
+    with pytest.raises(RuntimeError):  # a client of another launch finds no server that answers its nonce
+        Store(1, 2, addr="127.0.0.1", base_port=port, nonce="another-launch", timeout=0.5)
+    server.shutdown()

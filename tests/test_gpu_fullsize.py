@@ -395,7 +395,7 @@ def test_position_dependent_onsite_terms_full_length_at_full_size(api, hip_libra
         solver.set_lattice_shape(lattice.shape)
         (d, e), perf = _with_env(solver, {}, scale, moments // 2, vectors, seed=4, kind=vec_kind)
         assert perf["onsite_streamed"] == 1 and perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == 4, perf
-        assert perf["real_arithmetic"] == (1 if real else 0) and perf["dict_blocks"] == 2 and perf["dict_skipped"] == 1
+        assert perf["real_arithmetic"] == (1 if real else 0) and perf["dict_blocks"] == 1 and perf["dict_skipped"] == 1
         assert perf["launches"] == 4 * 21 + 2  # one lane group: four chunks of 63 steps, then 3 + 1
         (d1, e1), perf1 = _with_env(solver, {"BODGE_AMD_SWEEP": "0"}, scale, moments // 2, vectors, seed=4, kind=vec_kind)
         assert perf1["onsite_streamed"] == 0 and perf1["steps_per_launch"] == 1 and perf1["dict_blocks"] == 0

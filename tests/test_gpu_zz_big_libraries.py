@@ -49,12 +49,13 @@ def _build(api, name):
 
 # BASELINE config 5's feasible ladder: goldens are the reference's own
 # diagonalize() / free_energy() on these systems (tests/golden/make_golden.py)
-@pytest.mark.parametrize("name,driver", [("swave30_zeeman", "dsyevd"), ("peierls30", "zheevd"), ("chain300", "dsyevd")])
+@pytest.mark.parametrize("name,driver", [("swave30_zeeman", "dsyevd"), ("peierls30", "zheevd"), ("chain300", "dsyevd"),
+                                         ("swave50_zeeman", "dsyevd")])
 def test_dense_ladder_above_the_jacobi_limit_matches_reference(api, golden, knobs, dense_library, name, driver):
-    """n = 3600 real (dsyevd, the driver BASELINE config 5 names), n = 3600 complex (zheevd), and the
-    literal "300" chain (n = 1200, sent to rocSOLVER here as well): eigenvalues within 1e-10 of the
-    reference's, eigen-equation residual <= 1e-9, orthonormal finite vectors, reference shapes,
-    and F(T) from the same spectrum within 1e-10 relative."""
+    """n = 3600 real (dsyevd, the driver BASELINE config 5 names), n = 3600 complex (zheevd), the
+    literal "300" chain (n = 1200, sent to rocSOLVER here as well) and the next rung n = 10^4 (50 x 50,
+    0.8 GB real matrix): eigenvalues within 1e-10 of the reference's, eigen-equation residual <= 1e-9,
+    orthonormal finite vectors, reference shapes, and F(T) from the same spectrum within 1e-10 relative."""
     # pin the library route: 4N = 1200 would use the own Jacobi kernels, and so would 4N = 3600 while the
     # library is still cold (tests/test_gpu_parity.py::test_own_jacobi_kernels_reach_4096_rows covers those)
     knobs.set("BODGE_AMD_EIGH", "rocsolver")
@@ -75,7 +76,7 @@ def test_dense_ladder_above_the_jacobi_limit_matches_reference(api, golden, knob
     assert np.abs(gram).max() <= 1e-9
     _, shaped = system.diagonalize()
     assert shaped.shape == (dim // 2, dim // 4, 4) and np.array_equal(shaped[3, 7, :], vecs[28:32, 3])
-    for temperature in (0.0, 0.1, 0.5):
+    for temperature in systems.CATALOG[name]["temps"]:
         value = system.free_energy(temperature, method="dense")
         assert abs(value - golden.free_energy(name, temperature)) <= 1e-10 * abs(value)
 
@@ -157,3 +158,35 @@ def test_rccl_single_rank_communicator(hip_library, rccl_library):
     assert np.array_equal(comm.allreduce_max(values), values)
     comm.barrier()
     comm.close()
+
+
+@pytest.mark.timeout(900)
+def test_bench_launch_path_with_two_ranks_on_one_gpu(rccl_library):
+    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per
+    process), rehearsed on this one-GPU box with --allow-gloo: both ranks map to GPU 0, RCCL refuses
+    the duplicate device, the ranks agree on that through the rendezvous store and carry the three
+    scalar reductions over the host.  The JSON line must say so (rccl_ranks 0) and carry the fields
+    the multi-GPU record needs (rccl_load_s, host threads per rank, whole-job vector count)."""
+    import json
+    import socket
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--allow-gloo", "--lattice", "64,64,1",
+           "--steps", "12", "--warmup", "3", "--cpu-seconds", "0"]
+    proc = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=800)
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    lines = [line for line in proc.stdout.splitlines() if line.startswith("{")]
+    assert len(lines) == 1, proc.stdout[-2000:]  # rank 0 prints the one line
+    record = json.loads(lines[0])
+    assert record["n_gpus"] == 2 and record["steps"] == 12 and record["scaling"] == "weak" and record["value"] > 0
+    config = record["config"]
+    assert config["rccl_ranks"] == 0 and config["collective"].startswith("host fallback"), config
+    assert config["rccl_load_s"]["since_prefetch_start"] >= config["rccl_load_s"]["waited_after_assembly"] >= 0
+    assert config["host_threads_per_rank"] >= 1 and config["parallelism"] == "vectors x2"
+    assert record["cpu_baseline"] is None and record["streamed_blocks_kernels"] is None  # N = 1 only

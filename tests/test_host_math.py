@@ -143,6 +143,48 @@ def test_smoothed_density_and_krylov_cut():
     density = chebyshev.gapped_ground_state_density(0.013)
     assert np.abs(density(x) - (-(x / 4) * erf(x / 0.013))).max() <= 1e-15
     assert np.abs(density(x[np.abs(x) >= 0.065]) + np.abs(x[np.abs(x) >= 0.065]) / 4).max() <= 1e-13  # = -|ε|/4 beyond 5 widths
-    assert chebyshev.moments_for_gapped_ground_state(7.2, 0.0105) == 5486 and chebyshev.moments_for_gapped_ground_state(1.0, 10.0) == 32
+    assert chebyshev.moments_for_gapped_ground_state(7.2, 0.0105) == 6858 and chebyshev.moments_for_gapped_ground_state(1.0, 10.0) == 32
     beta = np.array([3.0, 2.5, 2.9, 1e-9, 4.0, 3.0])
     assert _krylov_length(beta, scale2=25.0) == 4 and _krylov_length(beta[:3], scale2=25.0) == 3
+
+
+def test_bench_assembly_leaves_the_gpu_alone(api, monkeypatch):
+    """bench.py takes its CPU baseline (which forks worker processes) before the first GPU call; the
+    closing `with` block of its assembly must therefore make its Hermiticity test on the host even
+    for large fills.  `hermiticity_check = "host"` never asks whether a GPU is there."""
+    import bench
+    from bodge_amd import hamiltonian
+
+    def forbidden():
+        raise AssertionError("the assembly asked for a GPU")
+
+    monkeypatch.setattr(hamiltonian, "_gpu_present", forbidden)
+    monkeypatch.setattr(hamiltonian, "DEVICE_HERMITICITY_MIN_BLOCKS", 1)
+    for model in ("swave", "dwave", "potential", "texture", "peierls"):
+        system = bench.build_system([12, 10, 1] if model != "dwave" else [6, 5, 4], model)
+        assert system.hermiticity_check == "host" and system._devices == {}
+        assert system._hermiticity_defect() < 1e-12
+    system = api.Hamiltonian(api.CubicLattice((4, 4, 1)))
+    system.hermiticity_check = "somewhere"
+    with pytest.raises(ValueError):
+        with system as (H, Δ):
+            H.set_sites(api.σ0)
+
+
+@pytest.mark.parametrize("scale,gap", [(8.0, 0.2), (8.0, 0.05), (20.0, 0.1)])
+def test_gapped_ground_state_series_pointwise_bound(scale, gap):
+    """The stated accuracy of the T = 0 route is a pointwise bound, not a cancellation in the trace
+    (ADVICE r2): at M = moments_for_gapped_ground_state the truncated series of -(ε/4)·erf(5ε/gap) is
+    within 1e-13 of -|ε|/4 for every gap ≤ |ε| < a; at 8·a/δ, round 2's order, it is 1e-11 .. 6e-11."""
+    width = gap / 5
+    density = chebyshev.gapped_ground_state_density(width)
+    eps = np.concatenate([np.linspace(-0.999 * scale, -gap, 2001), np.linspace(gap, 0.999 * scale, 2001)])
+
+    def worst(order):
+        coeff = chebyshev.chebyshev_coefficients(lambda x: density(scale * x), order)
+        return np.abs(np.polynomial.chebyshev.chebval(eps / scale, coeff) + np.abs(eps) / 4).max()
+
+    order = chebyshev.moments_for_gapped_ground_state(scale, width)
+    assert order == int(np.ceil(10 * scale / width)) + (int(np.ceil(10 * scale / width)) & 1)
+    assert worst(order) <= 1e-13
+    assert 1e-12 < worst(int(8 * scale / width)) < 1e-10

@@ -54,8 +54,20 @@ def test_sweep_kernels_fit_two_waves_per_simd_without_spilling(resources):
                 assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, reverse, row)
             for lanes in (2, 4):
                 for gen in ("false", "true") if reverse == "false" else ("false",):  # (GEN: start block made in registers)
-                    row = _row(resources, f"cheb_sweep3<bdg::{mode}, {lanes}, {reverse}, {gen}>")
+                    row = _row(resources, f"cheb_sweep3<bdg::{mode}, {lanes}, {reverse}, {gen}, false>")
                     assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, reverse, gen, row)
         for lanes in (2, 4):
             row = _row(resources, f"cheb_roll3<bdg::{mode}, {lanes}>")
             assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, row)
+
+
+@pytest.mark.timeout(600)
+def test_streamed_onsite_sweep_keeps_two_waves_per_simd(resources):
+    """cheb_sweep3<..., OS> carries the prefetched on-site records on top of K7b's state.  It must keep
+    two waves per SIMD; the register allocator parks a few loop-invariant values in scratch (real: 12 B
+    touched in the prologue only, complex: 64 B with four reloads per iteration - measured harmless
+    next to ~30 global loads per iteration), and that must not grow unnoticed."""
+    for mode, limit in (("RealPHMode", 24), ("ComplexPHMode", 64)):
+        for reverse, gen in (("false", "false"), ("true", "false"), ("false", "true")):
+            row = _row(resources, f"cheb_sweep3<bdg::{mode}, 4, {reverse}, {gen}, true>")
+            assert row["scratch"] <= limit and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, reverse, gen, row)

@@ -24,16 +24,23 @@ import re
 
 
 def kernel_key(name: str) -> str:
-    if re.search(r"cheb_sweep3<.*, true>\(", name):
-        return ""  # the start-block-generating first sweep of a run reads no t_n: not the typical launch
-    m = re.search(r"(cheb_sweep3?)<bdg::(\w+), (\d), (?:true|false)[,>]", name)  # both marching directions count as one kernel
+    # cheb_sweep3<Mode, lanes, REV, GEN, OS>: both marching directions count as one kernel; the
+    # start-block-generating first sweep of a run (GEN) reads no t_n and is not the typical launch
+    m = re.search(r"cheb_sweep3<bdg::(\w+), (\d), (?:true|false), (true|false), (true|false)>", name)
     if m:
-        return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
+        if m.group(3) == "true":
+            return ""
+        return f"cheb_sweep3<{m.group(1)},{m.group(2)}{',onsite-streamed' if m.group(4) == 'true' else ''}>"
+    m = re.search(r"cheb_sweep<bdg::(\w+), (\d), (?:true|false)>", name)
+    if m:
+        return f"cheb_sweep<{m.group(1)},{m.group(2)}>"
     m = re.search(r"cheb_roll3<bdg::(\w+), (\d)>", name)
     if m:
         return f"cheb_roll3<{m.group(1)},{m.group(2)}>"
     m = re.search(r"(cheb_step\w*)<bdg::(\w+), (\d+)", name)
-    return f"{m.group(1)}<{m.group(2)},{m.group(3)}>" if m else ""
+    if m:
+        return f"{m.group(1)}<{m.group(2)},{m.group(3)}>"
+    return "hermiticity_defect" if "hermiticity_defect" in name else ""
 
 
 def collect(directory):
