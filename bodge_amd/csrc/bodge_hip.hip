@@ -259,7 +259,10 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
         sys->row_needs_halo.assign((size_t)nb, 0);
         for (int64_t i = 0; i < nb; ++i)
             for (int k = indptr[i]; k < indptr[i + 1]; ++k)
-                if (indices[k] >= nb) sys->row_needs_halo[(size_t)i] = 1;
+                if (indices[k] >= nb) {
+                    sys->row_needs_halo[(size_t)i] = 1;
+                    sys->halo_refs.emplace_back((int32_t)i, indices[k]);
+                }
     }
     sys->dict_skipped = dict_skipped;
     sys->onsite_streamed = onsite_streamed;
@@ -355,6 +358,7 @@ int bdg_slab_set_exchange(bdg_system* sys, bdg_comm* comm, int32_t n_peers, cons
         HIP_TRY(hipMemcpy(sys->send_rows.ptr, send_rows, sizeof(int64_t) * send_total, hipMemcpyHostToDevice));
     }
     sys->peers = std::move(peers);
+    sys->send_rows_host.assign(send_rows, send_rows + send_total);
     sys->send_total = send_total;
     sys->recv_total = recv_total;
     sys->slab_comm = comm;
@@ -389,12 +393,33 @@ int bdg_group_create(bdg_system** members, int32_t n_members, bdg_group** out) {
     group->members.assign(members, members + n_members);
     group->packed.resize(n_members);
     group->copied.resize(n_members);
+    group->stepped[0].resize(n_members);
+    group->stepped[1].resize(n_members);
+    int64_t group_rows = 0;
+    for (int m = 0; m < n_members; ++m) group_rows += members[m]->nb;
     for (int m = 0; m < n_members; ++m) {
         (void)hipSetDevice(members[m]->device);
         if (hipEventCreateWithFlags(&group->packed[m], hipEventDisableTiming) != hipSuccess ||
-            hipEventCreateWithFlags(&group->copied[m], hipEventDisableTiming) != hipSuccess) {
+            hipEventCreateWithFlags(&group->copied[m], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&group->stepped[0][m], hipEventDisableTiming) != hipSuccess ||
+            hipEventCreateWithFlags(&group->stepped[1][m], hipEventDisableTiming) != hipSuccess) {
             delete group;
             return fail(BDG_EDEVICE, "event creation failed");
+        }
+        members[m]->group_rows = group_rows;
+        members[m]->group_peer_access = true;
+        members[m]->stencil_state = 0;  // (examined again with the group in view)
+        // members on different GPUs read each other's boundary planes in place: needs peer access
+        for (const ExchangePeer& peer : members[m]->peers) {
+            const int other = members[peer.rank]->device;
+            if (other == members[m]->device) continue;
+            int can = 0;
+            if (hipDeviceCanAccessPeer(&can, members[m]->device, other) == hipSuccess && can) {
+                const hipError_t err = hipDeviceEnablePeerAccess(other, 0);
+                if (err != hipSuccess && err != hipErrorPeerAccessAlreadyEnabled) can = 0;
+                (void)hipGetLastError();
+            }
+            members[m]->group_peer_access = members[m]->group_peer_access && can;
         }
     }
     *out = group;
@@ -408,6 +433,10 @@ int bdg_group_destroy(bdg_group* group) {
         (void)hipStreamSynchronize(group->members[m]->stream);
         if (group->packed[m]) (void)hipEventDestroy(group->packed[m]);
         if (group->copied[m]) (void)hipEventDestroy(group->copied[m]);
+        for (auto& events : group->stepped)
+            if (events[m]) (void)hipEventDestroy(events[m]);
+        group->members[m]->group_rows = 0;
+        group->members[m]->group_lo = group->members[m]->group_hi = bdg_system::NeighbourPlane{};
     }
     delete group;
     return BDG_OK;

@@ -92,6 +92,19 @@ struct bdg_system {
     int64_t slab_max_ncols = 0;
     // overlap of the halo exchange with the rows that do not need it
     std::vector<uint8_t> row_needs_halo;  // host: block row reads at least one halo column
+    std::vector<std::pair<int32_t, int32_t>> halo_refs;  // host: every (block row, halo column) pair of the matrix
+    std::vector<int64_t> send_rows_host;                 // host copy of send_rows (per peer, concatenated)
+    // Same-process slab groups (bdg_group_create): lattice-stencil slabs read the neighbouring slab's t_n in
+    // place.  stencil_lo_base / hi_base: first halo column of the plane below plane 0 / above plane lx-1
+    // (-1: none); group_rows: block rows of the whole group (kernel choice goes by the size of the lattice,
+    // not of the slab); lo / hi: which member holds that plane and where (filled by the group).
+    int stencil_lo_base = -1, stencil_hi_base = -1;
+    int64_t group_rows = 0;
+    struct NeighbourPlane {
+        bdg_system* owner = nullptr;
+        int64_t site0 = 0;
+    } group_lo, group_hi;
+    bool group_peer_access = true;  // every peer of this member sits on the same GPU or one it can address
     hipStream_t comm_stream = nullptr;
     hipEvent_t ev_step_done = nullptr, ev_halo_ready = nullptr;
     DeviceBuffer<int> tiles_interior, tiles_boundary;
@@ -150,4 +163,5 @@ struct bdg_comm {
 struct bdg_group {
     std::vector<bdg_system*> members;
     std::vector<hipEvent_t> packed, copied;  // per member
+    std::vector<hipEvent_t> stepped[2];      // per member, alternating by step parity (zero-copy stencil slabs)
 };

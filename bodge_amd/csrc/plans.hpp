@@ -488,10 +488,31 @@ int ensure_stencil(bdg_system* sys, int* kind) {
     const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
     if (sys->stencil_state == 0) {
         sys->stencil_state = -1;
+        sys->stencil_lo_base = sys->stencil_hi_base = -1;
         const bool shaped = plane >= 2 * bdg::kSweepOwned && sys->shape[0] >= 8 &&
                             (int64_t)sys->shape[0] * plane == sys->nb;
         const bool three_d = sys->shape[1] > 1 && sys->shape[2] > 1;
-        if (shaped && sys->ncols == sys->nb && sys->n_unique > 0 && sys->n_unique < (int)bdg::kNoBlock &&
+        // A row slab (ncols > nb) of a 3-D lattice qualifies if its halo columns are exactly the plane below
+        // its first plane and / or the plane above its last one, referenced position by position.
+        bool slab_ok = sys->ncols == sys->nb;
+        if (!slab_ok && shaped && three_d) {
+            slab_ok = true;
+            const int64_t lx = sys->shape[0];
+            int64_t lo = -1, hi = -1;
+            for (const auto& ref : sys->halo_refs) {
+                const int64_t x = ref.first / plane, p = ref.first % plane, base = (int64_t)ref.second - p;
+                if (x == 0 && (lo < 0 || lo == base)) lo = base;
+                else if (x == lx - 1 && (hi < 0 || hi == base)) hi = base;
+                else slab_ok = false;
+            }
+            for (int64_t base : {lo, hi})
+                if (base >= 0 && (base < sys->nb || base + plane > sys->ncols)) slab_ok = false;
+            if (slab_ok) {
+                sys->stencil_lo_base = (int)lo;
+                sys->stencil_hi_base = (int)hi;
+            }
+        }
+        if (shaped && slab_ok && sys->n_unique > 0 && sys->n_unique < (int)bdg::kNoBlock &&
             sys->max_row_blocks <= (three_d ? 7 : 5) && sys->nnzb > 0 && !(three_d && sys->onsite_streamed)) {
             if (int rc = sys->stencil.reserve((size_t)sys->nb)) return rc;
             DeviceBuffer<int> bad;
@@ -503,7 +524,8 @@ int ensure_stencil(bdg_system* sys, int* kind) {
                 if (three_d)
                     bdg::build_stencil3<<<grid, 256, 0, sys->stream>>>(sys->indptr.ptr, sys->dict_ids.ptr,
                                                                         sys->dict_diagonal.ptr, (int)sys->nb, (int)plane,
-                                                                        sys->shape[2], sys->stencil.ptr, bad.ptr);
+                                                                        sys->shape[2], sys->stencil_lo_base, sys->stencil_hi_base,
+                                                                        sys->stencil.ptr, bad.ptr);
                 else
                     bdg::build_stencil<<<grid, 256, 0, sys->stream>>>(sys->indptr.ptr, sys->dict_ids.ptr,
                                                                        sys->dict_diagonal.ptr, (int)sys->nb, (int)plane,
@@ -534,13 +556,20 @@ int ensure_stencil(bdg_system* sys, int* kind) {
 int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, int* kind) {
     *kind = 0;
     const char* env = knob::raw("BODGE_AMD_SWEEP");
-    if ((env && env[0] == '0') || !random_start || col_scalars || !sys->peers.empty()) return BDG_OK;
+    if ((env && env[0] == '0') || !random_start || col_scalars) return BDG_OK;
+    // Row slabs: members of a same-process group may run the 3-D rolling kernel, which reads the neighbouring
+    // slabs' boundary planes where they are; slabs exchanging halos through RCCL keep the one-step kernels
+    // (their exchange is overlapped with the rows that do not need it, Batch::step_overlapped).
+    const bool slab = !sys->peers.empty() || sys->ncols != sys->nb;
+    if (slab && (sys->slab_comm || sys->group_rows == 0)) return BDG_OK;
     const bool forced = env && env[0] == '1';
-    if (!forced && sys->nb < std::min(kSweepMinSites, kRollMinSites)) return BDG_OK;
+    const int64_t lattice_rows = std::max(sys->nb, sys->group_rows);  // (the size of the lattice, not of the slab, decides)
+    if (!forced && lattice_rows < std::min(kSweepMinSites, kRollMinSites)) return BDG_OK;
     const char* dict_env = knob::raw("BODGE_AMD_DICT");
     if (dict_env && dict_env[0] == '0') return BDG_OK;
     if (int rc = ensure_stencil(sys, kind)) return rc;
-    if (!forced && sys->nb < (*kind == 2 ? kRollMinSites : kSweepMinSites)) *kind = 0;
+    if (slab && *kind != 2) *kind = 0;  // (2-D multi-step sweeps would need three-plane halos: not built)
+    if (!forced && lattice_rows < (*kind == 2 ? kRollMinSites : kSweepMinSites)) *kind = 0;
     return BDG_OK;
 }
 
@@ -702,6 +731,7 @@ int make_roll_plan(bdg_system* sys, const ModeInfo& mode, int lanes, RollPlan* p
     if (int rc = ensure_dict_table(sys, mode, &a.dict_table)) return rc;
     a.n_unique = sys->n_unique;
     a.nb = (int)sys->nb;
+    a.ld = (int)sys->ncols;
     a.plane = (int)plane;
     a.lz = sys->shape[2];
     a.lx = sys->shape[0];

@@ -38,6 +38,11 @@ struct Batch {
     SweepPlan splan;
     RollPlan rplan;
     double2 *spare1 = nullptr, *spare2 = nullptr;
+    // rolling kernel on a row slab: where t_n of the planes just outside the slab is read.  Default = the
+    // halo rows of this handle's own buffer (filled by the exchange); a same-process group points these
+    // at the neighbouring members' buffers instead and skips the exchange (run_group).
+    const double2 *ext_lo = nullptr, *ext_hi = nullptr;
+    int64_t ext_lo_site0 = 0, ext_lo_ld = 0, ext_hi_site0 = 0, ext_hi_ld = 0;
     int launch_grid = 0;   // workgroups whose dot partials one recurrence step leaves behind
     int n_launches = 0;
 
@@ -425,6 +430,17 @@ struct Batch {
             ra.partial = args.partial;
             ra.reverse = args.reverse;
             ra.stream = args.stream_vectors;
+            ra.lo_buf = ra.hi_buf = nullptr;
+            if (sys->stencil_lo_base >= 0) {
+                ra.lo_buf = ext_lo ? ext_lo : cur;
+                ra.lo_site0 = (int)(ext_lo ? ext_lo_site0 : sys->stencil_lo_base);
+                ra.lo_ld = (int)(ext_lo ? ext_lo_ld : sys->ncols);
+            }
+            if (sys->stencil_hi_base >= 0) {
+                ra.hi_buf = ext_hi ? ext_hi : cur;
+                ra.hi_site0 = (int)(ext_hi ? ext_hi_site0 : sys->stencil_hi_base);
+                ra.hi_ld = (int)(ext_hi ? ext_hi_ld : sys->ncols);
+            }
             rplan.kernel<<<rplan.grid, bdg::kBlockThreads, rplan.lds_bytes, st>>>(ra);
         } else {
             plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
@@ -690,15 +706,88 @@ int run_group(bdg_group* group, double scale, int n_steps, int n_vectors, StartS
     const char* real_env = knob::raw("BODGE_AMD_REAL");
     const int force_real = (all_real && start_is_real && !(real_env && real_env[0] == '0')) ? 1 : 0;
 
-    for (int col = 0; col < n_vectors; col += 64) {
+    // Where a member that runs the rolling stencil kernel finds the plane below / above its slab in the
+    // member that owns it: the rows that member would send are one whole plane, in order.
+    auto neighbour_plane = [&](size_t m, int base, bdg_system::NeighbourPlane* out) -> bool {
+        bdg_system* sys = group->members[m];
+        const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
+        for (const ExchangePeer& peer : sys->peers) {
+            if (base < peer.recv_col || base + plane > peer.recv_col + peer.recv_count) continue;
+            bdg_system* src = group->members[peer.rank];
+            for (const ExchangePeer& back : src->peers) {
+                if (back.rank != (int)m) continue;
+                const int64_t first = back.send_begin + (base - peer.recv_col);
+                if (first + plane > (int64_t)src->send_rows_host.size()) return false;
+                for (int64_t j = 1; j < plane; ++j)
+                    if (src->send_rows_host[(size_t)(first + j)] != src->send_rows_host[(size_t)first] + j) return false;
+                out->owner = src;
+                out->site0 = src->send_rows_host[(size_t)first];
+                return true;
+            }
+        }
+        return false;
+    };
+
+    const int width = batch_width(group->members[0], start, n_vectors);
+    for (int col = 0; col < n_vectors; col += width) {
         std::vector<Batch> batch(n_members);
         for (size_t m = 0; m < n_members; ++m)
-            if (int rc = batch[m].begin(group->members[m], scale, n_steps, std::min(64, n_vectors - col),
+            if (int rc = batch[m].begin(group->members[m], scale, n_steps, std::min(width, n_vectors - col),
                                         batch_start(start, col), force_real))
                 return rc;
         for (size_t m = 1; m < n_members; ++m)
             if (batch[m].rl != batch[0].rl)
                 return fail(BDG_EINVAL, "group members chose different kernel configurations");
+        // Zero-copy: every member runs the rolling stencil kernel and can address its neighbours' buffers.
+        // Then no halo row is packed, copied or unpacked: step n of a member waits for step n-1 of its
+        // neighbours (their t_n is complete, and they have finished reading the buffer step n overwrites).
+        bool zero_copy = true;
+        for (size_t m = 0; m < n_members; ++m) {
+            bdg_system* sys = group->members[m];
+            zero_copy = zero_copy && batch[m].roll && sys->group_peer_access;
+            if (!zero_copy) break;
+            sys->group_lo = sys->group_hi = bdg_system::NeighbourPlane{};
+            if (sys->stencil_lo_base >= 0) zero_copy = zero_copy && neighbour_plane(m, sys->stencil_lo_base, &sys->group_lo);
+            if (sys->stencil_hi_base >= 0) zero_copy = zero_copy && neighbour_plane(m, sys->stencil_hi_base, &sys->group_hi);
+        }
+        if (zero_copy) {
+            auto index_of = [&](bdg_system* sys) {
+                for (size_t m = 0; m < n_members; ++m)
+                    if (group->members[m] == sys) return m;
+                return (size_t)0;
+            };
+            for (size_t m = 0; m < n_members; ++m) {  // t_0 written everywhere before anyone reads a neighbour's
+                HIP_TRY(hipSetDevice(group->members[m]->device));
+                HIP_TRY(hipEventRecord(group->stepped[1][m], group->members[m]->stream));
+            }
+            for (int n = 0; n < n_steps; ++n) {
+                for (size_t m = 0; m < n_members; ++m) {
+                    bdg_system* sys = group->members[m];
+                    HIP_TRY(hipSetDevice(sys->device));
+                    Batch& b = batch[m];
+                    b.ext_lo = b.ext_hi = nullptr;
+                    for (const bdg_system::NeighbourPlane* side : {&sys->group_lo, &sys->group_hi}) {
+                        if (!side->owner) continue;
+                        const size_t o = index_of(side->owner);
+                        HIP_TRY(hipStreamWaitEvent(sys->stream, group->stepped[(n + 1) & 1][o], 0));
+                        (side == &sys->group_lo ? b.ext_lo : b.ext_hi) = batch[o].cur;
+                        (side == &sys->group_lo ? b.ext_lo_site0 : b.ext_hi_site0) = side->site0;
+                        (side == &sys->group_lo ? b.ext_lo_ld : b.ext_hi_ld) = side->owner->ncols;
+                    }
+                    if (int rc = b.step(n)) return rc;  // (swaps b.cur / b.prev: the neighbours later in this loop must see t_n)
+                    std::swap(b.cur, b.prev);
+                }
+                for (size_t m = 0; m < n_members; ++m) {
+                    bdg_system* sys = group->members[m];
+                    HIP_TRY(hipSetDevice(sys->device));
+                    std::swap(batch[m].cur, batch[m].prev);
+                    HIP_TRY(hipEventRecord(group->stepped[n & 1][m], sys->stream));
+                }
+            }
+            for (size_t m = 0; m < n_members; ++m)
+                if (int rc = batch[m].finish(d_out, e_out, n_vectors, col, m > 0, col == 0)) return rc;
+            continue;
+        }
         const size_t unit = (size_t)4 * batch[0].rl * sizeof(double2);  // bytes per exchanged block row
         for (int n = 0; n < n_steps; ++n) {
             for (size_t m = 0; m < n_members; ++m) {

@@ -71,7 +71,7 @@ struct SweepArgs {
     int two;                 // cheb_sweep: 1 = both steps, 0 = step 1 only (odd tail of a run)
     int steps;               // cheb_sweep3: steps this launch makes, 1..3 (out1 = t_{n+steps-1}, out2 = t_{n+steps})
     double* partial3;        // cheb_sweep3: dots of step 3
-    int stream;              // non-temporal hints: bit 0 t_{n-1} loads, bit 1 stores, bit 2 t_n loads
+    int stream;              // non-temporal hints: bit 0 t_{n-1} loads, bit 1 stores, bit 2 t_n loads, bit 3 on-site records
     int zigzag;              // 1 = odd segments march against the even ones
     int wrap_p;              // 1 = the plane is a ring: position P-1 neighbours position 0 (periodic edge blocks)
     int wrap_x;              // 1 = the planes form a ring: plane lx-1 neighbours plane 0
@@ -403,7 +403,7 @@ constexpr int sweep3_owned(int rl) { return kWave / rl - 6; }
 // every diagonal block distinct and defeat the dictionary, while the bond blocks still come from a
 // handful of distinct ones.  Then only the bonds sit in the LDS table; the diagonal block of every
 // site is read from a per-site stream in HBM exactly once per launch (Mode::kOnsiteSlots x 16 B,
-// non-temporal, whole-wave contiguous loads one plane ahead of their first use) into a wave-private
+// whole-wave contiguous loads one plane ahead of their first use) into a wave-private
 // LDS ring of three planes, because step j of iteration k works on plane k-j+1: plane k's blocks
 // serve step 1 now, step 2 in the next iteration and step 3 in the one after.  Only with 4 lanes
 // per site (16 slots: the ring is 3 x 16 x kOnsiteStride slots per wave) and the particle-hole modes.
@@ -595,8 +595,12 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
                     const bool in_e = pe >= 0 && pe < a.plane;
                     const int pwe = in_e ? pe : ((pe % a.plane) + a.plane) % a.plane;
                     out[j] = zero;
-                    if (wanted && slot < SLOTS && (in_e || a.wrap_p) && k >= 0 && k < a.lx)
-                        out[j] = load_stream(a.onsite + ((size_t)k * a.plane + pwe) * PIECES + part);
+                    // (plain loads: the halo slots of the neighbouring windows read the same records - 16 slots
+                    // per 10 owned - and should find them in L2; a.stream bit 3 = non-temporal, for A/B runs)
+                    if (wanted && slot < SLOTS && (in_e || a.wrap_p) && k >= 0 && k < a.lx) {
+                        const double2* src = a.onsite + ((size_t)k * a.plane + pwe) * PIECES + part;
+                        out[j] = (a.stream & 8) ? load_stream(src) : *src;
+                    }
                 }
             }
         };
@@ -769,20 +773,37 @@ struct RollArgs {
     int n_segs;
     int stream;              // non-temporal hints: bit 0 t_{n-1} loads, bit 1 stores
     int reverse;             // 1 = march every segment from its far end (launches alternate)
+    // Row slabs (a stack of whole x-planes of a larger lattice, one handle per slab): the vector buffers
+    // have `ld` block rows per component plane (own rows + halo rows), and t_n of the plane below plane 0 /
+    // above plane lx-1 is read where the neighbouring slab keeps it - `lo_buf` / `hi_buf` point into that
+    // slab's own t_n buffer (same process: no copy, no pack / unpack; block row lo_site0 + p of a buffer
+    // with lo_ld rows per component plane).  nullptr = no neighbour on that side (the lattice ends there).
+    int ld;
+    const double2* lo_buf;
+    const double2* hi_buf;
+    int lo_site0, lo_ld, hi_site0, hi_ld;
 };
 
+// Row slabs: columns >= nb are halo rows.  The only ones a stencil may reference are the plane below
+// the slab's first plane (local column lo_base + p, from rows of plane 0) and the plane above its last
+// (hi_base + p, from rows of plane lx-1); lo_base / hi_base = -1 where the slab has no such neighbour.
 __global__ void build_stencil3(const int* __restrict__ indptr, const int* __restrict__ words,
-                               const int* __restrict__ diagonal, int nb, int plane, int lz,
+                               const int* __restrict__ diagonal, int nb, int plane, int lz, int lo_base, int hi_base,
                                uint2* __restrict__ stencil, int* __restrict__ bad) {
+    const int lx = nb / plane;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
         unsigned id[8] = {kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock, kNoBlock, 0u};
-        const int p = i % plane, z = p % lz, y = p / lz, ly = plane / lz;
+        const int p = i % plane, z = p % lz, y = p / lz, ly = plane / lz, x = i / plane;
         bool ok = true;
         for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
             const unsigned w = (unsigned)words[k];
-            const int off = (int)(w & 0xFFFFFFu) - i;
+            const int col = (int)(w & 0xFFFFFFu);
+            const int off = col - i;
             int slot = -1;
-            if (off == -plane) slot = 0;
+            if (col >= nb) {
+                if (x == 0 && lo_base >= 0 && col == lo_base + p) slot = 0;
+                else if (x == lx - 1 && hi_base >= 0 && col == hi_base + p) slot = 6;
+            } else if (off == -plane) slot = 0;
             else if (off == -lz && y >= 1) slot = 1;
             else if (off == -1 && z >= 1) slot = 2;
             else if (off == 0) slot = 3;
@@ -830,7 +851,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
 
     double dot[4] = {0.0, 0.0, 0.0, 0.0};
     const double2 zero = make_double2(0.0, 0.0);
-    const size_t nb = (size_t)a.nb;
+    const size_t nb = (size_t)a.ld;  // block rows per component plane of this handle's vector buffers
     const bool nt_prev = a.stream & 1, nt_store = a.stream & 2;
 
     for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
@@ -855,6 +876,22 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
                 for (int al = 0; al < 4; ++al) out[al] = zero;
             }
         };
+        // t_n of the lane's own position in plane k; planes -1 and lx are the neighbouring slabs' (if any)
+        auto load_cur = [&](int k, bool wanted, double2 out[4]) {
+            k = act(k);
+            const double2* buf = a.cur;
+            size_t site = (size_t)k * a.plane + p, ld = nb;
+            bool there = k >= 0 && k < a.lx;
+            if (k == -1 && a.lo_buf) buf = a.lo_buf, site = (size_t)a.lo_site0 + p, ld = (size_t)a.lo_ld, there = true;
+            if (k == a.lx && a.hi_buf) buf = a.hi_buf, site = (size_t)a.hi_site0 + p, ld = (size_t)a.hi_ld, there = true;
+            if (wanted && there) {
+#pragma unroll
+                for (int al = 0; al < 4; ++al) out[al] = buf[vslot(al, site, r, ld, RL)];
+            } else {
+#pragma unroll
+                for (int al = 0; al < 4; ++al) out[al] = zero;
+            }
+        };
         auto load_ids = [&](int k) {
             uint2 w = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
             k = act(k);
@@ -865,9 +902,9 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
 
         // ---- prologue: t_n of planes x0-1, x0, x0+1; t_{n-1}, ids and y-neighbours of plane x0
         double2 cn_m[4], cn_0[4], cn_p[4], pv[4], ym[4], yp[4];
-        load_plane(a.cur, false, x0 - 1, 0, valid, cn_m);
-        load_plane(a.cur, false, x0, 0, valid, cn_0);
-        load_plane(a.cur, false, x0 + 1, 0, valid, cn_p);
+        load_cur(x0 - 1, valid, cn_m);
+        load_cur(x0, valid, cn_0);
+        load_cur(x0 + 1, valid, cn_p);
         load_plane(a.prev, nt_prev, x0, 0, owned, pv);
         uint2 ids = load_ids(x0);
         load_plane(a.cur, false, x0, -a.lz, owned && id_of(ids, 1) != kNoBlock, ym);
@@ -877,7 +914,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
             // ---- prefetch for the next iteration
             double2 nx_cn[4], nx_pv[4], nx_ym[4], nx_yp[4];
             const bool more = k + 1 < x1;
-            load_plane(a.cur, false, k + 2, 0, valid && more, nx_cn);
+            load_cur(k + 2, valid && more, nx_cn);
             load_plane(a.prev, nt_prev, k + 1, 0, owned && more, nx_pv);
             const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
             load_plane(a.cur, false, k + 1, -a.lz, owned && more && id_of(nx_ids, 1) != kNoBlock, nx_ym);

@@ -275,7 +275,7 @@ class SlabGroup:
     several GPUs of the node (`devices`); halo rows move by device-to-device copies.
     """
 
-    def __init__(self, indptr, indices, data, n_slabs: int, granule: int = 1, devices=None):
+    def __init__(self, indptr, indices, data, n_slabs: int, granule: int = 1, devices=None, lattice_shape=None):
         from . import slab
 
         n_rows = len(indptr) - 1
@@ -283,6 +283,11 @@ class SlabGroup:
         self.plans = [slab.build_plan(indptr, indices, data, self.bounds, r) for r in range(n_slabs)]
         devices = [None] * n_slabs if devices is None else list(devices)
         self.members = [DeviceSolver.from_slab_plan(p, device=d) for p, d in zip(self.plans, devices)]
+        if lattice_shape is not None and granule == lattice_shape[1] * lattice_shape[2]:
+            # geometry hint per slab (a stack of whole x-planes): lets a 3-D slab run the stencil kernel that
+            # reads its neighbours' boundary planes in place instead of exchanging halo rows
+            for member, plan in zip(self.members, self.plans):
+                member.set_lattice_shape((plan.n_own // granule, lattice_shape[1], lattice_shape[2]))
         self._lib = backend.load()
         self._handle = C.c_void_p()
         handles = (C.c_void_p * n_slabs)(*[m._handle for m in self.members])
@@ -294,7 +299,9 @@ class SlabGroup:
         from . import slab
 
         indptr, indices, data = system.bsr_arrays()
-        return cls(indptr, indices, data, n_slabs, slab.lattice_granule(system.lattice), devices)
+        shape = getattr(system.lattice, "shape", None)
+        return cls(indptr, indices, data, n_slabs, slab.lattice_granule(system.lattice), devices,
+                   lattice_shape=tuple(shape) if shape is not None and len(shape) == 3 else None)
 
     def dots_random(self, scale, n_steps, n_vectors, seed=0, first_id=0, kind=VEC_RADEMACHER):
         d = np.empty((n_steps, n_vectors))

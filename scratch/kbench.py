@@ -3,7 +3,7 @@
 usage: python3 scratch/kbench.py "NAME=ENV1=V1,ENV2=V2" "NAME2=..." [--lattice 1000,1000,1] [--vectors 8] [--rounds 5]
 """
 import os, sys, time
-sys.path.insert(0, ".")
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import numpy as np
 import bench
 from bodge_amd import backend, chebyshev

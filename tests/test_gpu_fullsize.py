@@ -269,6 +269,8 @@ def test_config4_100cubed_dwave_256_moments_full_length_whole_and_slabs_against_
         mono = whole.dots_random(scale, moments // 2, vectors, seed=4)
     with SlabGroup.from_hamiltonian(system, 8) as group:
         split = group.dots_random(scale, moments // 2, vectors, seed=4)
+        # slabs of 12 / 13 whole planes: the rolling stencil kernel, neighbours' boundary planes read in place
+        assert all(member.perf()["rolling"] == 1 and member.perf()["launches"] == moments // 2 for member in group.members)
     for d, e in (mono, split):
         assert np.abs(d - d_ref).max() <= 1e-12 * n and np.abs(e - e_ref).max() <= 1e-12 * n
         f = chebyshev.free_energy_series(chebyshev.dots_to_moments(d, e).mean(axis=1), scale, temperature)

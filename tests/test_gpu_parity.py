@@ -945,6 +945,43 @@ def test_slab_group_matches_whole_matrix(api, solver_cls, name, n_slabs, n_vecto
     assert np.allclose(unit_split[1], unit_ref[1], rtol=0, atol=1e-13)
 
 
+@pytest.mark.parametrize("shape,kind,n_slabs,n_vectors,vec_kind,periodic_x", [
+    ((32, 6, 8), "dwave", 3, 8, cheb_ref.VEC_RADEMACHER, False),   # slabs of 11 / 11 / 10 planes, 4 lanes per site
+    ((27, 5, 7), "dwave", 2, 3, cheb_ref.VEC_RADEMACHER, False),   # 14 / 13 planes, 2 lanes per site (<= 4 real vectors)
+    ((26, 6, 6), "peierls", 3, 6, cheb_ref.VEC_Z4, False),         # complex blocks, two batches of 4 and 2 vectors
+    ((24, 6, 8), "swave", 3, 8, cheb_ref.VEC_RADEMACHER, True),    # ring of planes: slab 0 and slab 2 are neighbours too
+])
+def test_stencil_slabs_read_their_neighbours_planes_in_place(api, solver_cls, knobs, block_storage, shape, kind, n_slabs,
+                                                             n_vectors, vec_kind, periodic_x):
+    """Same-process slab groups of a 3-D lattice whose slabs are stacks of >= 8 whole x-planes run the
+    rolling stencil kernel (cheb_roll3) and read the planes just outside a slab directly from the
+    neighbouring member's buffer: no pack, copy or unpack.  Against the undivided matrix, the oracle,
+    and the exchange-based form of the same group (stencil kernels off)."""
+    from bodge_amd.solver import SlabGroup
+
+    system = _sweep_system(api, shape, kind)
+    if periodic_x:
+        with system as (H, Δ):
+            H.set_edges(-0.8 * api.σ0 + 0.1 * api.σ3, axis=0)
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    n, steps = bsr.shape[0], 9
+    ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 6, range(n_vectors), vec_kind))
+    with SlabGroup.from_hamiltonian(system, n_slabs) as group:
+        assert all(plan.n_own // (shape[1] * shape[2]) >= 8 for plan in group.plans)
+        knobs.set("BODGE_AMD_SWEEP", "0")
+        exchanged = group.dots_random(scale, steps, n_vectors, seed=6, kind=vec_kind)
+        assert all(member.perf()["rolling"] == 0 for member in group.members)
+        knobs.set("BODGE_AMD_SWEEP", "1")
+        in_place = group.dots_random(scale, steps, n_vectors, seed=6, kind=vec_kind)
+        rolled = [member.perf()["rolling"] for member in group.members]
+        again = group.dots_random(scale, steps, n_vectors, seed=6, kind=vec_kind)
+    assert rolled == [1 if block_storage == "dictionary" else 0] * n_slabs  # (the stencil forms read the block dictionary)
+    assert np.array_equal(in_place[0], again[0]) and np.array_equal(in_place[1], again[1])
+    for got in (exchanged, in_place):
+        assert np.abs(got[0] - ref[0]).max() <= 1e-12 * n and np.abs(got[1] - ref[1]).max() <= 1e-12 * n
+
+
 # ------------------------------------------------------------------ Lanczos / gap
 @pytest.mark.parametrize("name,k", [("swave20", 3), ("complex235", 2), ("snf", 2), ("chain128", 3), ("dwave8", 2)])
 def test_lowest_eigenvalues_match_dense_spectrum(api, golden, name, k):
