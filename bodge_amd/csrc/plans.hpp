@@ -460,32 +460,9 @@ SweepKernel sweep3_kernel(const ModeInfo& mode, int lanes, bool reverse) {
     return sweep3_kernel_for<ComplexMode>(lanes, reverse);
 }
 
-// generic-depth form (cheb_sweepn): four steps per sweep; three for A/B runs against cheb_sweep3
-using SweepNKernel = void (*)(bdg::SweepNArgs);
-
-template <typename Mode>
-SweepNKernel sweepn_kernel_for(int lanes, bool reverse, int depth) {
-    if (depth == 4 && lanes == 2) return reverse ? bdg::cheb_sweepn<Mode, 2, true, 4> : bdg::cheb_sweepn<Mode, 2, false, 4>;
-    if (depth == 4 && lanes == 4) return reverse ? bdg::cheb_sweepn<Mode, 4, true, 4> : bdg::cheb_sweepn<Mode, 4, false, 4>;
-    return nullptr;
-}
-
-SweepNKernel sweepn_kernel(const ModeInfo& mode, int lanes, bool reverse, int depth) {
-    if (depth == 3 && lanes == 2 && mode.id == 3)  // A/B of the generic form against the hand-unrolled cheb_sweep3
-        return reverse ? bdg::cheb_sweepn<RealPHMode, 2, true, 3> : bdg::cheb_sweepn<RealPHMode, 2, false, 3>;
-    switch (mode.id) {
-        case 1: return sweepn_kernel_for<RealMode>(lanes, reverse, depth);
-        case 2: return sweepn_kernel_for<ComplexPHMode>(lanes, reverse, depth);
-        case 3: return sweepn_kernel_for<RealPHMode>(lanes, reverse, depth);
-    }
-    return sweepn_kernel_for<ComplexMode>(lanes, reverse, depth);
-}
-
 struct SweepPlan {
     int lanes = bdg::kSweepLanes;
-    int depth = 2;  // recurrence steps per sweep: 2 (cheb_sweep), 3 (cheb_sweep3) or 4 (cheb_sweepn)
-    bool generic = false;  // cheb_sweepn (always for depth 4; depth 3 with BODGE_AMD_SWEEP_GENERIC=1)
-    SweepNKernel kernel_n = nullptr, kernel_n_reverse = nullptr;
+    int depth = 2;  // recurrence steps per sweep: 2 (cheb_sweep) or 3 (cheb_sweep3)
     SweepKernel kernel = nullptr, kernel_reverse = nullptr;
     SweepKernel kernel_gen = nullptr;  // depth 3: first sweep of a random-start run, t_0 made in registers
     int grid = 0;
@@ -602,21 +579,12 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     const bool streamed = sys->onsite_streamed;
     if (streamed && (lanes != 4 || depth != 3 || !mode.ph))
         return fail(BDG_EINVAL, "streamed on-site blocks need the three-step sweep with 4 lanes per site and particle-hole packed blocks");
-    plan->generic = !streamed && (depth == 4 || (depth == 3 && knob::raw("BODGE_AMD_SWEEP_GENERIC") != nullptr &&
-                                                   sweepn_kernel(mode, lanes, false, 3) != nullptr));
-    if (plan->generic) {
-        plan->kernel_n = sweepn_kernel(mode, lanes, false, depth);
-        plan->kernel_n_reverse = sweepn_kernel(mode, lanes, true, depth);
-        plan->kernel = plan->kernel_reverse = plan->kernel_gen = nullptr;
-        if (!plan->kernel_n) return fail(BDG_EINVAL, "no %d-step sweep kernel with %d lanes per site", depth, lanes);
-    } else {
-        plan->kernel = streamed ? sweep3_streamed_kernel(mode, false, false)
-                                : depth == 3 ? sweep3_kernel(mode, lanes, false) : sweep_kernel(mode, lanes, false);
-        plan->kernel_reverse = streamed ? sweep3_streamed_kernel(mode, true, false)
-                                        : depth == 3 ? sweep3_kernel(mode, lanes, true) : sweep_kernel(mode, lanes, true);
-        plan->kernel_gen = streamed ? sweep3_streamed_kernel(mode, false, true) : depth == 3 ? sweep3_gen_kernel(mode, lanes) : nullptr;
-        if (!plan->kernel) return fail(BDG_EINVAL, "the sweep kernel has 1, 2 or 4 lanes per site, not %d", lanes);
-    }
+    plan->kernel = streamed ? sweep3_streamed_kernel(mode, false, false)
+                            : depth == 3 ? sweep3_kernel(mode, lanes, false) : sweep_kernel(mode, lanes, false);
+    plan->kernel_reverse = streamed ? sweep3_streamed_kernel(mode, true, false)
+                                    : depth == 3 ? sweep3_kernel(mode, lanes, true) : sweep_kernel(mode, lanes, true);
+    plan->kernel_gen = streamed ? sweep3_streamed_kernel(mode, false, true) : depth == 3 ? sweep3_gen_kernel(mode, lanes) : nullptr;
+    if (!plan->kernel) return fail(BDG_EINVAL, "the sweep kernel has 1, 2 or 4 lanes per site, not %d", lanes);
     const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
     if (table > table_limit(sys)) return fail(BDG_EINVAL, "block table too large for the sweep kernel");
     size_t rows = (size_t)bdg::kSweepWaves * depth * bdg::kWave * 4 * sizeof(double2);
@@ -625,14 +593,12 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
                 (mode.real ? RealPHMode::kOnsiteStride : ComplexPHMode::kOnsiteStride) * sizeof(double2);
     plan->lds_bytes = table + rows;
     if (plan->lds_bytes > 64 * 1024)
-        for (const void* k : {reinterpret_cast<const void*>(plan->kernel), reinterpret_cast<const void*>(plan->kernel_reverse),
-                              reinterpret_cast<const void*>(plan->kernel_gen), reinterpret_cast<const void*>(plan->kernel_n),
-                              reinterpret_cast<const void*>(plan->kernel_n_reverse)})
-            if (k) HIP_TRY(hipFuncSetAttribute(k, hipFuncAttributeMaxDynamicSharedMemorySize, (int)plan->lds_bytes));
+        for (SweepKernel k : {plan->kernel, plan->kernel_reverse, plan->kernel_gen})
+            if (k) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)plan->lds_bytes));
     int per_cu = 0;
-    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(
-        &per_cu, plan->generic ? reinterpret_cast<const void*>(plan->kernel_n) : reinterpret_cast<const void*>(plan->kernel),
-        bdg::kSweepThreads, plan->lds_bytes));
+    HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(plan->kernel),
+                                                         bdg::kSweepThreads, plan->lds_bytes));
     per_cu = std::max(1, std::min(per_cu, 2 * bdg::kWavesPerBlock / bdg::kSweepWaves));
     if (const char* cap = knob::raw("BODGE_AMD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(cap));
     const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
@@ -646,7 +612,7 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     a.nb = (int)sys->nb;
     a.plane = (int)plane;
     a.lx = sys->shape[0];
-    const int owned = bdg::kWave / lanes - 2 * depth;  // window slots minus `depth` halo slots on either side
+    const int owned = depth == 3 ? bdg::sweep3_owned(lanes) : bdg::sweep_owned(lanes);
     a.n_cols = (int)((plane + owned - 1) / owned);
     // one unit (segment x window) per resident wave, segments of at least 8 planes
     const int waves = per_cu * sys->num_cus * bdg::kSweepWaves;
@@ -686,7 +652,7 @@ int sweep_depth_for(const bdg_system* sys, int lanes) {
     int depth = lanes >= 2 ? 3 : 2;
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_STEPS")) {
         const int forced = atoi(env);
-        if (forced == 2 || ((forced == 3 || forced == 4) && lanes >= 2)) depth = forced;
+        if (forced == 2 || (forced == 3 && lanes >= 2)) depth = forced;
     }
     return depth;
 }

@@ -149,7 +149,7 @@ struct Batch {
         // n_steps (up to 1024), so a short warm-up call leaves nothing to allocate later.
         per_step = (size_t)(overlapped ? grid_interior + grid_boundary : launch_grid) * width;
         constexpr int kChunk = 64;
-        chunk = std::min(n_steps, sweep && splan.depth == 3 ? 63 : kChunk);  // a sweep must not straddle two chunks (64 = 16 x 4)
+        chunk = std::min(n_steps, sweep && splan.depth == 3 ? 63 : kChunk);  // a sweep must not straddle two chunks
         if (int rc = sys->partial.reserve((size_t)kChunk * per_step)) return rc;
         const size_t dots_count = (size_t)std::max(n_steps, 1024) * width;
         if (int rc = sys->dots.reserve(dots_count)) return rc;
@@ -485,18 +485,10 @@ struct Batch {
         a.partial1 = sys->partial.ptr + (size_t)in_chunk * per_step;
         a.partial2 = a.partial1 + per_step;
         a.partial3 = a.partial2 + per_step;
-        if (splan.generic) {
-            bdg::SweepNArgs na;
-            na.base = a;
-            for (int j = 0; j < 4; ++j) na.partial[j] = a.partial1 + (size_t)j * per_step;
-            const SweepNKernel kernel = alternate && (n_launches & 1) ? splan.kernel_n_reverse : splan.kernel_n;
-            kernel<<<splan.grid, bdg::kSweepThreads, splan.lds_bytes, st>>>(na);
-        } else {
-            const SweepKernel kernel = n == 0 && gen_start ? splan.kernel_gen
-                                       : alternate && (n_launches & 1) ? splan.kernel_reverse : splan.kernel;
-            if (n == 0 && gen_start) a.cur = nullptr;  // (never read)
-            kernel<<<splan.grid, bdg::kSweepThreads, splan.lds_bytes, st>>>(a);
-        }
+        const SweepKernel kernel = n == 0 && gen_start ? splan.kernel_gen
+                                   : alternate && (n_launches & 1) ? splan.kernel_reverse : splan.kernel;
+        if (n == 0 && gen_start) a.cur = nullptr;  // (never read)
+        kernel<<<splan.grid, bdg::kSweepThreads, splan.lds_bytes, st>>>(a);
         ++n_launches;
         double2* old_cur = cur;
         double2* old_prev = prev;

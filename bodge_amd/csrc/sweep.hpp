@@ -743,228 +743,6 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
 }
 
 // =====================================================================================
-// K7c  cheb_sweepn<Mode, RL, REV, DEPTH> - DEPTH recurrence steps per sweep, written once for any depth.
-//
-// The same march as cheb_sweep3 with the levels in arrays: level 0 = t_n, level j = t_{n+j}; row[j] (LDS) holds
-// the current plane of level j (plane k-j in iteration k), before[j] the plane behind it (registers), and
-// made[j] the plane of level j+1 the iteration has just produced - which is at once the plane ahead that
-// step j+2 needs.  A sweep of DEPTH steps still reads t_n, t_{n-1} once and writes the last two levels
-// once: four array passes per DEPTH steps, so DEPTH = 4 moves 3/4 of the bytes per step of cheb_sweep3
-// (and 1/3 of the one-step kernels'), for a halo slot more on either side of the window (step j is valid
-// on slots j .. SLOTS-1-j, DEPTH .. SLOTS-1-DEPTH are owned), one more recomputed plane at either end of
-// a segment, one more LDS row per wave and one more plane of registers.  DEPTH = 3 is cheb_sweep3 again
-// (kept for A/B runs of the generic form against the hand-unrolled one).
-struct SweepNArgs {
-    SweepArgs base;     // stencil, table, buffers, geometry as for cheb_sweep3 (base.steps = steps of this launch)
-    double* partial[4]; // dots of step j+1: <t_{n+j}|t_{n+j}>, <t_{n+j+1}|t_{n+j}>
-};
-
-template <typename Mode, int RL, bool REV, int DEPTH>
-__global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweepn(SweepNArgs args) {
-    static_assert(DEPTH >= 2 && DEPTH <= 4, "levels per sweep");
-    const SweepArgs& a = args.base;
-    extern __shared__ double2 lds[];
-    constexpr int SLOTS = kWave / RL;
-    constexpr int OWNED = SLOTS - 2 * DEPTH;
-    static_assert(OWNED >= 2, "window too narrow for this depth");
-    constexpr int SPB = Mode::kSlotsPerBlock;
-    constexpr int STRIDE = Mode::kBlockStride;
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const int s = lane / RL;
-    const int r = lane % RL;
-
-    const double2* table = static_cast<const double2*>(a.dict_table);
-    for (int e = threadIdx.x; e < a.n_unique * SPB; e += kBlockThreads)
-        lds[(e / SPB) * STRIDE + (e % SPB)] = table[e];
-    double2* row[DEPTH];
-#pragma unroll
-    for (int j = 0; j < DEPTH; ++j) row[j] = lds + a.n_unique * STRIDE + (wave * DEPTH + j) * (kWave * 4);
-    __syncthreads();
-
-    const int n_units = a.n_cols * a.n_segs;
-    const int xcd = blockIdx.x & 7;
-    const int u_lo = (int)(((int64_t)n_units * xcd) >> 3);
-    const int u_hi = (int)(((int64_t)n_units * (xcd + 1)) >> 3);
-    const int waves_per_xcd = (gridDim.x >> 3) * kWavesPerBlock;
-
-    double dot[DEPTH][4];
-#pragma unroll
-    for (int j = 0; j < DEPTH; ++j)
-#pragma unroll
-        for (int c = 0; c < 4; ++c) dot[j][c] = 0.0;
-    const double2 zero = make_double2(0.0, 0.0);
-    const size_t nb = (size_t)a.nb;
-    const int steps = a.steps;  // uniform, 1..DEPTH
-    const bool nt_prev = a.stream & 1, nt_store = a.stream & 2, nt_cur = a.stream & 4;
-
-    for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
-        const int seg = u / a.n_cols, col = u - seg * a.n_cols;
-        const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
-        const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
-        const int p = col * OWNED - DEPTH + s;
-        const bool inside = p >= 0 && p < a.plane;
-        const bool valid = inside || a.wrap_p;
-        const int pw = inside ? p : ((p % a.plane) + a.plane) % a.plane;
-        const bool owned = inside && s >= DEPTH && s <= SLOTS - 1 - DEPTH;
-        auto ok = [&](int j) { return valid && s >= j && s <= SLOTS - 1 - j; };  // step j (1-based) is valid on this slot
-
-        const bool rev = REV != (bool)(a.zigzag & seg & 1);  // wave-uniform
-        auto act = [&](int k) { return rev ? x0 + x1 - 1 - k : k; };
-        auto ring = [&](int k) { return a.wrap_x ? (k < 0 ? k + a.lx : (k >= a.lx ? k - a.lx : k)) : k; };
-        auto in_lattice = [&](int k) { return a.wrap_x || (act(k) >= 0 && act(k) < a.lx); };
-        auto load_plane = [&](const double2* buf, bool nt, int k, bool wanted, double2 out[4]) {
-            k = ring(act(k));
-            if (wanted && k >= 0 && k < a.lx) {
-                const size_t site = (size_t)k * a.plane + pw;
-#pragma unroll
-                for (int al = 0; al < 4; ++al)
-                    out[al] = nt ? load_stream(buf + vslot(al, site, r, nb, RL)) : buf[vslot(al, site, r, nb, RL)];
-            } else {
-#pragma unroll
-                for (int al = 0; al < 4; ++al) out[al] = zero;
-            }
-        };
-        auto store_plane = [&](double2* buf, int k, const double2 v[4]) {
-            const size_t site = (size_t)act(k) * a.plane + p;
-#pragma unroll
-            for (int al = 0; al < 4; ++al) {
-                if (nt_store) store_stream(buf + vslot(al, site, r, nb, RL), v[al]);
-                else buf[vslot(al, site, r, nb, RL)] = v[al];
-            }
-        };
-        auto load_ids = [&](int k) {
-            uint2 w = make_uint2(0xFFFFFFFFu, 0xFFu);
-            k = ring(act(k));
-            if (ok(1) && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + pw];
-            return w;
-        };
-        auto id_of = [](uint2 w, int slot) { return slot < 4 ? (w.x >> (8 * slot)) & 0xFFu : w.y & 0xFFu; };
-        auto mac = [&](uint2 w, int slot, const double2 x[4], double2 acc[4]) {
-            const unsigned id = id_of(w, slot);
-            if (id == kNoBlock) return;
-            if ((w.y >> (8 + slot)) & 1u) Mode::mac_diag(acc, lds + id * STRIDE, x);
-            else Mode::mac_row(acc, lds + id * STRIDE, x);
-        };
-        auto own_of = [&](const double2* rw, double2 out[4]) {
-#pragma unroll
-            for (int be = 0; be < 4; ++be) out[be] = rw[SHARE_SLOT(lane, be)];
-        };
-        auto put_own = [&](double2* rw, const double2 v[4]) {
-#pragma unroll
-            for (int be = 0; be < 4; ++be) rw[SHARE_SLOT(lane, be)] = v[be];
-        };
-        auto wave_sync = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        };
-        auto apply = [&](uint2 w, const double2 behind[4], const double2* rw, const double2 mid[4],
-                         const double2 ahead[4], double2 acc[4]) {
-            double2 x[4];
-            if (rev) mac(w, 0, ahead, acc);
-            else mac(w, 0, behind, acc);
-            if (id_of(w, 1) != kNoBlock) {
-#pragma unroll
-                for (int be = 0; be < 4; ++be) x[be] = rw[SHARE_SLOT(lane - RL, be)];
-                mac(w, 1, x, acc);
-            }
-            mac(w, 2, mid, acc);
-            if (id_of(w, 3) != kNoBlock) {
-#pragma unroll
-                for (int be = 0; be < 4; ++be) x[be] = rw[SHARE_SLOT(lane + RL, be)];
-                mac(w, 3, x, acc);
-            }
-            if (rev) mac(w, 4, behind, acc);
-            else mac(w, 4, ahead, acc);
-        };
-
-        // step j (1-based) runs on plane k-j+1 and is needed on planes [x0-(steps-j), x1+(steps-j))
-        const int k_first = x0 - (steps - 1), k_last = x1 + steps - 2;
-
-        double2 before[DEPTH][4];  // before[j]: level j, the plane behind the current one (k-j-1)
-        double2 buf_a[4], buf_b[4], pv[4];
-        load_plane(a.cur, nt_cur, k_first - 1, valid, before[0]);
-        load_plane(a.cur, nt_cur, k_first, valid, buf_a);
-        load_plane(a.cur, nt_cur, k_first + 1, valid, buf_b);
-        load_plane(a.prev, nt_prev, k_first, ok(1) && a.prev != nullptr, pv);
-        uint2 ids[DEPTH];
-        ids[0] = load_ids(k_first);
-#pragma unroll
-        for (int j = 1; j < DEPTH; ++j) {
-            ids[j] = make_uint2(0xFFFFFFFFu, 0xFFu);
-#pragma unroll
-            for (int al = 0; al < 4; ++al) before[j][al] = zero;
-            put_own(row[j], before[j]);  // (the rows still hold the previous unit's planes)
-        }
-
-        auto iterate = [&](int k, double2 (&centre)[4], const double2 (&after)[4]) {
-            const bool more = k < k_last;
-            const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFu);
-            put_own(row[0], centre);
-            wave_sync();
-            load_plane(a.cur, nt_cur, k + 2, valid && more, centre);
-
-            double2 made[DEPTH][4];  // made[j]: level j+1 on plane k-j
-#pragma unroll
-            for (int j = 0; j < DEPTH; ++j) {
-#pragma unroll
-                for (int al = 0; al < 4; ++al) made[j][al] = zero;
-                const int q = k - j;  // plane step j+1 works on
-                const bool last_level = j + 1 == DEPTH;
-                const bool here = steps >= j + 1 && (last_level ? owned : ok(j + 1)) && in_lattice(q) &&
-                                  q >= x0 - (steps - j - 1) && q < x1 + (steps - j - 1);
-                if (here) {
-                    double2 acc[4], mid[4];
-#pragma unroll
-                    for (int al = 0; al < 4; ++al) acc[al] = zero;
-                    own_of(row[j], mid);
-                    if (j == 0) apply(ids[0], before[0], row[0], mid, after, acc);
-                    else apply(ids[j], before[j], row[j], mid, made[j - 1], acc);
-                    const double coef = j == 0 ? a.coef1 : a.coef2;
-#pragma unroll
-                    for (int al = 0; al < 4; ++al) {
-                        const double2 sub = j == 0 ? pv[al] : before[j - 1][al];  // level j-1 on plane q
-                        made[j][al].x = fma(coef, acc[al].x, -sub.x);
-                        made[j][al].y = fma(coef, acc[al].y, -sub.y);
-                    }
-                    if (owned && q >= x0 && q < x1) {
-#pragma unroll
-                        for (int al = 0; al < 4; ++al) Mode::dots(dot[j], mid[al], made[j][al]);
-                        if (steps == j + 1) store_plane(a.out2, q, made[j]);
-                        if (steps == j + 2) store_plane(a.out1, q, made[j]);
-                    }
-                }
-                if (j == 0) load_plane(a.prev, nt_prev, k + 1, ok(1) && more && a.prev != nullptr, pv);
-            }
-
-            // ---- roll: every level moves one plane on
-            wave_sync();
-#pragma unroll
-            for (int j = 0; j < DEPTH; ++j) own_of(row[j], before[j]);
-            wave_sync();
-#pragma unroll
-            for (int j = 1; j < DEPTH; ++j) put_own(row[j], made[j - 1]);
-#pragma unroll
-            for (int j = DEPTH - 1; j >= 1; --j) ids[j] = ids[j - 1];
-            ids[0] = nx_ids;
-        };
-        for (int k = k_first; k <= k_last; k += 2) {
-            iterate(k, buf_a, buf_b);
-            if (k + 1 <= k_last) iterate(k + 1, buf_b, buf_a);
-        }
-    }
-
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < DEPTH; ++j)
-        if (steps >= j + 1) {
-            if (j > 0) __syncthreads();
-            sweep_reduce_dots<Mode, RL, kWavesPerBlock>(dot[j], reinterpret_cast<double*>(lds), args.partial[j], lane, wave);
-        }
-}
-
-// =====================================================================================
 // K8  cheb_roll3 - one recurrence step on a 3-D lattice stencil with the x-neighbours in registers.
 //
 // The one-step kernels gather all six neighbours of a site from L2.  On a 100^3 lattice the two

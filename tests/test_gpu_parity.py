@@ -294,10 +294,6 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
                                       (5, 5, {"BODGE_AMD_SWEEP_LANES": "2", "BODGE_AMD_SWEEP_STEPS": "2"}),  # 28-position windows
                                       (6, 7, {"BODGE_AMD_SWEEP_LANES": "4"}),  # (K8: 14-position windows, 8 real vectors per launch)
                                       (8, per_group, {"BODGE_AMD_SWEEP_GEN": "0"}),  # start block written by the fill kernel and read back
-                                      (9, per_group, {"BODGE_AMD_SWEEP_STEPS": "4"}),  # cheb_sweepn: four steps per sweep (8 owned of 16 slots)
-                                      (7, 3, {"BODGE_AMD_SWEEP_STEPS": "4", "BODGE_AMD_SWEEP_LANES": "2"}),  # 24 owned of 32 slots
-                                      (6, 5, {"BODGE_AMD_SWEEP_STEPS": "4", "BODGE_AMD_SWEEP_ZIGZAG": "0", "BODGE_AMD_SWEEP_SEGMENTS": "2"}),
-                                      (3, 2, {"BODGE_AMD_SWEEP_STEPS": "4"}),  # a run shorter than one four-step sweep
                                       (1, 3, {}), (2, per_group, {}),  # runs shorter than one sweep
                                       (4, 3, {"BODGE_AMD_NO_DIAGONAL_BLOCKS": "1"})]:  # (read at upload: no effect here, see below)
             ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 5, range(vectors), vec_kind))
