@@ -33,10 +33,13 @@ def _run(seed, n_cases, size, lanczos) -> int:
                 shape = (shape[0], 1, shape[1])
         lat = ba.CubicLattice(shape)
         s = ba.Hamiltonian(lat)
-        model = rng.choice(["uniform", "disorder", "complex", "periodic"])
+        model = rng.choice(["uniform", "disorder", "texture", "complex", "periodic"])
         with s as (H, D):
-            if model == "disorder":
+            if model == "disorder":  # > 256 distinct real diagonal blocks: the sweep that streams the on-site blocks
                 H.set_sites(rng.normal(size=(lat.size, 1, 1)) * ba.σ0 + 0.1 * rng.normal(size=(lat.size, 1, 1)) * ba.σ3)
+            elif model == "texture":  # the same with complex diagonal blocks (σ2 component)
+                th, ph = rng.uniform(0, np.pi, (lat.size, 1, 1)), rng.uniform(0, 2 * np.pi, (lat.size, 1, 1))
+                H.set_sites(3.0 * ba.σ0 - 0.3 * (np.sin(th) * np.cos(ph) * ba.σ1 + np.sin(th) * np.sin(ph) * ba.σ2 + np.cos(th) * ba.σ3))
             else:
                 H.set_sites(3.0 * ba.σ0 - 0.05 * ba.σ3)
             D.set_sites(-0.1 * ba.jσ2)
@@ -45,8 +48,9 @@ def _run(seed, n_cases, size, lanczos) -> int:
                 pairs = lat.bond_array(axis=0, coords=True)
                 phase = np.where(pairs[:, 1, 0] > pairs[:, 0, 0], np.exp(0.3j), np.exp(-0.3j))
                 H.set_bonds(-phase[:, None, None] * ba.σ0, axis=0)
-            if model == "periodic" and not three_d:
-                H.set_edges(-0.7 * ba.σ0)
+            if (model == "periodic" or (model in ("disorder", "texture") and rng.random() < 0.3)) and not three_d:
+                H.set_edges(-0.7 * ba.σ0, axis=0)
+                H.set_edges(-0.7 * ba.σ0, axis=1 if shape[1] > 1 else 2)
         indptr, indices, data = s.bsr_arrays()
         scale = chebyshev.spectral_bound(indptr, data)
         steps = int(rng.integers(1, 14))
@@ -68,7 +72,7 @@ def _run(seed, n_cases, size, lanczos) -> int:
                 perf = dev.perf()
         n = 4 * lat.size
         err = max(np.abs(got[0] - one[0]).max(), np.abs(got[1] - one[1]).max()) / n
-        tag = f"case {case}: {shape} {model} steps={steps} vectors={vectors} kind={kind} {env} -> steps/launch {perf['steps_per_launch']} rolling {perf['rolling']}"
+        tag = f"case {case}: {shape} {model} steps={steps} vectors={vectors} kind={kind} {env} -> steps/launch {perf['steps_per_launch']} rolling {perf['rolling']} onsite-streamed {perf['onsite_streamed']}"
         if not err <= 1e-12:
             failures += 1
             print("FAIL", tag, "err", err, flush=True)
