@@ -83,6 +83,8 @@ SIGNATURES = {
     "bdg_lanczos_begin": (C.c_int, [_handle, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, C.c_int32]),
     "bdg_lanczos_advance": (C.c_int, [_handle, C.c_int32, _f64p, _f64p]),
     "bdg_lanczos_ritz_vectors": (C.c_int, [_handle, C.c_int32, C.c_int32, _f64p, _f64p]),
+    "bdg_lanczos_ritz_pairs": (C.c_int, [_handle, C.c_int32, C.c_int32, _f64p, _f64p, C.c_double, C.c_int32,
+                                        C.POINTER(C.c_int32), _f64p, _f64p]),
     "bdg_random_vector": (C.c_int, [_handle, C.c_uint64, C.c_uint64, C.c_int32, _f64p]),
     "bdg_eigh_dense": (C.c_int, [_handle, _f64p, _f64p]),
     "bdg_hermiticity_defect": (C.c_int, [_handle, _f64p]),

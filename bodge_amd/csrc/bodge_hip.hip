@@ -911,6 +911,13 @@ int bdg_lanczos_ritz_vectors(bdg_system* sys, int32_t n_iter, int32_t n_levels, 
     return lanczos_ritz_vectors(sys, n_iter, n_levels, coef, y_out);
 }
 
+int bdg_lanczos_ritz_pairs(bdg_system* sys, int32_t n_iter, int32_t n_levels, const double* coef, const double* eps,
+                           double rank_tol, int32_t max_out, int32_t* n_out, double* values_out, double* vectors_out) {
+    if (!sys || !coef || !eps) return fail(BDG_EINVAL, "null argument");
+    if (!(rank_tol >= 0.0 && rank_tol < 1.0)) return fail(BDG_EINVAL, "rank_tol must lie in [0, 1)");
+    return lanczos_ritz_pairs(sys, n_iter, n_levels, coef, eps, rank_tol, max_out, n_out, values_out, vectors_out);
+}
+
 int bdg_perf_query(bdg_system* sys, bdg_perf* out) {
     if (!sys || !out) return fail(BDG_EINVAL, "null argument");
     *out = sys->perf;

@@ -1112,6 +1112,88 @@ __global__ void sitemajor_from_planar_real(const double2* __restrict__ planar, d
     }
 }
 
+// ---- small dense algebra on blocks of vectors (Rayleigh-Ritz of the partial spectrum on the device)
+// A block is a planar buffer of `pairs` (component, site) rows x rl payloads: `cols` = rl x PER_LANE columns
+// (PER_LANE = 1: one complex column per payload; 2: two real columns per payload, in .x and .y).
+constexpr int kBlockAlgebraMaxCols = 16;
+
+// Gram matrix G[i][j] = sum over rows of conj(A[., i]) * B[., j].  blockIdx.y = i; every thread keeps
+// row i of G for its rows, then wave shuffles + LDS give one partial per workgroup:
+// partial[i][blockIdx.x][j] (complex, interleaved), summed afterwards by reduce_partials (one "step" per row i).
+template <int PER_LANE>
+__global__ __launch_bounds__(256) void block_gram(const double2* __restrict__ a, const double2* __restrict__ b,
+                                                  int64_t pairs, int rl, double* __restrict__ partial) {
+    __shared__ double red[4][2 * kBlockAlgebraMaxCols];
+    const int cols = rl * PER_LANE, i = blockIdx.y;
+    double2 acc[kBlockAlgebraMaxCols];
+#pragma unroll
+    for (int j = 0; j < kBlockAlgebraMaxCols; ++j) acc[j] = make_double2(0.0, 0.0);
+    for (int64_t pair = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; pair < pairs; pair += (int64_t)gridDim.x * blockDim.x) {
+        const double2 ai = a[pair * rl + i / PER_LANE];
+#pragma unroll
+        for (int j = 0; j < kBlockAlgebraMaxCols; ++j)
+            if (j < cols) {
+                const double2 bj = b[pair * rl + j / PER_LANE];
+                if (PER_LANE == 1) {  // conj(ai) * bj
+                    acc[j].x = fma(ai.x, bj.x, fma(ai.y, bj.y, acc[j].x));
+                    acc[j].y = fma(ai.x, bj.y, fma(-ai.y, bj.x, acc[j].y));
+                } else {
+                    acc[j].x = fma((i & 1) ? ai.y : ai.x, (j & 1) ? bj.y : bj.x, acc[j].x);
+                }
+            }
+    }
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+    for (int j = 0; j < kBlockAlgebraMaxCols; ++j)
+        if (j < cols) {
+#pragma unroll
+            for (int off = kWave / 2; off >= 1; off >>= 1) {
+                acc[j].x += __shfl_xor(acc[j].x, off);
+                acc[j].y += __shfl_xor(acc[j].y, off);
+            }
+            if (lane == 0) {
+                red[wave][2 * j] = acc[j].x;
+                red[wave][2 * j + 1] = acc[j].y;
+            }
+        }
+    __syncthreads();
+    if ((int)threadIdx.x < 2 * cols)
+        partial[((size_t)i * gridDim.x + blockIdx.x) * 2 * cols + threadIdx.x] =
+            red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+}
+
+// out[., m] = sum_i A[., i] * M[i][m]  (M: cols x cols complex, row-major, interleaved; the real form uses the
+// real parts).  One thread per row: it reads all of the row before it writes, so out may be A itself.
+template <int PER_LANE>
+__global__ __launch_bounds__(256) void block_mix(const double2* a, const double* __restrict__ m, int64_t pairs,
+                                                 int rl, double2* out) {
+    const int cols = rl * PER_LANE;
+    for (int64_t pair = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; pair < pairs; pair += (int64_t)gridDim.x * blockDim.x) {
+        double2 row[kBlockAlgebraMaxCols / PER_LANE];
+#pragma unroll
+        for (int r = 0; r < kBlockAlgebraMaxCols / PER_LANE; ++r)
+            if (r < rl) row[r] = a[pair * rl + r];
+#pragma unroll
+        for (int r = 0; r < kBlockAlgebraMaxCols / PER_LANE; ++r) {
+            if (r >= rl) continue;
+            double2 v = make_double2(0.0, 0.0);
+#pragma unroll
+            for (int q = 0; q < kBlockAlgebraMaxCols / PER_LANE; ++q) {
+                if (q >= rl) continue;
+                if (PER_LANE == 1) {
+                    const double mr = m[2 * ((size_t)q * cols + r)], mi = m[2 * ((size_t)q * cols + r) + 1];
+                    v.x = fma(row[q].x, mr, fma(-row[q].y, mi, v.x));
+                    v.y = fma(row[q].x, mi, fma(row[q].y, mr, v.y));
+                } else {  // columns 2q, 2q+1 in, 2r, 2r+1 out
+                    v.x = fma(row[q].x, m[2 * ((size_t)(2 * q) * cols + 2 * r)], fma(row[q].y, m[2 * ((size_t)(2 * q + 1) * cols + 2 * r)], v.x));
+                    v.y = fma(row[q].x, m[2 * ((size_t)(2 * q) * cols + 2 * r + 1)], fma(row[q].y, m[2 * ((size_t)(2 * q + 1) * cols + 2 * r + 1)], v.y));
+                }
+            }
+            out[pair * rl + r] = v;
+        }
+    }
+}
+
 // per-column |v|^2 over the owned rows (start of the process): partial[block][column]
 template <int PER_LANE>
 __global__ __launch_bounds__(256) void column_norms(const double2* __restrict__ v, int64_t nb, int64_t ncols,

@@ -825,6 +825,8 @@ __global__ void build_stencil3(const int* __restrict__ indptr, const int* __rest
 // vectors, 30 owned positions: half the ghost slots, and half the bytes an XCD touches per plane).
 constexpr int roll_owned(int rl) { return kWave / rl - 2; }
 
+// (three waves per SIMD - 168 VGPRs - would fill the 2048 x 1.5 wave slots of a 100^3 launch better, but the
+// seven planes of rolling state and a plane of prefetch then spill 250-360 B per lane: round 3, not kept)
 template <typename Mode, int RL = kSweepLanes>
 __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
     extern __shared__ double2 lds[];

@@ -520,7 +520,8 @@ def lowest_eigenvalues(system, k: int = 1, *, tol: float = 1e-6, vectors: int = 
 
 
 def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8, seed: int = 0,
-                      max_iter: int = 20000, check_every: int = 50, format: str = "reshape", method: str = "auto"):
+                      max_iter: int = 20000, check_every: int = 50, format: str = "reshape", method: str = "auto",
+                      rayleigh_ritz: str = "device"):
     """The k lowest positive eigenvalues of H **with their multiplicities** and orthonormal
     eigenvectors, for systems where the dense `diagonalize()` is out of reach: what
     `E, v = system.diagonalize()` followed by `E[:k], v[:k]` gives the reference's callers
@@ -540,7 +541,10 @@ def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8
     Rayleigh-Ritz step with H inside that span the final pairs.  Residuals ‖Hv − εv‖ come out at
     about `tol`; eigenvalues, being Rayleigh quotients, at about tol².
     method="auto" answers matrices up to 4N = 2048 from `diagonalize()` itself; method="lanczos"
-    always runs the two passes.
+    always runs the two passes.  rayleigh_ritz="device" (default, up to 16 start vectors) keeps the
+    block of Ritz vectors on the GPU and does the Gram / projection steps there
+    (`bdg_lanczos_ritz_pairs`: only r x r matrices and the k results cross PCIe); "host" is the
+    numpy form of the same steps on (levels, vectors, 4N) arrays, kept for comparison.
     """
     import warnings
 
@@ -552,6 +556,8 @@ def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8
         raise RuntimeError(f"Eigenstate format '{format}' is not yet supported.")
     if method not in ("auto", "lanczos"):
         raise ValueError("method must be 'auto' or 'lanczos'")
+    if rayleigh_ritz not in ("device", "host"):
+        raise ValueError("rayleigh_ritz must be 'device' or 'host'")
     if method == "auto" and system.shape[0] <= DENSE_AUTO_LIMIT:
         # small matrices: the dense solve is exact and cheaper than a Krylov process that would
         # exhaust its space (found by scratch/fuzz_api.py on a 72x72 matrix)
@@ -628,6 +634,14 @@ def lowest_eigenpairs(system, k: int = 1, *, tol: float = 1e-8, vectors: int = 8
             if entry is not None:
                 coef[: entry[0], l, c] = entry[1]
     solver.lanczos_begin(vectors, seed=seed, max_iter=max_iter)
+    if rayleigh_ritz == "device" and vectors <= 16:
+        # second pass and Rayleigh-Ritz inside the library: the (levels, vectors, 4N) block of Ritz vectors stays on
+        # the GPU, H acts there, r x r matrices go to the host and only the k states asked for come back
+        eps = np.sqrt(np.maximum(np.asarray(targets[:levels], dtype=float), 0.0))
+        vals, vecs, _ = solver.lanczos_ritz_pairs(coef, eps, k)
+        if format == "raw":
+            return vals, np.ascontiguousarray(vecs.T)
+        return vals, vecs.reshape(len(vals), dim // 4, 4)
     ritz = solver.lanczos_ritz_vectors(coef)  # (levels, vectors, 4N)
 
     values, states = [], []

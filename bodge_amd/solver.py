@@ -237,6 +237,25 @@ class DeviceSolver:
                                                         backend.as_f64p(out.view(np.float64))))
         return out
 
+    def lanczos_ritz_pairs(self, coef: np.ndarray, eps: np.ndarray, k: int, rank_tol: float = 1e-4):
+        """Second pass + Rayleigh-Ritz on the device: the k lowest states found in the levels whose Ritz
+        coordinates `coef[j, l, r]` and eigenvalue estimates `eps[l]` are given.  Returns
+        (values (k',), vectors (k', 4N), n_found) with k' = min(k, n_found); only these cross PCIe."""
+        n_vectors = getattr(self, "_lanczos_vectors", 0)
+        coef = np.ascontiguousarray(coef, dtype=np.float64)
+        eps = np.ascontiguousarray(eps, dtype=np.float64)
+        if not n_vectors or coef.ndim != 3 or coef.shape[2] != n_vectors or eps.shape != (coef.shape[1],):
+            raise ValueError("bodge_hip: coefficients must be (iterations, levels, start vectors of lanczos_begin), eps (levels,)")
+        values = np.empty(k)
+        vectors = np.empty((k, self.dim), dtype=np.complex128)
+        found = C.c_int32(0)
+        backend.check(self._lib.bdg_lanczos_ritz_pairs(
+            self._handle, coef.shape[0], coef.shape[1], backend.as_f64p(coef), backend.as_f64p(eps), float(rank_tol), k,
+            C.byref(found), backend.as_f64p(values), backend.as_f64p(vectors.view(np.float64))))
+        self._lanczos_vectors = 0  # (the library ended the run)
+        kept = min(k, found.value)
+        return values[:kept], vectors[:kept], found.value
+
     def eigh(self, vectors: bool = True):
         """All eigenvalues ascending (and eigenvectors as columns): own Jacobi kernels up to 4N = 2048,
         rocSOLVER above (dsyevd when imag(H) = 0, else zheevd)."""

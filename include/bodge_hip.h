@@ -173,6 +173,21 @@ int bdg_lanczos_advance(bdg_system* sys, int32_t n_iter, double* alpha_out, doub
 int bdg_lanczos_ritz_vectors(bdg_system* sys, int32_t n_iter, int32_t n_levels, const double* coef,
                              double* y_out);
 
+/*
+ * Eigenpairs from the same second pass without the Ritz block leaving the device (Rayleigh-Ritz with H
+ * on the GPU; what a caller of diagonalize() wants from a lattice too large to diagonalise: reference
+ * tests/test_physics.py:105, `eigvals, eigvecs = system.diagonalize()`).  Arguments as for
+ * bdg_lanczos_ritz_vectors, plus eps[l] = the level's eigenvalue estimate (square root of the converged
+ * Ritz value of H^2).  Per level the candidates (H + eps_l) y span the +eps_l eigenspace; the rank of
+ * their Gram matrix (eigenvalues above rank_tol x the largest) is the multiplicity; H is diagonalised
+ * inside that span.  n_out receives the number of states found over all levels; the max_out lowest are
+ * returned: values_out[k] ascending, vectors_out + 8*nb*k = 4*nb complex entries (site-major) of state k.
+ * At most 16 columns (16 real-arithmetic or 16 complex start vectors).  Ends the Lanczos run.
+ */
+int bdg_lanczos_ritz_pairs(bdg_system* sys, int32_t n_iter, int32_t n_levels, const double* coef,
+                           const double* eps, double rank_tol, int32_t max_out, int32_t* n_out,
+                           double* values_out, double* vectors_out);
+
 /* Write the counter-based start vector (4*nb complex entries) to a host buffer. */
 int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t vec_kind,
                       double* v_out);

@@ -1135,21 +1135,24 @@ def test_default_call_warns_when_it_is_not_the_reference_computation(api, monkey
     assert abs(zero / system.free_energy(0.0, method="dense") - 1) < 1e-10
 
 
+@pytest.mark.parametrize("rayleigh_ritz", ["device", "host"])
 @pytest.mark.parametrize("name,k", [("swave20", 6), ("snf", 5), ("complex235", 4), ("swave20_zeeman", 3)])
-def test_lowest_eigenpairs_with_multiplicities_and_vectors(api, golden, name, k):
+def test_lowest_eigenpairs_with_multiplicities_and_vectors(api, golden, name, k, rayleigh_ritz):
     """f4 completed: the k lowest positive eigenvalues WITH multiplicities (swave20's lowest level is
     four-fold: spin x the k_x <-> k_y symmetry of the square) and orthonormal eigenvectors in the
     reference's layouts (ref hamiltonian.py:235-248), from two passes of the device Lanczos process.
     Eigenvalues against the reference's spectrum, residual |Hv - εv| <= 1e-8."""
     system = _build(api, name)
     ref = golden.eigenvalues(name)
-    vals, vecs = system.lowest_eigenpairs(k, format="raw", method="lanczos")
+    # rayleigh_ritz="device": Gram matrices, projections and H products of the second pass on the GPU
+    # (bdg_lanczos_ritz_pairs); "host": the numpy form on (levels, vectors, 4N) arrays
+    vals, vecs = system.lowest_eigenpairs(k, format="raw", method="lanczos", rayleigh_ritz=rayleigh_ritz)
     dense = np.asarray(system.matrix("dense"))
     assert vals.shape == (k,) and vecs.shape == (dense.shape[0], k)
     assert np.all(np.diff(vals) >= -1e-12) and np.abs(vals - ref[:k]).max() <= 1e-9
     assert np.abs(dense @ vecs - vecs * vals).max() <= 1e-8
     assert np.abs(vecs.conj().T @ vecs - np.eye(k)).max() <= 1e-8
-    vals2, shaped = system.lowest_eigenpairs(k, method="lanczos")
+    vals2, shaped = system.lowest_eigenpairs(k, method="lanczos", rayleigh_ritz=rayleigh_ritz)
     assert shaped.shape == (k, system.lattice.size, 4) and np.allclose(vals2, vals, rtol=0, atol=1e-12)
     for n in range(k):  # same layout rule as diagonalize(): v[n, site, α] = X[4 site + α, n]
         assert np.abs(dense @ shaped[n].reshape(-1) - vals2[n] * shaped[n].reshape(-1)).max() <= 1e-8
@@ -1160,6 +1163,33 @@ def test_lowest_eigenpairs_with_multiplicities_and_vectors(api, golden, name, k)
     assert np.abs(vals3 - ref[:k]).max() <= 1e-10 and shaped3.shape == shaped.shape
     for n in range(k):
         assert np.abs(dense @ shaped3[n].reshape(-1) - vals3[n] * shaped3[n].reshape(-1)).max() <= 1e-9
+
+
+def test_bound_states_of_a_large_lattice_without_host_copies_of_the_ritz_block(api, solver_cls):
+    """A 300 x 300 s-wave lattice (3.6e5 x 3.6e5, far beyond the dense solver) with two identical magnetic
+    impurities 100 sites apart: their in-gap (Yu-Shiba-Rusinov) states are degenerate to ~1e-9, i.e. ONE
+    level of multiplicity two for the Lanczos process.  `lowest_eigenpairs(2)` must return both states,
+    orthonormal, residual |Hv - εv| <= 1e-8, with the Rayleigh-Ritz step on the device - and the same
+    values from the host form of that step."""
+    lattice = api.CubicLattice((300, 300, 1))
+    system = api.Hamiltonian(lattice)
+    spots = [lattice[(100, 150, 0)], lattice[(200, 150, 0)]]
+    field = np.zeros(lattice.size)
+    field[spots] = 2.0
+    with system as (H, Δ):
+        H.set_sites(3.0 * api.σ0 - field[:, None, None] * api.σ3)
+        Δ.set_sites(-0.5 * api.jσ2)
+        H.set_bonds(-1.0 * api.σ0)
+    vals, vecs = system.lowest_eigenpairs(2, format="raw", tol=1e-8, max_iter=4000)
+    assert vals.shape == (2,) and vecs.shape == (4 * lattice.size, 2)
+    assert 0.0 < vals[0] < 0.45 and abs(vals[1] - vals[0]) < 1e-6  # both below the clean gap 0.5, degenerate
+    bsr = system.matrix("bsr")
+    assert np.abs(bsr @ vecs - vecs * vals).max() <= 1e-8
+    assert np.abs(vecs.conj().T @ vecs - np.eye(2)).max() <= 1e-8
+    weight = (np.abs(vecs.reshape(lattice.size, 4, 2)) ** 2).sum(axis=(1, 2))
+    assert weight[spots].min() > 100 * weight.mean()  # localised at the two impurities
+    host_vals, _ = system.lowest_eigenpairs(2, format="raw", tol=1e-8, max_iter=4000, rayleigh_ritz="host")
+    assert np.abs(host_vals - vals).max() <= 1e-10
 
 
 def test_lowest_eigenpairs_when_a_ritz_vector_has_no_positive_energy_part(api):
