@@ -20,7 +20,7 @@ LIBRARY = os.path.join(CSRC, "libbodge_hip.so")
 SOURCES = [os.path.join(CSRC, "bodge_hip.hip")]
 HEADERS = [os.path.join(CSRC, name) for name in (
     "kernels.hpp", "sweep.hpp", "host_assembly.hpp", "core.hpp", "plans.hpp", "libraries.hpp", "recurrence.hpp",
-    "lanczos.hpp", "dense.hpp", "knobs.hpp")] + [os.path.join(INCLUDE, "bodge_hip.h")]
+    "lanczos.hpp", "dense.hpp", "tridiag.hpp", "knobs.hpp")] + [os.path.join(INCLUDE, "bodge_hip.h")]
 ARCH = "gfx950"
 
 

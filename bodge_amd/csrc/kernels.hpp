@@ -1450,9 +1450,9 @@ __global__ __launch_bounds__(256) void jacobi_eigenvalues(const T* __restrict__ 
 // (i, j) against the conjugate transpose of block (j, i), found by binary search in the sorted
 // row j; a block without a stored partner counts with its own magnitude.  Sixteen lanes per block
 // row, one per block element: a block is one 256-byte run read by 16 adjacent lanes, its partner
-// the same 256 bytes read transposed (same cache lines), so the matrix crosses the fabric about
-// twice (2.1 x measured; the thread-per-row form of round 2 fetched it 7 x).  One partial maximum
-// per workgroup.
+// the same 256 bytes read transposed (same cache lines), so the matrix crosses the fabric less than
+// twice: 2.17 GB for the 1.28 GB matrix of 10^6 sites, 0.53 ms (profiles/r03_hermiticity.log; the
+// thread-per-row form of round 2: 8.7 GB, 2.39 ms).  One partial maximum per workgroup.
 __global__ __launch_bounds__(256) void hermiticity_defect(const int* __restrict__ indptr,
                                                           const int* __restrict__ indices,
                                                           const double2* __restrict__ blocks, int nb,

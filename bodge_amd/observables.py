@@ -28,6 +28,7 @@ from .backend import VEC_RADEMACHER, VEC_Z4
 
 DENSE_AUTO_LIMIT = 2048  # largest 4N served by the own Jacobi kernels (kJacobiLimit in the library)
 DENSE_AUTO_LIMIT_T0 = 16384  # largest 4N method="auto" ever sends to a dense eigensolver
+DENSE_VALUES_LIMIT_T0 = 8192  # T = 0: up to here the eigenvalues-only dense route (tridiagonalisation, ~1 s) is simply taken
 GAP_SURROGATE_RATIO = 5.0  # T = 0: the kink of -|ε|/4 is smoothed over gap / this (see free_energy)
 EXACT_TRACE_LIMIT = 65536  # largest 4N for which trace="auto" is exact (128x128 sites: ~2 s at T = 0.1)
 
@@ -99,13 +100,14 @@ def _gap_estimate(system) -> float:
 def _auto_method(system, temperature: float, moments, scale) -> str:
     """Dense or Chebyshev for `free_energy(method="auto")`, by estimated run time.
 
-    T = 0: dense within reach of the own Jacobi kernels; above, the Chebyshev expansion of the
-    smoothed density -(ε/4)·erf(5ε/gap) (see `free_energy`) when the spectrum is gapped enough, else the
-    dense library.  Matrices without the particle-hole form must go dense.  Otherwise the two
-    routes are priced with measured constants (profiles/r01_wall_table.log): the Jacobi kernels
-    cost ≈ 6e-11·(4N)³ s (0.25 s at 4N = 1600), rocSOLVER ≈ 2e-12·(4N)³ s plus its
-    load time; an exact-trace Chebyshev run costs M/2 launches per batch of 64 unit vectors, each
-    ≥ 7 µs or its HBM time.  Both routes meet the 1e-10 relative accuracy the tests ask for.
+    The dense route needs eigenvalues only: the library's own Householder tridiagonalisation +
+    bisection (csrc/tridiag.hpp; no rocSOLVER), 8 ms at 4N = 512, 0.12 s at 3600, 1.7 s at 10^4,
+    i.e. ≈ 2e-12·(4N)³ s above a floor of ≈ 16 µs per row (two launches), and the Jacobi kernels
+    below 4N = 512.  T = 0: dense up to 4N = 8192; above, the Chebyshev expansion of the smoothed
+    density -(ε/4)·erf(5ε/gap) (see `free_energy`) when the spectrum is gapped enough, else dense.
+    Matrices without the particle-hole form must go dense.  Otherwise the two routes are priced:
+    an exact-trace Chebyshev run costs M/2 launches per batch of 64 unit vectors, each ≥ 7 µs or its
+    HBM time.  Both routes meet the 1e-10 relative accuracy the tests ask for.
     """
     dim = system.shape[0]
     if dim > DENSE_AUTO_LIMIT_T0:
@@ -116,7 +118,7 @@ def _auto_method(system, temperature: float, moments, scale) -> str:
     if temperature == 0:
         # beyond the own Jacobi kernels: Chebyshev on the smoothed density if the spectrum is gapped enough
         # for that expansion to converge within the moment cap, the dense library otherwise
-        if dim <= DENSE_AUTO_LIMIT or moments is not None:
+        if dim <= DENSE_VALUES_LIMIT_T0 or moments is not None:
             return "dense"
         gap = _gap_estimate(system)
         gapped = gap > 0 and cheb.moments_for_gapped_ground_state(a, gap / GAP_SURROGATE_RATIO) <= cheb.MAX_MOMENTS
@@ -125,7 +127,7 @@ def _auto_method(system, temperature: float, moments, scale) -> str:
     batches = -(-(dim // 2) // 64) if dim <= EXACT_TRACE_LIMIT else 1  # electron rows only
     launch = max(7e-6, (dim // 4) * 64 * 192 / 5e12)
     chebyshev_seconds = 0.5 * m * batches * launch
-    dense_seconds = 6e-11 * dim**3 if dim <= DENSE_AUTO_LIMIT else 2.0 + 2e-12 * dim**3
+    dense_seconds = 6e-11 * dim**3 if dim <= 512 else max(1.6e-5 * dim, 2.6e-12 * dim**3)
     return "dense" if dense_seconds <= chebyshev_seconds else "chebyshev"
 
 
@@ -192,7 +194,13 @@ def free_energy(
 
     if method == "dense":
         eps, _ = system._solver(device=None if devices is None else devices[0]).eigh(vectors=False)
-        eps = eps[eps > 0]
+        if system.has_symmetric_spectrum(1e-12):
+            # ±-symmetric spectrum: the reference's "ε > 0" (ref :305) keeps one member of every pair, and of a
+            # pair of zero modes whichever round-off made positive - the upper half of the sorted spectrum is the
+            # same set without depending on the sign of 1e-17 (each zero mode then contributes T ln 2, as there)
+            eps = np.maximum(eps[len(eps) // 2:], 0.0)
+        else:
+            eps = eps[eps > 0]
         internal = -0.5 * np.sum(eps)
         entropy = 0.0 if temperature == 0 else np.sum(np.log1p(np.exp(-eps / temperature)))
         return float(internal - temperature * entropy)

@@ -198,10 +198,13 @@ int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t v
  * eigenvalues ascending in w_out; if z_out is non-null it receives the
  * eigenvectors in column-major (Fortran) order: eigenvector n occupies the
  * 4nb complex entries starting at z_out[2*n*4nb].
- * Drivers: own one-sided Jacobi kernels for 4*nb <= 2048 (and up to 4096 for as long as the
- * rocSOLVER object is still being read from cold storage, see bdg_dense_prefetch); above,
- * rocSOLVER dsyevd when imag(H) = 0 (real eigenvectors, widened to complex in z_out) and zheevd
- * otherwise; limit 4*nb <= 46000.  Results are scanned for non-finite values on the device.
+ * Drivers.  Eigenvalues only (z_out NULL, what free_energy needs): own Householder
+ * tridiagonalisation + bisection from 4*nb > 512 on (no library; real arithmetic when imag(H) = 0),
+ * own Jacobi kernels below.  With eigenvectors: own one-sided Jacobi kernels for 4*nb <= 2048 (and
+ * up to 4096 for as long as the rocSOLVER object is still being read from cold storage, see
+ * bdg_dense_prefetch); above, rocSOLVER dsyevd when imag(H) = 0 (real eigenvectors, widened to
+ * complex in z_out) and zheevd otherwise; limit 4*nb <= 46000.  Results are scanned for non-finite
+ * values on the device.
  */
 int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out);
 
