@@ -87,6 +87,7 @@ SIGNATURES = {
                                         C.POINTER(C.c_int32), _f64p, _f64p]),
     "bdg_random_vector": (C.c_int, [_handle, C.c_uint64, C.c_uint64, C.c_int32, _f64p]),
     "bdg_eigh_dense": (C.c_int, [_handle, _f64p, _f64p]),
+    "bdg_eigh_dense_above": (C.c_int, [_handle, C.c_double, C.c_int64, _f64p, C.POINTER(C.c_int64), _f64p]),
     "bdg_hermiticity_defect": (C.c_int, [_handle, _f64p]),
     "bdg_dense_prefetch": (C.c_int, []),
     "bdg_dense_prefetch_wait": (C.c_int, [C.c_double, C.POINTER(C.c_int32)]),

@@ -808,6 +808,30 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     return rc;
 }
 
+int bdg_eigh_dense_above(bdg_system* sys, double lower_bound, int64_t capacity, double* w_out, int64_t* n_vectors,
+                         double* z_out) {
+    if (!sys || !w_out || !n_vectors) return fail(BDG_EINVAL, "null argument");
+    if (capacity < 0 || (capacity > 0 && !z_out)) return fail(BDG_EINVAL, "bad eigenvector buffer");
+    if (sys->ncols != sys->nb) return fail(BDG_EINVAL, "bdg_eigh_dense_above needs a whole (square) matrix, not a slab");
+    const int64_t n = 4 * sys->nb;
+    const char* forced = knob::raw("BODGE_AMD_EIGH");
+    const bool own = forced ? std::string(forced) == "tridiagonal" : n > 512;
+    if (own) {
+        lanczos_free(sys);
+        HIP_TRY(hipSetDevice(sys->device));
+        return eig_tridiagonal_above(sys, w_out, lower_bound, capacity, n_vectors, z_out);
+    }
+    // the full solve of another driver, cut to the eigenvalues above the bound
+    std::vector<double> z_all((size_t)2 * n * n);
+    if (int rc = bdg_eigh_dense(sys, w_out, z_all.data())) return rc;
+    int64_t first = 0;
+    while (first < n && !(w_out[first] > lower_bound)) ++first;
+    *n_vectors = n - first;
+    if (n - first > capacity) return fail(BDG_EINVAL, "%lld eigenvalues above the bound, room for %lld eigenvectors", (long long)(n - first), (long long)capacity);
+    if (n - first > 0) memcpy(z_out, z_all.data() + (size_t)2 * n * first, sizeof(double) * 2 * n * (size_t)(n - first));
+    return BDG_OK;
+}
+
 int bdg_hermiticity_defect(bdg_system* sys, double* defect_out) {
     if (!sys || !defect_out) return fail(BDG_EINVAL, "null argument");
     if (sys->ncols != sys->nb) return fail(BDG_EINVAL, "bdg_hermiticity_defect needs a whole (square) matrix, not a slab");

@@ -38,9 +38,11 @@ void warm_page_cache(const char* path) {
     close(fd);
 }
 
+std::mutex g_disk_stream;  // the cold disk serves one stream best: whichever read was started first goes first
+
 struct FilePrefetch {
     std::vector<const char*> paths;
-    FilePrefetch* after = nullptr;  // read only once that one is done (the disk serves one stream best)
+    FilePrefetch* after = nullptr;  // (unused since round 3: reads queue on g_disk_stream in the order they were started)
     std::mutex lock;
     std::condition_variable changed;
     bool started = false, done = false, reported = false;
@@ -57,7 +59,7 @@ struct FilePrefetch {
         // detached: a process that ends before the read has finished must not wait for it
         // (the objects themselves are never destroyed, see below)
         std::thread([this] {
-            if (after && after->is_started()) (void)after->wait(-1.0);
+            std::lock_guard<std::mutex> one_stream(g_disk_stream);
             const auto t0 = std::chrono::steady_clock::now();
             for (const char* path : paths) warm_page_cache(path);
             std::lock_guard<std::mutex> inner(lock);
@@ -84,8 +86,8 @@ struct FilePrefetch {
     }
 };
 // deliberately immortal: they outlive every exit path.  One stream at a time - side by side the two
-// reads take as long as one after the other (the cold storage delivers ~2.5 MB/s in total) - and the
-// dense-solver objects first when both are wanted: a diagonalize() call is waiting for those.
+// reads take as long as one after the other (the cold storage delivers ~2.5 MB/s in total) - in the
+// order they were asked for.
 FilePrefetch& g_solver_prefetch =
     *new FilePrefetch({"/opt/rocm/lib/librocblas.so", "/opt/rocm/lib/librocsolver.so"}, nullptr);
 FilePrefetch& g_rccl_prefetch = *new FilePrefetch({"/opt/rocm/lib/librccl.so"}, &g_solver_prefetch);

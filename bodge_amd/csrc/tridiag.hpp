@@ -69,10 +69,13 @@ __device__ inline T td_block_sum(T value, T* scratch) {
 // One workgroup.  Step j: (i) finish w of step j-1 from q = B' v  (ii) row j of the lazily updated matrix:
 // d_j and x  (iii) the Householder vector of step j.  v_prev / w / q are indexed by absolute row (>= j),
 // v_new by absolute row (>= j+1).
+// The reflector is also kept for the back-transformation of eigenvectors: v_j(j+2:) in row j of the matrix
+// (dead from here on: later passes touch rows > j only), v_j(j+1) = 1 implied, tau_j in taus[j].
 template <typename T>
-__global__ __launch_bounds__(1024) void td_vector_step(const T* __restrict__ a, int n, int j, const T* __restrict__ v_prev,
+__global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n, int j, const T* __restrict__ v_prev,
                                                        T* __restrict__ w, const T* __restrict__ q, T* __restrict__ v_new,
-                                                       double* __restrict__ d, double* __restrict__ e, TdScalars<T>* scal) {
+                                                       double* __restrict__ d, double* __restrict__ e, TdScalars<T>* scal,
+                                                       T* __restrict__ taus) {
     __shared__ T scratch[16];
     __shared__ T shared_scalar;
     T zero;
@@ -113,8 +116,11 @@ __global__ __launch_bounds__(1024) void td_vector_step(const T* __restrict__ a, 
         if (threadIdx.x == 0) {
             e[j] = td_re(alpha);
             scal->tau = zero;
+            taus[j] = zero;
             td_set(v_new[j + 1], 1.0, 0.0);
         }
+        __syncthreads();  // (every thread has read row j by now)
+        for (int c = j + 2 + threadIdx.x; c < n; c += blockDim.x) a[(size_t)j * n + c] = zero;
         return;
     }
     const double ar = td_re(alpha), ai = td_im(alpha);
@@ -124,10 +130,17 @@ __global__ __launch_bounds__(1024) void td_vector_step(const T* __restrict__ a, 
     T scale;
     td_set(scale, sr / den, -si / den);
     __syncthreads();  // (v_new written above by the same threads that rescale it: same index set, no hazard; keep order explicit)
-    for (int c = j + 2 + threadIdx.x; c < n; c += blockDim.x) v_new[c] = td_mul(v_new[c], scale);
+    for (int c = j + 2 + threadIdx.x; c < n; c += blockDim.x) {
+        const T scaled = td_mul(v_new[c], scale);
+        v_new[c] = scaled;
+        a[(size_t)j * n + c] = scaled;  // (row j: every thread read its entries before the barrier above)
+    }
     if (threadIdx.x == 0) {
         e[j] = beta;
-        td_set(scal->tau, (beta - ar) / beta, -ai / beta);
+        T tau;
+        td_set(tau, (beta - ar) / beta, -ai / beta);
+        scal->tau = tau;
+        taus[j] = tau;
         td_set(v_new[j + 1], 1.0, 0.0);
     }
     (void)shared_scalar;
@@ -186,6 +199,283 @@ __global__ void td_bisect(const double* __restrict__ d, const double* __restrict
     out[k] = 0.5 * (a + b);
 }
 
+// ---- eigenvectors of the tridiagonal matrix by inverse iteration (the scheme of LAPACK's dstein).
+// One wave per cluster of close eigenvalues; its members are treated one after the other: LU of T - λ
+// with partial pivoting (lane 0; scratch in global memory), three solves from a pseudo-random start,
+// each followed by an orthogonalisation against the members already done and a normalisation (all
+// lanes).  Singletons - almost every eigenvalue - need no orthogonalisation: eigenvalues further apart
+// than the cluster tolerance give vectors orthogonal to ε|T| / gap.  Output z[i * ld + (k - first_index)].
+struct TdCluster {
+    int first, count;  // positions in the ascending eigenvalue array
+};
+
+__device__ inline double td_wave_sum(double v) {
+    for (int off = kWave / 2; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    return v;
+}
+
+// The recurrences (LU, forward and backward substitution) are sequential in the row index.  They run
+// REDUNDANTLY ON ALL 64 LANES with wave-uniform values: a tile of 64 rows is loaded with one coalesced
+// load per array, row i of the tile is fetched from lane i's register with v_readlane (no memory access
+// on the dependent chain - the first version, lane 0 walking global memory, spent 1.6 s of a 6 s solve
+// at n = 10^4 here), lane i keeps the outputs of step i, and the tile is stored with coalesced stores.
+__device__ inline double td_from_lane(double v, int src) {  // src wave-uniform
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src);
+    return __hiloint2double(hi, lo);
+}
+
+// One wave per eigenvalue (`shift[k]`: the eigenvalue, members of a cluster a few ulp |T| apart so that their
+// iterations decorrelate).  No orthogonalisation here: clusters are orthonormalised afterwards by
+// td_cluster_orthonormalise - the members of a degenerate level (50 of them on a 50 x 50 lattice) need not
+// wait for each other.
+__global__ __launch_bounds__(64) void td_inverse_iteration(const double* __restrict__ d, const double* __restrict__ e,
+                                                           int n, const double* __restrict__ shift, int n_vec,
+                                                           double norm_t, double* __restrict__ scratch,
+                                                           double* __restrict__ z, int ld) {
+    const int lane = threadIdx.x;
+    double* lu_a = scratch + (size_t)blockIdx.x * 6 * n;  // pivots
+    double* lu_b = lu_a + n;                              // first super-diagonal of U
+    double* lu_c = lu_b + n;                              // multipliers
+    double* lu_d = lu_c + n;                              // second super-diagonal of U
+    double* lu_in = lu_d + n;                             // 1.0 where rows k, k+1 were interchanged
+    double* x = lu_in + n;
+    const double eps = 2.220446049250313e-16;
+    const double tiny = eps * norm_t;
+    {
+        for (int k_eig = blockIdx.x; k_eig < n_vec; k_eig += gridDim.x) {
+            const double lambda = shift[k_eig];
+            // ---- LU factorisation of T - lambda with partial pivoting (LAPACK dlagtf): a = pivots, b / d = first and
+            // second super-diagonal of U, c = multipliers, in = 1 where rows k, k+1 were interchanged
+            {
+                double a_k = d[0] - lambda;           // pivot candidate of the current row
+                double b_k = n > 1 ? e[0] : 0.0;      // its super-diagonal entry (changed by an interchange above it)
+                double scale1 = fabs(a_k) + fabs(b_k);
+                for (int t = 0; t < n; t += kWave) {
+                    const int row = t + lane;
+                    const double sub_l = row < n - 1 ? e[row] : 0.0;                    // c(row): sub-diagonal below row
+                    const double a1_l = row + 1 < n ? d[row + 1] - lambda : 0.0;        // diagonal of row + 1
+                    const double b1_l = row + 1 < n - 1 ? e[row + 1] : 0.0;             // super-diagonal of row + 1
+                    double out_a = 0.0, out_b = 0.0, out_c = 0.0, out_d = 0.0, out_in = 0.0;
+                    const int steps = min(kWave, n - t);
+                    for (int i = 0; i < steps; ++i) {
+                        const int k = t + i;
+                        double oa = a_k, ob = b_k, oc = 0.0, od = 0.0, oin = 0.0;
+                        if (k < n - 1) {
+                            const double sub = td_from_lane(sub_l, i), a1 = td_from_lane(a1_l, i), b1 = td_from_lane(b1_l, i);
+                            const double scale2 = fabs(sub) + fabs(a1) + fabs(b1);
+                            const double piv1 = a_k == 0.0 ? 0.0 : fabs(a_k) / scale1;
+                            if (sub == 0.0) {
+                                scale1 = scale2;
+                                a_k = a1;
+                                b_k = b1;
+                            } else if (fabs(sub) / scale2 <= piv1) {  // no interchange
+                                scale1 = scale2;
+                                oc = sub / a_k;
+                                a_k = a1 - oc * b_k;
+                                b_k = b1;
+                            } else {  // rows k and k+1 interchanged
+                                oin = 1.0;
+                                oc = a_k / sub;
+                                oa = sub;
+                                ob = a1;
+                                od = b1;
+                                a_k = b_k - oc * a1;
+                                b_k = -oc * b1;
+                            }
+                        }
+                        if (lane == i) out_a = oa, out_b = ob, out_c = oc, out_d = od, out_in = oin;
+                    }
+                    if (row < n) lu_a[row] = out_a, lu_b[row] = out_b, lu_c[row] = out_c, lu_d[row] = out_d, lu_in[row] = out_in;
+                }
+            }
+            for (int i = lane; i < n; i += kWave) {  // pseudo-random start in (-1, 1)
+                const uint64_t h = splitmix64(((uint64_t)(k_eig + 1) << 32) ^ (uint64_t)i);
+                x[i] = (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+            }
+            __syncthreads();
+            for (int iteration = 0; iteration < 3; ++iteration) {
+                double norm2 = 0.0;
+                for (int i = lane; i < n; i += kWave) norm2 += x[i] * x[i];
+                norm2 = td_wave_sum(norm2);
+                const double scale = norm2 > 0.0 ? 1.0 / sqrt(norm2) : 1.0;
+                // ---- forward: the row operations of the factorisation (dlagts); the scaling is applied on the way
+                {
+                    double r = x[0] * scale;  // x(k) as modified so far
+                    for (int t = 0; t < n; t += kWave) {
+                        const int row = t + lane;
+                        const double next_l = row + 1 < n ? x[row + 1] * scale : 0.0;
+                        const double c_l = row < n ? lu_c[row] : 0.0, in_l = row < n ? lu_in[row] : 0.0;
+                        double out = 0.0;
+                        const int steps = min(kWave, n - t);
+                        for (int i = 0; i < steps; ++i) {
+                            const int k = t + i;
+                            double o = r;
+                            if (k < n - 1) {
+                                const double next = td_from_lane(next_l, i), c = td_from_lane(c_l, i);
+                                if (td_from_lane(in_l, i) == 0.0) r = next - c * r;
+                                else {
+                                    o = next;
+                                    r = r - c * next;
+                                }
+                            }
+                            if (lane == i) out = o;
+                        }
+                        __syncthreads();  // (every lane has read x(row + 1) of this tile before x(row) of the next is ... x(t + 64) is rewritten)
+                        if (row < n) x[row] = out;
+                    }
+                }
+                __syncthreads();
+                // ---- backward: U y = x, tiny pivots perturbed (dlagts, job = -1)
+                {
+                    double y1 = 0.0, y2 = 0.0;  // y(k+1), y(k+2)
+                    for (int t = ((n - 1) / kWave) * kWave; t >= 0; t -= kWave) {
+                        const int row = t + lane;
+                        const double x_l = row < n ? x[row] : 0.0, a_l = row < n ? lu_a[row] : 1.0;
+                        const double b_l = row < n ? lu_b[row] : 0.0, d_l = row < n ? lu_d[row] : 0.0;
+                        double out = 0.0;
+                        for (int i = min(kWave, n - t) - 1; i >= 0; --i) {
+                            const int k = t + i;
+                            double value = td_from_lane(x_l, i);
+                            if (k + 1 < n) value -= td_from_lane(b_l, i) * y1;
+                            if (k + 2 < n) value -= td_from_lane(d_l, i) * y2;
+                            double pivot = td_from_lane(a_l, i);
+                            if (fabs(pivot) < tiny) pivot = pivot < 0.0 ? -tiny : tiny;
+                            const double yk = value / pivot;
+                            y2 = y1;
+                            y1 = yk;
+                            if (lane == i) out = yk;
+                        }
+                        if (row < n) x[row] = out;
+                    }
+                }
+                __syncthreads();
+            }
+            double norm2 = 0.0;
+            for (int i = lane; i < n; i += kWave) norm2 += x[i] * x[i];
+            norm2 = td_wave_sum(norm2);
+            const double scale = norm2 > 0.0 ? 1.0 / sqrt(norm2) : 1.0;
+            for (int i = lane; i < n; i += kWave) z[(size_t)i * ld + k_eig] = x[i] * scale;
+            __syncthreads();
+        }
+    }
+}
+
+// Modified Gram-Schmidt, twice, over the columns first .. first+count-1 of z (one workgroup per cluster of close
+// eigenvalues): an orthonormal basis of the cluster's invariant subspace.  Distinct-but-close members overlap by
+// eps |T| / gap only and are hardly changed; the members of a degenerate level come out as some orthonormal basis of it.
+__global__ __launch_bounds__(256) void td_cluster_orthonormalise(const TdCluster* __restrict__ clusters, int n,
+                                                                 double* __restrict__ z, int ld) {
+    __shared__ double red[4];
+    const TdCluster cluster = clusters[blockIdx.x];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    auto block_sum = [&](double v) {
+        v = td_wave_sum(v);
+        __syncthreads();
+        if (lane == 0) red[wave] = v;
+        __syncthreads();
+        return red[0] + red[1] + red[2] + red[3];
+    };
+    for (int m = 0; m < cluster.count; ++m) {
+        double* zm = z + cluster.first + m;
+        for (int pass = 0; pass < 2; ++pass)
+            for (int p = 0; p < m; ++p) {
+                const double* zp = z + cluster.first + p;
+                double dot = 0.0;
+                for (int i = threadIdx.x; i < n; i += blockDim.x) dot += zm[(size_t)i * ld] * zp[(size_t)i * ld];
+                dot = block_sum(dot);
+                for (int i = threadIdx.x; i < n; i += blockDim.x) zm[(size_t)i * ld] -= dot * zp[(size_t)i * ld];
+                __syncthreads();
+            }
+        double norm2 = 0.0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) norm2 += zm[(size_t)i * ld] * zm[(size_t)i * ld];
+        norm2 = block_sum(norm2);
+        const double scale = norm2 > 0.0 ? 1.0 / sqrt(norm2) : 1.0;
+        for (int i = threadIdx.x; i < n; i += blockDim.x) zm[(size_t)i * ld] *= scale;
+        __syncthreads();
+    }
+}
+
+// ---- back-transformation: eigenvectors of B = Q T Q^H are Q z, Q = H_0 H_1 ... H_{n-2}, H_j = I - tau_j v_j v_j^H.
+// Reflector j acts on rows j+1 .. n-1 of Z:  Z <- Z - tau v (v^H Z).  Two launches per reflector: partial column
+// sums of v^H Z per chunk of rows, then the update (which first adds the chunks up).
+template <typename T>
+__global__ __launch_bounds__(256) void td_reflect_dot(const T* __restrict__ a, int n, int j, const T* __restrict__ z,
+                                                      int ld, int n_vec, int rows_per_chunk, T* __restrict__ partial) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_vec) return;
+    const int r0 = j + 1 + blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    T acc;
+    td_set(acc, 0.0, 0.0);
+    for (int r = r0; r < r1; ++r) {
+        T v;
+        if (r == j + 1) td_set(v, 1.0, 0.0);
+        else v = a[(size_t)j * n + r];
+        acc = td_add(acc, td_mul(td_conj(v), z[(size_t)r * ld + c]));
+    }
+    partial[(size_t)blockIdx.y * n_vec + c] = acc;
+}
+
+// Reflector j applied (rows j+1 .. n-1, in `n_chunks` chunks of `rows_per_chunk` rows) and, on the values just
+// written, the column sums reflector j-1 needs (its rows are j .. n-1: the same rows and row j, which chunk 0 adds).
+// One read and one write of Z per reflector instead of a read for the sums and a read-modify-write for the update.
+template <typename T>
+__global__ __launch_bounds__(256) void td_reflect_step(const T* __restrict__ a, int n, int j, const T* __restrict__ taus,
+                                                       T* __restrict__ z, int ld, int n_vec, int rows_per_chunk,
+                                                       int summed_chunks, const T* __restrict__ partial,
+                                                       T* __restrict__ next_partial) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_vec) return;
+    T g;
+    td_set(g, 0.0, 0.0);
+    for (int chunk = 0; chunk < summed_chunks; ++chunk) g = td_add(g, partial[(size_t)chunk * n_vec + c]);  // (as many as the previous launch wrote)
+    g = td_mul(taus[j], g);
+    const int r0 = j + 1 + blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    T acc;
+    td_set(acc, 0.0, 0.0);
+    const bool feeds_next = j > 0;
+    if (feeds_next && blockIdx.y == 0) acc = z[(size_t)j * ld + c];  // row j: v_{j-1}(j) = 1, untouched by reflector j
+    for (int r = r0; r < r1; ++r) {
+        T v;
+        if (r == j + 1) td_set(v, 1.0, 0.0);
+        else v = a[(size_t)j * n + r];
+        const T value = td_sub(z[(size_t)r * ld + c], td_mul(v, g));
+        z[(size_t)r * ld + c] = value;
+        if (feeds_next) acc = td_add(acc, td_mul(td_conj(a[(size_t)(j - 1) * n + r]), value));  // v_{j-1}(r), r >= j+1
+    }
+    if (feeds_next) next_partial[(size_t)blockIdx.y * n_vec + c] = acc;
+}
+
+// real tridiagonal eigenvectors -> the arithmetic of the back-transformation
+__global__ void td_widen(const double* __restrict__ in, double2* __restrict__ out, int64_t count) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = make_double2(in[i], 0.0);
+}
+__global__ void td_widen(const double* __restrict__ in, double* __restrict__ out, int64_t count) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
+        out[i] = in[i];
+}
+
+// Y (n x n_vec, row-major: eigenvectors of B = conj(H) as columns) -> out[m][i] = conj(Y[i][m]) complex,
+// i.e. eigenvector m of H contiguous (the column-major layout bdg_eigh_dense returns)
+template <typename T>
+__global__ void td_emit_vectors(const T* __restrict__ y, int n, int ld, int n_vec, double2* __restrict__ out) {
+    __shared__ double2 tile[32][33];
+    const int i0 = blockIdx.x * 32, m0 = blockIdx.y * 32;
+    for (int dy = threadIdx.y; dy < 32; dy += blockDim.y) {
+        const int i = i0 + dy, m = m0 + threadIdx.x;
+        if (i < n && m < n_vec) {
+            const T v = y[(size_t)i * ld + m];
+            tile[dy][threadIdx.x] = make_double2(td_re(v), -td_im(v));
+        }
+    }
+    __syncthreads();
+    for (int dy = threadIdx.y; dy < 32; dy += blockDim.y) {
+        const int m = m0 + dy, i = i0 + threadIdx.x;
+        if (i < n && m < n_vec) out[(size_t)m * n + i] = tile[threadIdx.x][dy];
+    }
+}
+
 }  // namespace bdg
 
 namespace {
@@ -197,22 +487,32 @@ inline void scatter_for_tridiagonal(bdg_system* sys, double* a, hipStream_t st) 
     bdg::scatter_dense_real<<<(unsigned)sys->nb, 128, 0, st>>>(sys->indptr.ptr, sys->indices.ptr, sys->blocks.ptr, a, (int)sys->nb);
 }
 
-// All eigenvalues, ascending, of the uploaded matrix.  T = double when imag(H) = 0, else double2.
+// All eigenvalues, ascending, of the uploaded matrix, and - if z_out is given - the eigenvectors of the
+// eigenvalues above `lower_bound` (diagonalize() wants the positive half).  T = double when imag(H) = 0,
+// else double2.  *n_vectors receives the number of such eigenvalues; if it exceeds `capacity` nothing is
+// written to z_out and BDG_EINVAL is returned.  z_out: eigenvector m (m-th eigenvalue above the bound,
+// ascending) in the 4*nb complex entries from z_out + 8*nb*m.
 template <typename T>
-int eigvals_tridiagonal_typed(bdg_system* sys, double* w_out) {
+int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, int64_t capacity, int64_t* n_vectors,
+                          double* z_out) {
     const int64_t n = 4 * sys->nb;
     if (n > 46000) return fail(BDG_EINVAL, "dense path limited to 4*nb <= 46000");
     hipStream_t st = sys->stream;
-    DeviceBuffer<T> a, vectors;  // vectors: v[2], w, q (n each)
-    DeviceBuffer<double> diag;   // d, e, e^2 scratch, eigenvalues (n each)
+    DeviceBuffer<T> a, vectors, taus, y, partial;  // vectors: v[2], w, q (n each)
+    DeviceBuffer<double> diag;                    // d, e, e^2, eigenvalues (n each)
+    DeviceBuffer<double> zt, scratch;             // tridiagonal eigenvectors, LU work space
+    DeviceBuffer<bdg::TdCluster> clusters_dev;
+    DeviceBuffer<double2> emitted;
     DeviceBuffer<bdg::TdScalars<T>> scal;
     auto body = [&]() -> int {
         if (int rc = a.reserve((size_t)n * n)) return rc;
         if (int rc = vectors.reserve((size_t)4 * n)) return rc;
+        if (int rc = taus.reserve((size_t)n)) return rc;
         if (int rc = diag.reserve((size_t)4 * n)) return rc;
         if (int rc = scal.reserve(1)) return rc;
         HIP_TRY(hipMemsetAsync(a.ptr, 0, sizeof(T) * n * n, st));
         HIP_TRY(hipMemsetAsync(vectors.ptr, 0, sizeof(T) * 4 * n, st));
+        HIP_TRY(hipMemsetAsync(taus.ptr, 0, sizeof(T) * n, st));
         HIP_TRY(hipMemsetAsync(diag.ptr, 0, sizeof(double) * 4 * n, st));
         HIP_TRY(hipMemsetAsync(scal.ptr, 0, sizeof(bdg::TdScalars<T>), st));
         scatter_for_tridiagonal(sys, a.ptr, st);
@@ -224,7 +524,7 @@ int eigvals_tridiagonal_typed(bdg_system* sys, double* w_out) {
         for (int64_t j = 0; j < n; ++j) {
             T* v_prev = v[(j + 1) & 1];  // made at step j-1
             T* v_new = v[j & 1];
-            bdg::td_vector_step<T><<<1, 1024, 0, st>>>(a.ptr, (int)n, (int)j, v_prev, w, q, v_new, d, e, scal.ptr);
+            bdg::td_vector_step<T><<<1, 1024, 0, st>>>(a.ptr, (int)n, (int)j, v_prev, w, q, v_new, d, e, scal.ptr, taus.ptr);
             if (j + 1 < n) {
                 const int64_t rows = n - j - 1;
                 const unsigned grid = (unsigned)std::min<int64_t>(4096, (rows + 3) / 4);
@@ -258,20 +558,111 @@ int eigvals_tridiagonal_typed(bdg_system* sys, double* w_out) {
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(w_out, eig_dev, sizeof(double) * n, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (!z_out && !n_vectors) return BDG_OK;
+
+        // ---- eigenvectors of the eigenvalues above the bound
+        int64_t first = 0;
+        while (first < n && !(w_out[first] > lower_bound)) ++first;
+        const int64_t n_vec = n - first;
+        if (n_vectors) *n_vectors = n_vec;
+        if (!z_out || n_vec == 0) return BDG_OK;
+        if (n_vec > capacity) return fail(BDG_EINVAL, "%lld eigenvalues above the bound, room for %lld eigenvectors", (long long)n_vec, (long long)capacity);
+        // clusters: runs of eigenvalues closer than 1e-5 |T| are orthogonalised against each other afterwards; everything
+        // further apart is orthogonal to eps |T| / gap <= 2e-11 from inverse iteration alone.  Column m of zt = eigenvalue first + m.
+        const double cluster_gap = 1e-5 * std::max(span, 1e-300), nudge = 10.0 * 2.220446049250313e-16 * span;
+        std::vector<bdg::TdCluster> clusters;  // (first = column, count >= 2)
+        std::vector<double> shift((size_t)n_vec);
+        for (int64_t k = first, run = 0; k < n; ++k) {
+            run = (k > first && w_out[k] - w_out[k - 1] < cluster_gap) ? run + 1 : 0;
+            // shifts of a run at least `nudge` apart (dstein): members of a degenerate level decorrelate
+            shift[(size_t)(k - first)] = run == 0 ? w_out[k] : std::max(w_out[k], shift[(size_t)(k - first - 1)] + nudge);
+            if (run == 1) clusters.push_back({(int)(k - first - 1), 2});
+            else if (run > 1) ++clusters.back().count;
+        }
+        const int n_waves = (int)std::min<int64_t>(n_vec, 7168);
+        if (int rc = zt.reserve((size_t)n * n_vec)) return rc;
+        if (int rc = scratch.reserve((size_t)n_waves * 6 * n + (size_t)n_vec)) return rc;
+        double* shift_dev = scratch.ptr + (size_t)n_waves * 6 * n;
+        HIP_TRY(hipMemcpyAsync(shift_dev, shift.data(), sizeof(double) * n_vec, hipMemcpyHostToDevice, st));
+        bdg::td_inverse_iteration<<<n_waves, 64, 0, st>>>(d, e, (int)n, shift_dev, (int)n_vec, span, scratch.ptr, zt.ptr, (int)n_vec);
+        if (!clusters.empty()) {
+            if (int rc = clusters_dev.reserve(clusters.size())) return rc;
+            HIP_TRY(hipMemcpyAsync(clusters_dev.ptr, clusters.data(), sizeof(bdg::TdCluster) * clusters.size(), hipMemcpyHostToDevice, st));
+            bdg::td_cluster_orthonormalise<<<(unsigned)clusters.size(), 256, 0, st>>>(clusters_dev.ptr, (int)n, zt.ptr, (int)n_vec);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));  // (the host lists leave scope; errors of the kernels surface here)
+        scratch.release();
+        // ---- back-transformation Y = H_0 H_1 ... H_{n-2} Z, last reflector first
+        if (int rc = y.reserve((size_t)n * n_vec)) return rc;
+        bdg::td_widen<<<4096, 256, 0, st>>>(zt.ptr, y.ptr, n * n_vec);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+        zt.release();
+        // (the chunking of reflector j's rows also serves the sums of reflector j-1, which the same launch takes)
+        constexpr int kChunks = 16;
+        if (int rc = partial.reserve((size_t)2 * kChunks * n_vec)) return rc;
+        const unsigned col_blocks = (unsigned)((n_vec + 255) / 256);
+        auto chunks_of = [&](int64_t j, int* n_chunks, int* rows_per_chunk) {
+            const int64_t rows = n - j - 1;
+            *n_chunks = (int)std::min<int64_t>(kChunks, (rows + 63) / 64);
+            *rows_per_chunk = (int)((rows + *n_chunks - 1) / *n_chunks);
+        };
+        T* part[2] = {partial.ptr, partial.ptr + (size_t)kChunks * n_vec};
+        if (n >= 2) {
+            int n_chunks = 0, rows_per_chunk = 0;
+            chunks_of(n - 2, &n_chunks, &rows_per_chunk);
+            bdg::td_reflect_dot<T><<<dim3(col_blocks, (unsigned)n_chunks), 256, 0, st>>>(a.ptr, (int)n, (int)(n - 2), y.ptr, (int)n_vec,
+                                                                                    (int)n_vec, rows_per_chunk, part[0]);
+            int flip = 0, written_chunks = n_chunks;
+            for (int64_t j = n - 2; j >= 0; --j) {
+                chunks_of(j, &n_chunks, &rows_per_chunk);
+                bdg::td_reflect_step<T><<<dim3(col_blocks, (unsigned)n_chunks), 256, 0, st>>>(
+                    a.ptr, (int)n, (int)j, taus.ptr, y.ptr, (int)n_vec, (int)n_vec, rows_per_chunk, written_chunks, part[flip],
+                    part[flip ^ 1]);
+                written_chunks = n_chunks;
+                flip ^= 1;
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        // eigenvectors of H = conj(B): contiguous per vector, conjugated
+        if (int rc = emitted.reserve((size_t)n * n_vec)) return rc;
+        const dim3 tiles((unsigned)((n + 31) / 32), (unsigned)((n_vec + 31) / 32));
+        bdg::td_emit_vectors<T><<<tiles, dim3(32, 8), 0, st>>>(y.ptr, (int)n, (int)n_vec, (int)n_vec, emitted.ptr);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(z_out, emitted.ptr, sizeof(double2) * n * n_vec, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
         return BDG_OK;
     };
     const int rc = body();
     a.release();
     vectors.release();
+    taus.release();
+    y.release();
+    partial.release();
     diag.release();
+    zt.release();
+    scratch.release();
+    clusters_dev.release();
+    emitted.release();
     scal.release();
     return rc;
 }
 
-int eigvals_tridiagonal(bdg_system* sys, double* w_out) {
+bool tridiagonal_real_route(const bdg_system* sys) {
     bool real_route = sys->is_real;
     if (const char* env = knob::raw("BODGE_AMD_EIGH_REAL")) real_route = real_route && atoi(env) != 0;
-    return real_route ? eigvals_tridiagonal_typed<double>(sys, w_out) : eigvals_tridiagonal_typed<double2>(sys, w_out);
+    return real_route;
+}
+
+int eigvals_tridiagonal(bdg_system* sys, double* w_out) {
+    return tridiagonal_real_route(sys) ? eig_tridiagonal_typed<double>(sys, w_out, 0.0, 0, nullptr, nullptr)
+                                       : eig_tridiagonal_typed<double2>(sys, w_out, 0.0, 0, nullptr, nullptr);
+}
+
+int eig_tridiagonal_above(bdg_system* sys, double* w_out, double lower_bound, int64_t capacity, int64_t* n_vectors, double* z_out) {
+    return tridiagonal_real_route(sys) ? eig_tridiagonal_typed<double>(sys, w_out, lower_bound, capacity, n_vectors, z_out)
+                                       : eig_tridiagonal_typed<double2>(sys, w_out, lower_bound, capacity, n_vectors, z_out);
 }
 
 }  // namespace

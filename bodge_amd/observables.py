@@ -432,10 +432,11 @@ def diagonalize(system, format: str = "reshape"):
     """Positive eigenpairs, ascending; same shapes as reference hamiltonian.py:228-248."""
     if format not in ("raw", "reshape"):
         raise RuntimeError(f"Eigenstate format '{format}' is not yet supported.")
-    vals, vecs = system._solver().eigh(vectors=True)
-    keep = vals > 0
-    vals = np.ascontiguousarray(vals[keep])
-    vecs = np.ascontiguousarray(vecs[:, keep])
+    # (only the eigenvectors of the positive eigenvalues are computed and copied: half the work for a BdG matrix)
+    vals, vecs = system._solver().eigh_above(0.0)
+    vals = np.ascontiguousarray(vals[vals > 0])
+    vecs = np.ascontiguousarray(vecs)
+    assert vecs.shape[1] == vals.size
     if format == "raw":
         return vals, vecs
     return vals, vecs.T.reshape((vals.size, -1, 4))

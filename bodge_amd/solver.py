@@ -22,8 +22,7 @@ def _default_device() -> int:
     return device % backend.device_count()
 
 
-DENSE_LIBRARY_FROM = 2048  # 4N above which dense eigensolves go to rocSOLVER (kJacobiLimit in the library)
-DENSE_LIBRARY_PREFETCH_UPTO = 16384  # = observables.DENSE_AUTO_LIMIT_T0
+DENSE_LIBRARY_FROM = 2048  # 4N above which bdg_eigh_dense WITH all eigenvectors goes to rocSOLVER (kJacobiLimit in the library)
 
 
 def prefetch_dense_library() -> None:
@@ -105,8 +104,8 @@ class DeviceSolver:
 
     @classmethod
     def from_hamiltonian(cls, system, device: int | None = None, drop_zero_blocks: bool = True):
-        if DENSE_LIBRARY_FROM < system.shape[0] <= DENSE_LIBRARY_PREFETCH_UPTO:
-            prefetch_dense_library()  # sizes method="auto" may send to rocSOLVER: overlap its file I/O
+        # (no read-ahead of the rocSOLVER object any more: from 4N > 512 on eigenvalues and eigenvectors come from
+        # the library's own tridiagonalisation route; rocSOLVER is reached only through BODGE_AMD_EIGH)
         indptr, indices, data = system.bsr_arrays(drop_zero_blocks=drop_zero_blocks)
         solver = cls(indptr, indices, data, device=device)
         from .lattice import CubicLattice
@@ -269,6 +268,23 @@ class DeviceSolver:
             self._lib.bdg_eigh_dense(self._handle, backend.as_f64p(w), backend.as_f64p(z.view(np.float64)))
         )
         return w, z.T
+
+    def eigh_above(self, lower_bound: float = 0.0):
+        """All eigenvalues ascending, and the eigenvectors (as columns) of those above `lower_bound` - what
+        `diagonalize()` keeps.  From 4N > 512 on the library's own tridiagonalisation route (no rocSOLVER)."""
+        self._lanczos_vectors = 0
+        w = np.empty(self.dim)
+        count = C.c_int64(0)
+        capacity = self.dim // 2 + 8
+        for _ in range(2):
+            z = np.empty((capacity, self.dim), dtype=np.complex128)
+            status = self._lib.bdg_eigh_dense_above(self._handle, float(lower_bound), capacity, backend.as_f64p(w),
+                                                    C.byref(count), backend.as_f64p(z.view(np.float64)))
+            if status == 0 or count.value <= capacity:
+                break
+            capacity = count.value  # (an asymmetric spectrum: more than half of the eigenvalues above the bound)
+        backend.check(status)
+        return w, z[: count.value].T
 
     def hermiticity_defect(self) -> float:
         """max |H - H^†| over the stored entries of the uploaded matrix (device-side twin of the

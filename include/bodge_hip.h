@@ -209,6 +209,19 @@ int bdg_random_vector(bdg_system* sys, uint64_t seed, uint64_t vec_id, int32_t v
 int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out);
 
 /*
+ * What diagonalize() keeps (hamiltonian.py:235-238: the eigenpairs with eigenvalue > 0): all 4*nb
+ * eigenvalues ascending in w_out, and the eigenvectors of those above `lower_bound` only - vector m of
+ * them (ascending) in the 4*nb complex entries from z_out + 8*nb*m; *n_vectors = their number.  If it
+ * exceeds `capacity` (vectors z_out has room for) BDG_EINVAL is returned with *n_vectors set and z_out
+ * untouched.  Route from 4*nb > 512 on, no library involved: Householder tridiagonalisation, bisection,
+ * inverse iteration on the tridiagonal matrix (close eigenvalues orthogonalised against each other) and
+ * back-transformation by the stored reflectors - half the vectors of the full solve for a BdG matrix.
+ * Below, and when BODGE_AMD_EIGH names another driver, bdg_eigh_dense runs and its result is cut.
+ */
+int bdg_eigh_dense_above(bdg_system* sys, double lower_bound, int64_t capacity, double* w_out,
+                         int64_t* n_vectors, double* z_out);
+
+/*
  * max |H - H^†| over the stored entries of the uploaded matrix, computed on the device: the
  * Hermiticity test the reference makes on the host when a `with` block closes
  * (hamiltonian.py:121-122, `abs(M - M.getH()).max() > 1e-6` -> RuntimeError).  Whole matrices only.

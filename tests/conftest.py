@@ -107,8 +107,8 @@ def _dense_library_prefetch(request):
         from bodge_amd import backend, solver
 
         if backend.device_count() > 0:
-            solver.prefetch_dense_library()  # (read first: the dense ladder is a scope row of its own)
-            solver.prefetch_rccl_library()
+            solver.prefetch_rccl_library()   # (read first: the communicator tests have no other route)
+            solver.prefetch_dense_library()  # rocSOLVER: an optional cross-check since the own tridiagonalisation route
     except Exception:  # library not built yet: the tests that need it say so themselves
         pass
 

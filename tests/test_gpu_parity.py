@@ -1174,6 +1174,36 @@ def test_eigenvalues_by_tridiagonalisation_match_the_reference(api, golden, knob
             assert abs(value - expect) <= 1e-10 * abs(value)
 
 
+@pytest.mark.parametrize("name", ["swave30_zeeman", "peierls30", "chain300", "swave50_zeeman", "dwave8", "snf"])
+def test_dense_ladder_without_a_library(api, golden, name):
+    """BASELINE config 5's feasible ladder through the DEFAULT route of `diagonalize()` - the library's own
+    Householder tridiagonalisation, bisection, inverse iteration and back-transformation (csrc/tridiag.hpp),
+    no rocSOLVER: n = 3600 real and complex, the literal "300" chain (n = 1200), n = 10^4, and two smaller
+    systems with highly degenerate spectra (dwave8: zero modes and 4-fold levels; snf).  Eigenvalues within
+    1e-10 of the reference's own diagonalize(), eigen-equation residual <= 1e-9, orthonormal finite
+    vectors (every vector against a sample of 64), the reference's (k, N, 4) layout, and no rocSOLVER
+    object mapped into the process afterwards."""
+    system = _build(api, name)
+    dim = system.shape[0]
+    vals, vecs = system.diagonalize(format="raw")
+    ref = golden.eigenvalues(name)
+    zero_modes = int(np.count_nonzero(ref < 1e-12))
+    assert vecs.shape == (dim, vals.size) and np.isfinite(vecs).all() and np.all(np.diff(vals) >= 0)
+    # (zero modes: which of a ± pair at 1e-16 counts as "positive" is round-off, here as in the reference)
+    assert abs(vals.size - ref.size) <= zero_modes
+    assert np.abs(vals[-(ref.size - zero_modes):] - ref[zero_modes:]).max() <= 1e-10
+    bsr = system.matrix("bsr")
+    assert np.abs(bsr @ vecs - vecs * vals).max() <= 1e-9
+    idx = np.arange(0, vals.size, max(1, vals.size // 64))
+    gram = vecs[:, idx].conj().T @ vecs
+    gram[np.arange(idx.size), idx] -= 1.0
+    assert np.abs(gram).max() <= 1e-9
+    _, shaped = system.diagonalize()
+    assert shaped.shape == (vals.size, dim // 4, 4) and np.array_equal(shaped[3, 7, :], vecs[28:32, 3])
+    with open("/proc/self/maps") as fh:
+        assert "librocsolver" not in fh.read() or os.environ.get("BODGE_AMD_EIGH")
+
+
 @pytest.mark.parametrize("rayleigh_ritz", ["device", "host"])
 @pytest.mark.parametrize("name,k", [("swave20", 6), ("snf", 5), ("complex235", 4), ("swave20_zeeman", 3)])
 def test_lowest_eigenpairs_with_multiplicities_and_vectors(api, golden, name, k, rayleigh_ritz):
