@@ -147,7 +147,14 @@ __global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n,
 }
 
 // Trailing block rows / columns j+1 .. n-1: apply the pending update of step j-1, store, multiply by v_new.
-// One wave per row; q[r] = sum_c B'(r, c) v_new[c].
+// One wave per row; q[r] = sum_c B'(r, c) v_new[c].  16 bytes per lane and access: a complex entry, or two
+// real ones (n = 4 nb is even, so rows start 16-byte aligned and only the first column of an odd j+1 stands alone).
+template <typename T>
+__device__ inline T td_updated(T value, bool pending, T vr, T wr, T wc, T vc) {
+    if (pending) value = td_sub(value, td_add(td_mul(vr, td_conj(wc)), td_mul(wr, td_conj(vc))));
+    return value;
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void td_fused_pass(T* __restrict__ a, int n, int j, const T* __restrict__ v_prev,
                                                      const T* __restrict__ w_prev, const T* __restrict__ v_new,
@@ -163,13 +170,31 @@ __global__ __launch_bounds__(256) void td_fused_pass(T* __restrict__ a, int n, i
         T acc;
         td_set(acc, 0.0, 0.0);
         T* row = a + (size_t)r * n;
-        for (int c = j + 1 + lane; c < n; c += kWave) {
-            T value = row[c];
-            if (pending) {
-                value = td_sub(value, td_add(td_mul(vr, td_conj(w_prev[c])), td_mul(wr, td_conj(v_prev[c]))));
-                row[c] = value;
+        if constexpr (sizeof(T) == sizeof(double)) {
+            int c0 = j + 1;
+            if (c0 & 1) {  // lone first column
+                if (lane == 0) {
+                    const T value = td_updated(row[c0], pending, vr, wr, w_prev[c0], v_prev[c0]);
+                    if (pending) row[c0] = value;
+                    acc = td_mul(value, v_new[c0]);
+                }
+                ++c0;
             }
-            acc = td_add(acc, td_mul(value, v_new[c]));
+            for (int c = c0 + 2 * lane; c < n; c += 2 * kWave) {  // (n even: c + 1 < n)
+                double2 pair = *reinterpret_cast<const double2*>(row + c);
+                const double2 wc = *reinterpret_cast<const double2*>(w_prev + c), vc = *reinterpret_cast<const double2*>(v_prev + c);
+                const double2 vn = *reinterpret_cast<const double2*>(v_new + c);
+                pair.x = td_updated(pair.x, pending, vr, wr, wc.x, vc.x);
+                pair.y = td_updated(pair.y, pending, vr, wr, wc.y, vc.y);
+                if (pending) *reinterpret_cast<double2*>(row + c) = pair;
+                acc = fma(pair.x, vn.x, fma(pair.y, vn.y, acc));
+            }
+        } else {
+            for (int c = j + 1 + lane; c < n; c += kWave) {
+                const T value = td_updated(row[c], pending, vr, wr, w_prev[c], v_prev[c]);
+                if (pending) row[c] = value;
+                acc = td_add(acc, td_mul(value, v_new[c]));
+            }
         }
         for (int off = kWave / 2; off >= 1; off >>= 1) acc = td_add(acc, td_shfl(acc, off));
         if (lane == 0) q[r] = acc;
@@ -396,54 +421,109 @@ __global__ __launch_bounds__(256) void td_cluster_orthonormalise(const TdCluster
     }
 }
 
-// ---- back-transformation: eigenvectors of B = Q T Q^H are Q z, Q = H_0 H_1 ... H_{n-2}, H_j = I - tau_j v_j v_j^H.
-// Reflector j acts on rows j+1 .. n-1 of Z:  Z <- Z - tau v (v^H Z).  Two launches per reflector: partial column
-// sums of v^H Z per chunk of rows, then the update (which first adds the chunks up).
+// ---- back-transformation: eigenvectors of B = Q T Q^H are Q z, Q = H_0 H_1 ... H_{n-2}, H_l = I - tau_l v_l v_l^H
+// (v_l(r) = 0 for r <= l, 1 at r = l+1, stored in row l of the matrix beyond that).  The reflectors are applied
+// last first, kTdGroup at a time per pass over Z: for the group l_0 > l_1 > ... (l_i = hi - i) with column sums
+// s_i = v_{l_i}^H Z taken on Z as it is BEFORE the group,
+//     g_0 = tau_{l_0} s_0,   g_i = tau_{l_i} (s_i - sum_{m<i} (v_{l_i}^H v_{l_m}) g_m),   Z <- Z - sum_i v_{l_i} g_i
+// (the compact WY form written out), and the same pass takes, on the values it has just written, the sums the
+// NEXT group needs: one read and one write of Z per kTdGroup reflectors.
+constexpr int kTdGroup = 4;
+
 template <typename T>
-__global__ __launch_bounds__(256) void td_reflect_dot(const T* __restrict__ a, int n, int j, const T* __restrict__ z,
-                                                      int ld, int n_vec, int rows_per_chunk, T* __restrict__ partial) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= n_vec) return;
-    const int r0 = j + 1 + blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
-    T acc;
-    td_set(acc, 0.0, 0.0);
-    for (int r = r0; r < r1; ++r) {
-        T v;
-        if (r == j + 1) td_set(v, 1.0, 0.0);
-        else v = a[(size_t)j * n + r];
-        acc = td_add(acc, td_mul(td_conj(v), z[(size_t)r * ld + c]));
-    }
-    partial[(size_t)blockIdx.y * n_vec + c] = acc;
+__device__ inline T td_reflector_entry(const T* __restrict__ a, int n, int l, int r) {
+    T v;
+    td_set(v, r == l + 1 ? 1.0 : 0.0, 0.0);
+    if (r > l + 1) v = a[(size_t)l * n + r];
+    return v;
 }
 
-// Reflector j applied (rows j+1 .. n-1, in `n_chunks` chunks of `rows_per_chunk` rows) and, on the values just
-// written, the column sums reflector j-1 needs (its rows are j .. n-1: the same rows and row j, which chunk 0 adds).
-// One read and one write of Z per reflector instead of a read for the sums and a read-modify-write for the update.
+// cross[i][m] = v_{l_i}^H v_{l_m} for the reflectors l_i = hi - i, i < count (one workgroup)
 template <typename T>
-__global__ __launch_bounds__(256) void td_reflect_step(const T* __restrict__ a, int n, int j, const T* __restrict__ taus,
-                                                       T* __restrict__ z, int ld, int n_vec, int rows_per_chunk,
-                                                       int summed_chunks, const T* __restrict__ partial,
-                                                       T* __restrict__ next_partial) {
+__global__ __launch_bounds__(256) void td_reflector_gram(const T* __restrict__ a, int n, int hi, int count, T* __restrict__ cross) {
+    __shared__ T scratch[4];
+    const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+    for (int i = 1; i < count; ++i)
+        for (int m = 0; m < i; ++m) {
+            T acc;
+            td_set(acc, 0.0, 0.0);
+            for (int r = hi - m + 1 + threadIdx.x; r < n; r += blockDim.x)  // support of the higher reflector l_m
+                acc = td_add(acc, td_mul(td_conj(td_reflector_entry(a, n, hi - i, r)), td_reflector_entry(a, n, hi - m, r)));
+            for (int off = kWave / 2; off >= 1; off >>= 1) acc = td_add(acc, td_shfl(acc, off));
+            __syncthreads();
+            if (lane == 0) scratch[wave] = acc;
+            __syncthreads();
+            if (threadIdx.x == 0) cross[i * kTdGroup + m] = td_add(td_add(scratch[0], scratch[1]), td_add(scratch[2], scratch[3]));
+        }
+}
+
+// column sums of the first group, on Z as it comes from the inverse iteration: partial[chunk][i][c]
+template <typename T>
+__global__ __launch_bounds__(256) void td_reflect_sums(const T* __restrict__ a, int n, int hi, int count, const T* __restrict__ z,
+                                                       int ld, int n_vec, int row0, int rows_per_chunk, T* __restrict__ partial) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_vec) return;
-    T g;
-    td_set(g, 0.0, 0.0);
-    for (int chunk = 0; chunk < summed_chunks; ++chunk) g = td_add(g, partial[(size_t)chunk * n_vec + c]);  // (as many as the previous launch wrote)
-    g = td_mul(taus[j], g);
-    const int r0 = j + 1 + blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
-    T acc;
-    td_set(acc, 0.0, 0.0);
-    const bool feeds_next = j > 0;
-    if (feeds_next && blockIdx.y == 0) acc = z[(size_t)j * ld + c];  // row j: v_{j-1}(j) = 1, untouched by reflector j
+    const int r0 = row0 + blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    T acc[kTdGroup];
+#pragma unroll
+    for (int i = 0; i < kTdGroup; ++i) td_set(acc[i], 0.0, 0.0);
     for (int r = r0; r < r1; ++r) {
-        T v;
-        if (r == j + 1) td_set(v, 1.0, 0.0);
-        else v = a[(size_t)j * n + r];
-        const T value = td_sub(z[(size_t)r * ld + c], td_mul(v, g));
-        z[(size_t)r * ld + c] = value;
-        if (feeds_next) acc = td_add(acc, td_mul(td_conj(a[(size_t)(j - 1) * n + r]), value));  // v_{j-1}(r), r >= j+1
+        const T value = z[(size_t)r * ld + c];
+#pragma unroll
+        for (int i = 0; i < kTdGroup; ++i)
+            if (i < count) acc[i] = td_add(acc[i], td_mul(td_conj(td_reflector_entry(a, n, hi - i, r)), value));
     }
-    if (feeds_next) next_partial[(size_t)blockIdx.y * n_vec + c] = acc;
+#pragma unroll
+    for (int i = 0; i < kTdGroup; ++i) partial[((size_t)blockIdx.y * kTdGroup + i) * n_vec + c] = acc[i];
+}
+
+// The group hi, hi-1, ... (count of them) applied to rows row0 .. n-1 (row0 = hi - count + 2) and the sums of the next
+// group (next_hi = hi - count, next_count reflectors) taken on the result; the rows next_row0 .. row0 - 1 that only the
+// next group touches are added by chunk 0.
+template <typename T>
+__global__ __launch_bounds__(256) void td_reflect_group(const T* __restrict__ a, int n, int hi, int count, const T* __restrict__ taus,
+                                                        const T* __restrict__ cross, T* __restrict__ z, int ld, int n_vec,
+                                                        int row0, int rows_per_chunk, int summed_chunks, const T* __restrict__ partial,
+                                                        int next_count, int next_row0, T* __restrict__ next_partial) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= n_vec) return;
+    T g[kTdGroup], acc[kTdGroup];
+#pragma unroll
+    for (int i = 0; i < kTdGroup; ++i) {
+        td_set(g[i], 0.0, 0.0);
+        td_set(acc[i], 0.0, 0.0);
+        if (i < count) {
+            T s;
+            td_set(s, 0.0, 0.0);
+            for (int chunk = 0; chunk < summed_chunks; ++chunk) s = td_add(s, partial[((size_t)chunk * kTdGroup + i) * n_vec + c]);
+#pragma unroll
+            for (int m = 0; m < kTdGroup; ++m)
+                if (m < i) s = td_sub(s, td_mul(cross[i * kTdGroup + m], g[m]));
+            g[i] = td_mul(taus[hi - i], s);
+        }
+    }
+    const int next_hi = hi - count;
+    if (next_count > 0 && blockIdx.y == 0)
+        for (int r = next_row0; r < row0; ++r) {  // rows below this group's reach
+            const T value = z[(size_t)r * ld + c];
+#pragma unroll
+            for (int i = 0; i < kTdGroup; ++i)
+                if (i < next_count) acc[i] = td_add(acc[i], td_mul(td_conj(td_reflector_entry(a, n, next_hi - i, r)), value));
+        }
+    const int r0 = row0 + blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
+    for (int r = r0; r < r1; ++r) {
+        T value = z[(size_t)r * ld + c];
+#pragma unroll
+        for (int i = 0; i < kTdGroup; ++i)
+            if (i < count) value = td_sub(value, td_mul(td_reflector_entry(a, n, hi - i, r), g[i]));
+        z[(size_t)r * ld + c] = value;
+#pragma unroll
+        for (int i = 0; i < kTdGroup; ++i)
+            if (i < next_count) acc[i] = td_add(acc[i], td_mul(td_conj(td_reflector_entry(a, n, next_hi - i, r)), value));
+    }
+    if (next_count > 0)
+#pragma unroll
+        for (int i = 0; i < kTdGroup; ++i) next_partial[((size_t)blockIdx.y * kTdGroup + i) * n_vec + c] = acc[i];
 }
 
 // real tridiagonal eigenvectors -> the arithmetic of the back-transformation
@@ -599,29 +679,40 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
         zt.release();
-        // (the chunking of reflector j's rows also serves the sums of reflector j-1, which the same launch takes)
-        constexpr int kChunks = 16;
-        if (int rc = partial.reserve((size_t)2 * kChunks * n_vec)) return rc;
+        // kTdGroup reflectors per pass over Z; the pass of a group also takes the column sums of the next one
+        constexpr int kChunks = 16, kGroup = bdg::kTdGroup;
+        if (int rc = partial.reserve((size_t)2 * kChunks * kGroup * n_vec + (size_t)kGroup * kGroup)) return rc;
+        T* part[2] = {partial.ptr, partial.ptr + (size_t)kChunks * kGroup * n_vec};
+        T* cross = partial.ptr + (size_t)2 * kChunks * kGroup * n_vec;
         const unsigned col_blocks = (unsigned)((n_vec + 255) / 256);
-        auto chunks_of = [&](int64_t j, int* n_chunks, int* rows_per_chunk) {
-            const int64_t rows = n - j - 1;
-            *n_chunks = (int)std::min<int64_t>(kChunks, (rows + 63) / 64);
+        auto chunks_of = [&](int64_t row0, int* n_chunks, int* rows_per_chunk) {
+            const int64_t rows = n - row0;
+            *n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(kChunks, (rows + 63) / 64));
             *rows_per_chunk = (int)((rows + *n_chunks - 1) / *n_chunks);
         };
-        T* part[2] = {partial.ptr, partial.ptr + (size_t)kChunks * n_vec};
         if (n >= 2) {
+            int64_t hi = n - 2;
+            int count = (int)std::min<int64_t>(kGroup, hi + 1);
+            int64_t row0 = hi - count + 2;
             int n_chunks = 0, rows_per_chunk = 0;
-            chunks_of(n - 2, &n_chunks, &rows_per_chunk);
-            bdg::td_reflect_dot<T><<<dim3(col_blocks, (unsigned)n_chunks), 256, 0, st>>>(a.ptr, (int)n, (int)(n - 2), y.ptr, (int)n_vec,
-                                                                                    (int)n_vec, rows_per_chunk, part[0]);
+            chunks_of(row0, &n_chunks, &rows_per_chunk);
+            bdg::td_reflect_sums<T><<<dim3(col_blocks, (unsigned)n_chunks), 256, 0, st>>>(a.ptr, (int)n, (int)hi, count, y.ptr, (int)n_vec,
+                                                                                     (int)n_vec, (int)row0, rows_per_chunk, part[0]);
             int flip = 0, written_chunks = n_chunks;
-            for (int64_t j = n - 2; j >= 0; --j) {
-                chunks_of(j, &n_chunks, &rows_per_chunk);
-                bdg::td_reflect_step<T><<<dim3(col_blocks, (unsigned)n_chunks), 256, 0, st>>>(
-                    a.ptr, (int)n, (int)j, taus.ptr, y.ptr, (int)n_vec, (int)n_vec, rows_per_chunk, written_chunks, part[flip],
-                    part[flip ^ 1]);
+            while (hi >= 0) {
+                const int64_t next_hi = hi - count;
+                const int next_count = next_hi >= 0 ? (int)std::min<int64_t>(kGroup, next_hi + 1) : 0;
+                const int64_t next_row0 = next_count > 0 ? next_hi - next_count + 2 : row0;
+                bdg::td_reflector_gram<T><<<1, 256, 0, st>>>(a.ptr, (int)n, (int)hi, count, cross);
+                chunks_of(row0, &n_chunks, &rows_per_chunk);
+                bdg::td_reflect_group<T><<<dim3(col_blocks, (unsigned)n_chunks), 256, 0, st>>>(
+                    a.ptr, (int)n, (int)hi, count, taus.ptr, cross, y.ptr, (int)n_vec, (int)n_vec, (int)row0, rows_per_chunk,
+                    written_chunks, part[flip], next_count, (int)next_row0, part[flip ^ 1]);
                 written_chunks = n_chunks;
                 flip ^= 1;
+                hi = next_hi;
+                count = next_count;
+                row0 = next_row0;
             }
         }
         HIP_TRY(hipGetLastError());
