@@ -16,14 +16,16 @@
 //     BODGE_AMD_SWEEP_STEPS=2|3              steps per sweep (cheb_sweep / cheb_sweep3)
 //     BODGE_AMD_SWEEP_LANES=1|2|4            lanes per site of the sweep kernels
 //     BODGE_AMD_SWEEP_GEN=0                  write the random start block with the fill kernel instead of making it in the first sweep
-//     BODGE_AMD_EIGH=jacobi|rocsolver|...    dense solver route;  BODGE_AMD_EIGH_REAL=0  complex route for a real matrix
+//     BODGE_AMD_EIGH=jacobi|tridiagonal|rocsolver|evd|evj|ev   dense solver route (default: Jacobi up to 512 rows, own
+//                                            tridiagonalisation route above);  BODGE_AMD_EIGH_REAL=0  complex arithmetic for a real matrix
+//     BODGE_AMD_ONSITE_STREAM=0              (read at upload) no bond-only dictionary + on-site stream for matrices with > 256 distinct blocks
 //     BODGE_AMD_NO_DIAGONAL_BLOCKS           withhold the "diagonal as a 4x4 matrix" flag of dictionary blocks (read at upload)
 //   launch shape and memory hints
 //     BODGE_AMD_BLOCKS_PER_CU=n              cap on resident workgroups per CU
 //     BODGE_AMD_SWEEP_SEGMENTS=n             x-segments of the sweep / rolling kernels (default: choose_segments)
 //     BODGE_AMD_SWEEP_ZIGZAG=0               all segments march the same way
 //     BODGE_AMD_ALTERNATE=0                  launches do not alternate their marching direction
-//     BODGE_AMD_SWEEP_STREAM=bits            non-temporal hints of the sweep kernels (1 t_{n-1} loads, 2 stores, 4 t_n loads)
+//     BODGE_AMD_SWEEP_STREAM=bits            non-temporal hints of the sweep kernels (1 t_{n-1} loads, 2 stores, 4 t_n loads, 8 on-site records)
 //     BODGE_AMD_STREAM_VECTORS=bits          the same for the one-step and rolling kernels
 //     BODGE_AMD_L2_BUDGET=bytes              per-XCD budget behind the strip width of the tile order
 //     BODGE_AMD_BATCH=n                      vectors per launch of the one-step kernels (default: batch_width)
