@@ -59,7 +59,8 @@ def build_system(shape, model="swave", zeeman=0.05, gap=0.1, mu=3.0, seed=11):
     """Synthetic Hamiltonians of SURVEY §8d: "swave" = README model (+Zeeman), "dwave" = config 4;
     "potential" / "texture" = the s-wave model with position-dependent on-site terms (a random
     potential and gap amplitude: real; an exchange field of varying direction: complex blocks) -
-    10^6 distinct diagonal blocks, what per-site fills (ref hamiltonian.py:102-118) make of it; "peierls" =
+    10^6 distinct diagonal blocks, what per-site fills (ref hamiltonian.py:102-118) make of it; "ssd" = every term of the
+    s-wave model scaled by the reference's sine-squared envelope (bond blocks position dependent too); "peierls" =
     the s-wave model with a uniform phase on the x bonds (translation invariant, genuinely complex).
     The Hermiticity test of the closing `with` block is made on the host: the process must not touch
     the GPU before the CPU baseline has forked its workers."""
@@ -84,6 +85,14 @@ def build_system(shape, model="swave", zeeman=0.05, gap=0.1, mu=3.0, seed=11):
             H.set_sites(mu * ba.σ0 - 0.3 * (np.sin(th) * np.cos(ph) * ba.σ1 + np.sin(th) * np.sin(ph) * ba.σ2 + np.cos(th) * ba.σ3))
             Δ.set_sites(-gap * ba.jσ2)
             H.set_bonds(-1.0 * ba.σ0)
+        elif model == "ssd":  # the reference's sine-squared deformation (ref hamiltonian.py:488-531) of the s-wave model
+            φ = ba.ssd(system)
+            coords = np.stack(np.unravel_index(np.arange(sites), tuple(shape)), axis=-1)
+            pairs = lattice.bond_array(coords=True)
+            on_site, on_bond = φ(coords, coords)[:, None, None], φ(pairs[:, 0], pairs[:, 1])[:, None, None]
+            H.set_sites(on_site * (mu * ba.σ0 - zeeman * ba.σ3))
+            Δ.set_sites(-gap * on_site * ba.jσ2)
+            H.set_bonds(-on_bond * ba.σ0)
         elif model == "peierls":
             pairs = lattice.bond_array(axis=0, coords=True)  # directed x bonds: a phase one way, its conjugate back
             phase = np.where(pairs[:, 1, 0] > pairs[:, 0, 0], np.exp(0.3j), np.exp(-0.3j))
@@ -251,7 +260,7 @@ def main():
     ap.add_argument("--lanes", type=int, default=0, help="override lanes per block row (tuning)")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--temperature", type=float, default=0.5)
-    ap.add_argument("--model", default="swave", choices=["swave", "dwave"])
+    ap.add_argument("--model", default="swave", choices=["swave", "dwave", "potential", "texture", "ssd", "peierls"])
     ap.add_argument("--mode", default="vectors", choices=["vectors", "slab"],
                     help="vectors: H replicated, start vectors sharded (weak scaling, headline); "
                          "slab: lattice planes sharded with per-step halo exchange (strong scaling, config 4)")
@@ -365,7 +374,8 @@ def main():
     def kernel_label(pf):
         mode = f"{'Real' if pf['real_arithmetic'] else 'Complex'}{'PH' if pf['ph_packed'] else ''}Mode"
         if pf["steps_per_launch"] == 3:
-            return f"cheb_sweep3<{mode},{pf['lanes_per_row']}{',onsite-streamed' if pf['onsite_streamed'] else ''}>"
+            tag = {0: "", 1: ",onsite-streamed", 2: ",all-blocks-streamed"}[pf["onsite_streamed"]]
+            return f"cheb_sweep3<{mode},{pf['lanes_per_row']}{tag}>"
         if pf["steps_per_launch"] == 2:
             return f"cheb_sweep<{mode},{pf['lanes_per_row']}>"
         if pf["rolling"]:
@@ -418,7 +428,8 @@ def main():
         record = out["default"]
         record["one_step"] = out["one_step"]
         record["workload"] = {"potential": "random on-site potential and gap amplitude (10^6 distinct diagonal blocks), real",
-                              "texture": "exchange field of varying direction on every site (10^6 distinct diagonal blocks), complex"}[model]
+                              "texture": "exchange field of varying direction on every site (10^6 distinct diagonal blocks), complex",
+                              "ssd": "every term scaled by the reference's ssd() envelope (on-site AND bond blocks position dependent), real"}[model]
         record["distinct_blocks_total"] = "> 256" if pf["dict_skipped"] == 1 else pf["dict_blocks"]
         return record
 
@@ -432,6 +443,7 @@ def main():
     probe = solver.perf()  # which kernel family the default route takes on this matrix
     position_pass = other_matrix("potential", VEC_RADEMACHER) if world == 1 and args.model == "swave" else None
     texture_pass = other_matrix("texture", VEC_Z4) if world == 1 and args.model == "swave" else None
+    ssd_pass = other_matrix("ssd", VEC_RADEMACHER) if world == 1 and args.model == "swave" else None
     complex_one_step = (alternative({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"})
                         if probe["real_arithmetic"] else None)
     complex_sweep = alternative({"BODGE_AMD_REAL": "0"}) if probe["real_arithmetic"] and probe["steps_per_launch"] >= 2 else None
@@ -515,6 +527,7 @@ def main():
         "one_step_kernels": one_step_pass,
         "streamed_blocks_kernels": position_pass,
         "complex128_kernels": texture_pass,
+        "streamed_bonds_kernels": ssd_pass,
         "complex128_sweep_kernels": complex_sweep,
         "streamed_blocks_one_step_kernels": streamed_one_step,
         "complex128_one_step_kernels": complex_one_step,

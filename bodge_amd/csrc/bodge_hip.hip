@@ -121,7 +121,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     constexpr int kMaxDistinct = 256;  // table index shares a 32-bit word with the 24-bit column
     constexpr unsigned kStreamedId = 0xFEu;
     int dict_skipped = 0;
-    bool onsite_streamed = false;
+    bool onsite_streamed = false, bonds_streamed = false;
     std::vector<int> ids;
     std::vector<double> distinct;  // n_unique x 32 doubles
     {
@@ -177,8 +177,33 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
         if (wanted && !dedupe(false, kMaxDistinct)) {
             dict_skipped = 1;
             const char* os_env = knob::raw("BODGE_AMD_ONSITE_STREAM");
-            wanted = ncols == nb && !(os_env && os_env[0] == '0') && dedupe(true, (int)kStreamedId) && !distinct.empty();
+            const bool may_stream = ncols == nb && !(os_env && os_env[0] == '0');
+            wanted = may_stream && dedupe(true, (int)kStreamedId) && !distinct.empty();
             onsite_streamed = wanted;
+            if (!wanted && may_stream) {
+                // Third form: bond blocks position dependent too.  Every block of the matrix real; diagonal blocks
+                // packable as above; off-diagonal blocks diagonal as 4x4 matrices of the Nambu form diag(a, b, -a, -b).
+                // Then nothing is tabulated (one dummy table entry keeps the table plumbing uniform).
+                bool ok = true;
+                for (int64_t i = 0; i < nb && ok; ++i)
+                    for (int64_t k = indptr[i]; k < indptr[i + 1] && ok; ++k) {
+                        const double* blk = data + 32 * k;
+                        for (int e = 0; e < 16 && ok; ++e) ok = blk[2 * e + 1] == 0.0;  // real
+                        if (!ok) break;
+                        if (indices[k] == i) ok = onsite_packable(blk);
+                        else {
+                            for (int e = 0; e < 16 && ok; ++e)
+                                if ((e >> 2) != (e & 3)) ok = blk[2 * e] == 0.0;
+                            ok = ok && blk[2 * 10] == -blk[2 * 0] && blk[2 * 15] == -blk[2 * 5];
+                        }
+                    }
+                if (ok) {
+                    ids.assign((size_t)nnzb, 0);
+                    for (int64_t k = 0; k < nnzb; ++k) ids[(size_t)k] = (int)((unsigned)indices[k] | (kStreamedId << 24));
+                    distinct.assign(32, 0.0);
+                    wanted = onsite_streamed = bonds_streamed = true;
+                }
+            }
         }
         if (!wanted) {
             ids.clear();
@@ -268,6 +293,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     }
     sys->dict_skipped = dict_skipped;
     sys->onsite_streamed = onsite_streamed;
+    sys->bonds_streamed = bonds_streamed;
     sys->is_real = is_real;
     sys->is_ph = is_ph;
     sys->gershgorin = gershgorin;
@@ -475,6 +501,7 @@ int bdg_destroy(bdg_system* sys) {
     for (auto& buf : sys->packed) buf.release();
     for (auto& buf : sys->dict_table) buf.release();
     for (auto& buf : sys->onsite) buf.release();
+    sys->site_records.release();
     sys->dict_ids.release();
     sys->dict_diagonal.release();
     sys->dict_full.release();

@@ -130,6 +130,13 @@ struct bdg_system {
     // (cheb_sweep3<..., OS>); every other kernel family streams all blocks of such a matrix.
     bool onsite_streamed = false;
     DeviceBuffer<double2> onsite[2];  // [0] complex (6 x 16 B per site), [1] real (4 x 16 B); built on first use
+    // ... and when the bond blocks differ from bond to bond as well (the reference's ssd() profile, bond disorder) but
+    // are all diagonal as 4x4 matrices (spin-diagonal hopping, no bond pairing) and the matrix is real: no table at
+    // all, every site carries its four bond blocks (two doubles each) next to its on-site block in one 128-byte
+    // record (`site_records`, built once the lattice shape is known); real arithmetic only.
+    bool bonds_streamed = false;
+    DeviceBuffer<double2> site_records;
+    int site_records_plane = 0;  // lattice plane size the records were built for
     DeviceBuffer<int> dict_ids;
     DeviceBuffer<int> dict_diagonal;      // per distinct block: 1 = diagonal as a 4x4 matrix (stencil kernels)
     DeviceBuffer<double2> dict_full;      // n_unique x 16 complex entries

@@ -461,6 +461,13 @@ struct RealPHMode {
         rfma(acc[3], -s0.y, x[2]);
         rfma(acc[3], -s1.x, x[3]);
     }
+    // a streamed bond block diag(a.x, a.y, -a.x, -a.y) (sweep.hpp, OS = 2): mac_diag's products in mac_diag's order
+    __device__ static inline void mac_bond(double2 acc[4], const double2 a, const double2 x[4]) {
+        rfma(acc[0], a.x, x[0]);
+        rfma(acc[1], a.y, x[1]);
+        rfma(acc[2], -a.x, x[2]);
+        rfma(acc[3], -a.y, x[3]);
+    }
     __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
         RealMode::dots(dot, c, n);
     }

@@ -303,6 +303,19 @@ int ensure_onsite(bdg_system* sys, bool real, const double2** out) {
     return BDG_OK;
 }
 
+// Per-site records (on-site + four bond blocks) of a matrix whose bond blocks are streamed too; needs the lattice shape.
+int ensure_site_records(bdg_system* sys, int plane, const double2** out) {
+    if (!sys->site_records.ptr || sys->site_records_plane != plane) {
+        if (int rc = sys->site_records.reserve((size_t)sys->nb * 8)) return rc;
+        bdg::pack_site_records<<<(unsigned)std::min<int64_t>(4096, (sys->nb + 255) / 256), 256, 0, sys->stream>>>(
+            sys->indptr.ptr, sys->indices.ptr, sys->blocks.ptr, (int)sys->nb, plane, sys->site_records.ptr);
+        HIP_TRY(hipGetLastError());
+        sys->site_records_plane = plane;
+    }
+    *out = sys->site_records.ptr;
+    return BDG_OK;
+}
+
 // Matrix-side kernel arguments for `plan` (block data or dictionary, sizes).  Every launch of
 // a step kernel goes through here so that no pointer the chosen kernel reads is left unset.
 constexpr size_t kStreamVectorBytes = (size_t)256 << 20;
@@ -441,14 +454,19 @@ SweepKernel sweep3_gen_kernel(const ModeInfo& mode, int lanes) {
     return sweep3_gen_kernel_for<ComplexMode>(lanes);
 }
 
-// cheb_sweep3 with streamed on-site blocks: particle-hole modes, 4 lanes per site
-SweepKernel sweep3_streamed_kernel(const ModeInfo& mode, bool reverse, bool gen) {
+// cheb_sweep3 with streamed on-site blocks: particle-hole modes, 4 lanes per site; `bonds`: the bond blocks as well (real only)
+SweepKernel sweep3_streamed_kernel(const ModeInfo& mode, bool reverse, bool gen, bool bonds = false) {
     if (!mode.ph) return nullptr;
+    if (bonds) {
+        if (!mode.real) return nullptr;
+        return gen ? bdg::cheb_sweep3<RealPHMode, 4, false, true, 2>
+                   : reverse ? bdg::cheb_sweep3<RealPHMode, 4, true, false, 2> : bdg::cheb_sweep3<RealPHMode, 4, false, false, 2>;
+    }
     if (mode.real)
-        return gen ? bdg::cheb_sweep3<RealPHMode, 4, false, true, true>
-                   : reverse ? bdg::cheb_sweep3<RealPHMode, 4, true, false, true> : bdg::cheb_sweep3<RealPHMode, 4, false, false, true>;
-    return gen ? bdg::cheb_sweep3<ComplexPHMode, 4, false, true, true>
-               : reverse ? bdg::cheb_sweep3<ComplexPHMode, 4, true, false, true> : bdg::cheb_sweep3<ComplexPHMode, 4, false, false, true>;
+        return gen ? bdg::cheb_sweep3<RealPHMode, 4, false, true, 1>
+                   : reverse ? bdg::cheb_sweep3<RealPHMode, 4, true, false, 1> : bdg::cheb_sweep3<RealPHMode, 4, false, false, 1>;
+    return gen ? bdg::cheb_sweep3<ComplexPHMode, 4, false, true, 1>
+               : reverse ? bdg::cheb_sweep3<ComplexPHMode, 4, true, false, 1> : bdg::cheb_sweep3<ComplexPHMode, 4, false, false, 1>;
 }
 
 SweepKernel sweep3_kernel(const ModeInfo& mode, int lanes, bool reverse) {
@@ -529,7 +547,8 @@ int ensure_stencil(bdg_system* sys, int* kind) {
                 else
                     bdg::build_stencil<<<grid, 256, 0, sys->stream>>>(sys->indptr.ptr, sys->dict_ids.ptr,
                                                                        sys->dict_diagonal.ptr, (int)sys->nb, (int)plane,
-                                                                       sys->onsite_streamed ? 1 : 0, sys->stencil.ptr, bad.ptr);
+                                                                       sys->bonds_streamed ? 2 : sys->onsite_streamed ? 1 : 0,
+                                                                       sys->stencil.ptr, bad.ptr);
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipMemcpyAsync(host_bad, bad.ptr, 3 * sizeof(int), hipMemcpyDeviceToHost, sys->stream));
                 HIP_TRY(hipStreamSynchronize(sys->stream));
@@ -576,21 +595,21 @@ int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, int* kind
 int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth, SweepPlan* plan) {
     plan->lanes = lanes;
     plan->depth = depth;
-    const bool streamed = sys->onsite_streamed;
-    if (streamed && (lanes != 4 || depth != 3 || !mode.ph))
-        return fail(BDG_EINVAL, "streamed on-site blocks need the three-step sweep with 4 lanes per site and particle-hole packed blocks");
-    plan->kernel = streamed ? sweep3_streamed_kernel(mode, false, false)
+    const bool streamed = sys->onsite_streamed, bonds = sys->bonds_streamed;
+    if (streamed && (lanes != 4 || depth != 3 || !mode.ph || (bonds && !mode.real)))
+        return fail(BDG_EINVAL, "streamed on-site blocks need the three-step sweep with 4 lanes per site and particle-hole packed blocks (real arithmetic if the bond blocks are streamed too)");
+    plan->kernel = streamed ? sweep3_streamed_kernel(mode, false, false, bonds)
                             : depth == 3 ? sweep3_kernel(mode, lanes, false) : sweep_kernel(mode, lanes, false);
-    plan->kernel_reverse = streamed ? sweep3_streamed_kernel(mode, true, false)
+    plan->kernel_reverse = streamed ? sweep3_streamed_kernel(mode, true, false, bonds)
                                     : depth == 3 ? sweep3_kernel(mode, lanes, true) : sweep_kernel(mode, lanes, true);
-    plan->kernel_gen = streamed ? sweep3_streamed_kernel(mode, false, true) : depth == 3 ? sweep3_gen_kernel(mode, lanes) : nullptr;
+    plan->kernel_gen = streamed ? sweep3_streamed_kernel(mode, false, true, bonds) : depth == 3 ? sweep3_gen_kernel(mode, lanes) : nullptr;
     if (!plan->kernel) return fail(BDG_EINVAL, "the sweep kernel has 1, 2 or 4 lanes per site, not %d", lanes);
     const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
     if (table > table_limit(sys)) return fail(BDG_EINVAL, "block table too large for the sweep kernel");
     size_t rows = (size_t)bdg::kSweepWaves * depth * bdg::kWave * 4 * sizeof(double2);
-    if (streamed)  // ring of three planes of on-site records per wave
+    if (streamed)  // ring of three planes of per-site records per wave (stride 9: on-site + four bond blocks)
         rows += (size_t)bdg::kSweepWaves * 3 * (bdg::kWave / lanes) *
-                (mode.real ? RealPHMode::kOnsiteStride : ComplexPHMode::kOnsiteStride) * sizeof(double2);
+                (bonds ? 9 : mode.real ? RealPHMode::kOnsiteStride : ComplexPHMode::kOnsiteStride) * sizeof(double2);
     plan->lds_bytes = table + rows;
     if (plan->lds_bytes > 64 * 1024)
         for (SweepKernel k : {plan->kernel, plan->kernel_reverse, plan->kernel_gen})
@@ -606,8 +625,11 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     a = bdg::SweepArgs{};
     a.stencil = sys->stencil.ptr;
     if (int rc = ensure_dict_table(sys, mode, &a.dict_table)) return rc;
-    if (streamed)
+    if (bonds) {
+        if (int rc = ensure_site_records(sys, (int)plane, &a.onsite)) return rc;
+    } else if (streamed) {
         if (int rc = ensure_onsite(sys, mode.real, &a.onsite)) return rc;
+    }
     a.n_unique = sys->n_unique;
     a.nb = (int)sys->nb;
     a.plane = (int)plane;
@@ -635,6 +657,7 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
 // With streamed on-site blocks each site adds its packed record (64 B real / 96 B complex), read once.
 double sweep_bytes(const bdg_system* sys, const ModeInfo& mode, int lanes) {
     const double onsite = !sys->onsite_streamed ? 0.0
+                          : sys->bonds_streamed ? 128.0  // on-site + four bond blocks per site
                           : 16.0 * (mode.real ? RealPHMode::kOnsiteSlots : ComplexPHMode::kOnsiteSlots);
     return (8.0 + onsite) * (double)sys->nb + (mode.block_bytes - 4.0) * sys->n_unique +
            4.0 * (4.0 * lanes * sizeof(double2)) * (double)sys->nb;

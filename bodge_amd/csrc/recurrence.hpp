@@ -78,6 +78,7 @@ struct Batch {
         // wide arithmetic mode can exceed that: it takes the one-step kernels, which then stream its blocks)
         if ((size_t)sys->n_unique * mode.stride * sizeof(double2) > table_limit(sys)) stencil_kind = 0;
         if (sys->onsite_streamed && !mode.ph) stencil_kind = 0;  // (packed on-site records assume the Nambu form)
+        if (sys->bonds_streamed && !mode.real) stencil_kind = 0;  // (bond records exist in real arithmetic only: Z4 vectors take the one-step kernels)
         if (stencil_kind == 1) {
             const int lanes = sweep_lanes_for(sys, n_active, per_lane);
             if (n_active <= lanes * per_lane) {
@@ -562,7 +563,7 @@ struct Batch {
         p.steps_per_launch = sweep ? splan.depth : 1;
         p.rolling = roll ? 1 : 0;
         p.dict_skipped = sys->dict_skipped;
-        p.onsite_streamed = sweep && sys->onsite_streamed ? 1 : 0;
+        p.onsite_streamed = sweep && sys->onsite_streamed ? (sys->bonds_streamed ? 2 : 1) : 0;
         p.lanes_per_row = rl;
         p.vectors_per_launch = rv;
         p.real_arithmetic = real ? 1 : 0;

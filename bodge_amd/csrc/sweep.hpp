@@ -93,7 +93,8 @@ struct SweepArgs {
 // seam; they take the slots of the -1 / +1 / -P / +P neighbours they are, and bad[1] / bad[2]
 // tell the kernels to close the plane / the stack of planes into rings.
 // `onsite_streamed`: the words of the diagonal blocks carry no table id (the sweep reads those blocks
-// from the per-site stream); their slot is only marked present.
+// from the per-site stream); their slot is only marked present.  2 = the same for every block (bond blocks
+// streamed as well: pack_site_records).
 __global__ void build_stencil(const int* __restrict__ indptr, const int* __restrict__ words,
                               const int* __restrict__ diagonal, int nb, int plane, int onsite_streamed,
                               uint2* __restrict__ stencil, int* __restrict__ bad) {
@@ -126,7 +127,7 @@ __global__ void build_stencil(const int* __restrict__ indptr, const int* __restr
                 atomicOr(bad + 2, 1);
             }
             if (slot < 0 || (w >> 24) == kNoBlock) ok = false;
-            else if (onsite_streamed && slot == 2) id[slot] = 0;
+            else if (onsite_streamed == 2 || (onsite_streamed && slot == 2)) id[slot] = 0;  // (2: every block is streamed)
             else {
                 id[slot] = w >> 24;
                 if (diagonal[w >> 24]) mask |= 1u << slot;
@@ -134,6 +135,44 @@ __global__ void build_stencil(const int* __restrict__ indptr, const int* __restr
         }
         if (!ok) atomicOr(bad, 1);
         stencil[i] = make_uint2(id[0] | (id[1] << 8) | (id[2] << 16) | (id[3] << 24), id[4] | (mask << 8));
+    }
+}
+
+// Per-site records of a matrix whose bond blocks are streamed too (real, bond blocks diagonal as 4x4 matrices):
+// eight 16-byte slots per block row - the packed on-site block of RealPHMode::mac_onsite (slots 0..3), then
+// (A00, A11) of the blocks at the stencil offsets -P, -1, +1, +P (slots 4..7; zeros where not stored), found
+// by the rule of build_stencil (wrap-around blocks of periodic lattices included).
+__global__ void pack_site_records(const int* __restrict__ indptr, const int* __restrict__ indices,
+                                  const double2* __restrict__ blocks, int nb, int plane, double2* __restrict__ out) {
+    const int lx = nb / plane;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
+        const double2 zero = make_double2(0.0, 0.0);
+        double2 rec[8] = {zero, zero, zero, zero, zero, zero, zero, zero};
+        const int p = i % plane, x = i / plane;
+        for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
+            const double2* blk = blocks + (size_t)k * 16;
+            const int off = indices[k] - i;
+            int slot = -1;
+            if (off == -plane) slot = 0;
+            else if (off == -1 && p >= 1) slot = 1;
+            else if (off == 0) slot = 2;
+            else if (off == 1 && p <= plane - 2) slot = 3;
+            else if (off == plane) slot = 4;
+            else if (off == plane - 1 && p == 0) slot = 1;
+            else if (off == -(plane - 1) && p == plane - 1) slot = 3;
+            else if (off == (lx - 1) * plane && x == 0) slot = 0;
+            else if (off == -(lx - 1) * plane && x == lx - 1) slot = 4;
+            if (slot == 2) {
+                rec[0] = make_double2(blk[0].x, blk[1].x);
+                rec[1] = make_double2(blk[5].x, 0.0);
+                rec[2] = make_double2(blk[2].x, blk[3].x);
+                rec[3] = make_double2(blk[6].x, blk[7].x);
+            } else if (slot >= 0) {
+                rec[4 + (slot < 2 ? slot : slot - 1)] = make_double2(blk[0].x, blk[5].x);
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) out[(size_t)i * 8 + e] = rec[e];
     }
 }
 
@@ -407,18 +446,31 @@ constexpr int sweep3_owned(int rl) { return kWave / rl - 6; }
 // LDS ring of three planes, because step j of iteration k works on plane k-j+1: plane k's blocks
 // serve step 1 now, step 2 in the next iteration and step 3 in the one after.  Only with 4 lanes
 // per site (16 slots: the ring is 3 x 16 x kOnsiteStride slots per wave) and the particle-hole modes.
-template <typename Mode, bool OS>
-constexpr int sweep3_ring_slots(int slots) {
-    if constexpr (OS) return 3 * slots * Mode::kOnsiteStride;
+// OS = 2: the bond blocks are streamed as well (real matrices whose bond blocks are diagonal as 4x4 matrices - the
+// reference's ssd() profile on a model with on-site pairing, bond disorder): the record of a site is its packed on-site
+// block plus (A00, A11) of its four bond blocks, 8 slots = 128 B (pack_site_records), no table at all.
+template <typename Mode, int OS>
+constexpr int sweep3_record_slots() {
+    if constexpr (OS == 2) return 8;
+    else if constexpr (OS == 1) return Mode::kOnsiteSlots;
     else return 0;
 }
-template <typename Mode, bool OS>
-constexpr int sweep3_onsite_pieces() {
-    if constexpr (OS) return Mode::kOnsiteSlots;
+template <typename Mode, int OS>
+constexpr int sweep3_record_stride() {
+    if constexpr (OS == 2) return 9;
+    else if constexpr (OS == 1) return Mode::kOnsiteStride;
     else return 0;
+}
+template <typename Mode, int OS>
+constexpr int sweep3_ring_slots(int slots) {
+    return 3 * slots * sweep3_record_stride<Mode, OS>();
+}
+template <typename Mode, int OS>
+constexpr int sweep3_onsite_pieces() {
+    return sweep3_record_slots<Mode, OS>();
 }
 
-template <typename Mode, int RL, bool REV, bool GEN = false, bool OS = false>
+template <typename Mode, int RL, bool REV, bool GEN = false, int OS = 0>
 __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
     extern __shared__ double2 lds[];
     constexpr int SLOTS = kWave / RL;
@@ -426,6 +478,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
     constexpr int SPB = Mode::kSlotsPerBlock;
     constexpr int STRIDE = Mode::kBlockStride;
     constexpr int RING = sweep3_ring_slots<Mode, OS>(SLOTS);  // LDS slots of the on-site ring (0 without OS)
+    constexpr int RSTRIDE = sweep3_record_stride<Mode, OS>();
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
     const int s = lane / RL;
@@ -559,34 +612,44 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
         auto apply = [&](uint2 w, const double2 before[4], const double2* row, const double2 mid[4],
                          const double2 after[4], double2 acc[4], [[maybe_unused]] int kk) {
             double2 x[4];
-            if (rev) mac(w, 0, after, acc);
-            else mac(w, 0, before, acc);
+            [[maybe_unused]] const double2* rec = nullptr;
+            if constexpr (OS != 0) rec = ring_entry(kk) + s * RSTRIDE;
+            // one bond block times the neighbour's entries: from the table, or (OS = 2) from the site's record
+            auto bond = [&](int slot, const double2 v[4]) {
+                if constexpr (OS == 2) {
+                    if (id_of(w, slot) != kNoBlock) Mode::mac_bond(acc, rec[4 + (slot < 2 ? slot : slot - 1)], v);
+                } else {
+                    mac(w, slot, v, acc);
+                }
+            };
+            if (rev) bond(0, after);
+            else bond(0, before);
             if (id_of(w, 1) != kNoBlock) {
 #pragma unroll
                 for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane - RL, be)];
-                mac(w, 1, x, acc);
+                bond(1, x);
             }
-            if constexpr (OS) {
-                if (id_of(w, 2) != kNoBlock) Mode::mac_onsite(acc, ring_entry(kk) + s * Mode::kOnsiteStride, mid);
+            if constexpr (OS != 0) {
+                if (id_of(w, 2) != kNoBlock) Mode::mac_onsite(acc, rec, mid);
             } else {
                 mac(w, 2, mid, acc);
             }
             if (id_of(w, 3) != kNoBlock) {
 #pragma unroll
                 for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane + RL, be)];
-                mac(w, 3, x, acc);
+                bond(3, x);
             }
-            if (rev) mac(w, 4, before, acc);
-            else mac(w, 4, after, acc);
+            if (rev) bond(4, before);
+            else bond(4, after);
         };
 
         // OS: the wave's window of on-site records of one plane is contiguous in memory (SLOTS x
         // kOnsiteSlots 16-byte pieces; with periodic planes the halo slots wrap, so the address is
         // taken per piece): piece e of the window belongs to slot e / kOnsiteSlots.
-        constexpr int OSL = OS ? (SLOTS * sweep3_onsite_pieces<Mode, OS>() + kWave - 1) / kWave : 1;  // pieces per lane
+        constexpr int OSL = OS != 0 ? (SLOTS * sweep3_onsite_pieces<Mode, OS>() + kWave - 1) / kWave : 1;  // pieces per lane
         [[maybe_unused]] auto load_onsite = [&](int k, bool wanted, double2 out[OSL]) {
-            if constexpr (OS) {
-                constexpr int PIECES = Mode::kOnsiteSlots;
+            if constexpr (OS != 0) {
+                constexpr int PIECES = sweep3_record_slots<Mode, OS>();
                 k = ring(act(k));
 #pragma unroll
                 for (int j = 0; j < OSL; ++j) {
@@ -605,13 +668,13 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
             }
         };
         [[maybe_unused]] auto put_onsite = [&](int kk, const double2 v[OSL]) {
-            if constexpr (OS) {
-                constexpr int PIECES = Mode::kOnsiteSlots;
+            if constexpr (OS != 0) {
+                constexpr int PIECES = sweep3_record_slots<Mode, OS>();
                 double2* dst = ring_entry(kk);
 #pragma unroll
                 for (int j = 0; j < OSL; ++j) {
                     const int e = lane + j * kWave, slot = e / PIECES, part = e - slot * PIECES;
-                    if (slot < SLOTS) dst[slot * Mode::kOnsiteStride + part] = v[j];
+                    if (slot < SLOTS) dst[slot * RSTRIDE + part] = v[j];
                 }
             }
         };
@@ -632,7 +695,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
         for (int al = 0; al < 4; ++al) c1_m[al] = c2_m[al] = zero;
         put_own(row_1, c1_m);  // the rows still hold the previous unit's planes
         put_own(row_2, c1_m);
-        if constexpr (OS) {  // on-site blocks of the first plane (the later ones arrive one iteration ahead)
+        if constexpr (OS != 0) {  // on-site blocks of the first plane (the later ones arrive one iteration ahead)
             double2 first_os[OSL];
             load_onsite(k_first, true, first_os);
             put_onsite(k_first, first_os);

@@ -386,35 +386,57 @@ __global__ __launch_bounds__(64) void td_inverse_iteration(const double* __restr
     }
 }
 
-// Modified Gram-Schmidt, twice, over the columns first .. first+count-1 of z (one workgroup per cluster of close
-// eigenvalues): an orthonormal basis of the cluster's invariant subspace.  Distinct-but-close members overlap by
+// Gram-Schmidt with re-orthogonalisation over the columns first .. first+count-1 of z (one workgroup per cluster of
+// close eigenvalues): an orthonormal basis of the cluster's invariant subspace.  Distinct-but-close members overlap by
 // eps |T| / gap only and are hardly changed; the members of a degenerate level come out as some orthonormal basis of it.
+// Member m is orthogonalised against its predecessors eight at a time (one pass over the rows and one workgroup
+// reduction per eight: a flat band of a thousand-fold level stays affordable), twice, then normalised.
 __global__ __launch_bounds__(256) void td_cluster_orthonormalise(const TdCluster* __restrict__ clusters, int n,
                                                                  double* __restrict__ z, int ld) {
-    __shared__ double red[4];
+    constexpr int kAtOnce = 8;
+    __shared__ double red[4][kAtOnce];
+    __shared__ double dots[kAtOnce];
     const TdCluster cluster = clusters[blockIdx.x];
     const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
-    auto block_sum = [&](double v) {
-        v = td_wave_sum(v);
-        __syncthreads();
-        if (lane == 0) red[wave] = v;
-        __syncthreads();
-        return red[0] + red[1] + red[2] + red[3];
-    };
     for (int m = 0; m < cluster.count; ++m) {
         double* zm = z + cluster.first + m;
         for (int pass = 0; pass < 2; ++pass)
-            for (int p = 0; p < m; ++p) {
-                const double* zp = z + cluster.first + p;
-                double dot = 0.0;
-                for (int i = threadIdx.x; i < n; i += blockDim.x) dot += zm[(size_t)i * ld] * zp[(size_t)i * ld];
-                dot = block_sum(dot);
-                for (int i = threadIdx.x; i < n; i += blockDim.x) zm[(size_t)i * ld] -= dot * zp[(size_t)i * ld];
+            for (int p0 = 0; p0 < m; p0 += kAtOnce) {
+                const int np = min(kAtOnce, m - p0);
+                const double* zp = z + cluster.first + p0;
+                double acc[kAtOnce];
+#pragma unroll
+                for (int q = 0; q < kAtOnce; ++q) acc[q] = 0.0;
+                for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                    const double value = zm[(size_t)i * ld];
+#pragma unroll
+                    for (int q = 0; q < kAtOnce; ++q)
+                        if (q < np) acc[q] = fma(value, zp[(size_t)i * ld + q], acc[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < kAtOnce; ++q) {
+                    const double total = td_wave_sum(acc[q]);
+                    if (lane == 0) red[wave][q] = total;
+                }
+                __syncthreads();
+                if ((int)threadIdx.x < kAtOnce) dots[threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
+                __syncthreads();
+                for (int i = threadIdx.x; i < n; i += blockDim.x) {
+                    double value = zm[(size_t)i * ld];
+#pragma unroll
+                    for (int q = 0; q < kAtOnce; ++q)
+                        if (q < np) value = fma(-dots[q], zp[(size_t)i * ld + q], value);
+                    zm[(size_t)i * ld] = value;
+                }
                 __syncthreads();
             }
         double norm2 = 0.0;
-        for (int i = threadIdx.x; i < n; i += blockDim.x) norm2 += zm[(size_t)i * ld] * zm[(size_t)i * ld];
-        norm2 = block_sum(norm2);
+        for (int i = threadIdx.x; i < n; i += blockDim.x) norm2 = fma(zm[(size_t)i * ld], zm[(size_t)i * ld], norm2);
+        norm2 = td_wave_sum(norm2);
+        if (lane == 0) red[wave][0] = norm2;
+        __syncthreads();
+        norm2 = red[0][0] + red[1][0] + red[2][0] + red[3][0];
+        __syncthreads();
         const double scale = norm2 > 0.0 ? 1.0 / sqrt(norm2) : 1.0;
         for (int i = threadIdx.x; i < n; i += blockDim.x) zm[(size_t)i * ld] *= scale;
         __syncthreads();

@@ -66,7 +66,8 @@ typedef struct bdg_perf {
                               distinct blocks, 2 = more than 2^24 block columns, 3 = BODGE_AMD_DICT=0 */
     int32_t onsite_streamed; /* 1 = position-dependent on-site blocks: the diagonal block of every site is
                                 streamed from HBM once per launch, only the bond blocks sit in the table
-                                (dict_blocks then counts the distinct bond blocks)                      */
+                                (dict_blocks then counts the distinct bond blocks); 2 = the bond blocks are
+                                streamed as well (real matrices with spin-diagonal hopping: no table)      */
     int32_t reserved;      /* keeps the struct a multiple of 8 bytes */
 } bdg_perf;
 

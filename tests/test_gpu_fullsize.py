@@ -355,14 +355,16 @@ def test_complex_hamiltonian_full_length_at_full_size(api, hip_library):
             assert abs(f_gpu - f_ref) <= 1e-10 * abs(f_ref), env
 
 
-@pytest.mark.parametrize("kind", ["potential", "texture"])
+@pytest.mark.parametrize("kind", ["potential", "texture", "ssd"])
 def test_position_dependent_onsite_terms_full_length_at_full_size(api, hip_library, kind):
     """1000 x 1000 with a different on-site block at every site (10^6 distinct blocks - no dictionary),
     M = 512: the three-step sweep that streams the on-site blocks (cheb_sweep3 OS, sweep.hpp) against
     the C/OpenMP restatement on the same vectors, every d_n, e_n within 1e-12 * 4N and F within 1e-10
     relative; then the one-step streamed-blocks kernel, same gate.  "potential": random potential and
     gap amplitude, real arithmetic, 8 Rademacher vectors; "texture": an exchange field whose direction
-    varies from site to site (σ1, σ2, σ3 components: complex blocks), 4 Z4 vectors."""
+    varies from site to site (σ1, σ2, σ3 components: complex blocks), 4 Z4 vectors; "ssd": every term -
+    hopping included - scaled by the reference's sine-squared envelope (ref hamiltonian.py:488-531):
+    the bond blocks are streamed as well (cheb_sweep3 OS = 2)."""
     from bodge_amd import chebyshev
     from bodge_amd.solver import DeviceSolver
     from oracle import cheb_c
@@ -375,15 +377,24 @@ def test_position_dependent_onsite_terms_full_length_at_full_size(api, hip_libra
         if kind == "potential":
             H.set_sites((3.0 + rng.uniform(-0.5, 0.5, sites))[:, None, None] * api.σ0 - 0.05 * api.σ3)
             Δ.set_sites(-rng.uniform(0.05, 0.15, sites)[:, None, None] * api.jσ2)
+        elif kind == "ssd":
+            φ = api.ssd(system)
+            coords = np.stack(np.unravel_index(np.arange(sites), lattice.shape), axis=-1)
+            pairs = lattice.bond_array(coords=True)
+            on_site, on_bond = φ(coords, coords)[:, None, None], φ(pairs[:, 0], pairs[:, 1])[:, None, None]
+            H.set_sites(on_site * (3.0 * api.σ0 - 0.05 * api.σ3))
+            Δ.set_sites(-0.1 * on_site * api.jσ2)
+            H.set_bonds(-on_bond * api.σ0)
         else:
             th, ph = rng.uniform(0, np.pi, sites)[:, None, None], rng.uniform(0, 2 * np.pi, sites)[:, None, None]
             H.set_sites(3.0 * api.σ0 - 0.3 * (np.sin(th) * np.cos(ph) * api.σ1 + np.sin(th) * np.sin(ph) * api.σ2 + np.cos(th) * api.σ3))
             Δ.set_sites(-0.1 * api.jσ2)
-        H.set_bonds(-1.0 * api.σ0)
+        if kind != "ssd":
+            H.set_bonds(-1.0 * api.σ0)
     indptr, indices, data = system.bsr_arrays()
     scale = chebyshev.spectral_bound(indptr, data)
     bsr = system.matrix("bsr")
-    real = kind == "potential"
+    real = kind != "texture"
     assert (np.abs(data.imag).max() == 0) == real
     n, moments, temperature = bsr.shape[0], 512, 0.5
     vectors, vec_kind = (8, cheb_ref.VEC_RADEMACHER) if real else (4, cheb_ref.VEC_Z4)
@@ -396,7 +407,7 @@ def test_position_dependent_onsite_terms_full_length_at_full_size(api, hip_libra
     with DeviceSolver(indptr, indices, data) as solver:
         solver.set_lattice_shape(lattice.shape)
         (d, e), perf = _with_env(solver, {}, scale, moments // 2, vectors, seed=4, kind=vec_kind)
-        assert perf["onsite_streamed"] == 1 and perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == 4, perf
+        assert perf["onsite_streamed"] == (2 if kind == "ssd" else 1) and perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == 4, perf
         assert perf["real_arithmetic"] == (1 if real else 0) and perf["dict_blocks"] == 1 and perf["dict_skipped"] == 1
         assert perf["launches"] == 4 * 21 + 2  # one lane group: four chunks of 63 steps, then 3 + 1
         (d1, e1), perf1 = _with_env(solver, {"BODGE_AMD_SWEEP": "0"}, scale, moments // 2, vectors, seed=4, kind=vec_kind)

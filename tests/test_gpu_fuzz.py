@@ -4,6 +4,8 @@ profiles/r02_sweep_experiments.log); here they keep watch.
 
 * fuzz_sweep.py  random lattice shapes / models / step and vector counts / tuning knobs: the
                          lattice-stencil kernels (K7, K7b, K8, forced) against the one-step kernels, 1e-12·4N
+* fuzz_dense.py  random BdG matrices (decoupled chains, flat bands, zero modes, tiny lattices, complex blocks) through the
+                         library's own dense route: eigenvalues vs numpy 1e-11, eigenvectors' residual / orthonormality 1e-9
 * fuzz_api.py    random small systems through the public API against the CPU oracle: free energy
                          (dense, Chebyshev exact and stochastic trace), diagonalize, ldos (single, several
                          sites, band-limited), unit-start recurrences, slab groups, lowest_eigenpairs,
@@ -13,6 +15,7 @@ profiles/r02_sweep_experiments.log); here they keep watch.
 import pytest
 
 import fuzz_api
+import fuzz_dense
 import fuzz_sweep
 
 pytestmark = pytest.mark.gpu
@@ -25,3 +28,7 @@ def test_random_lattices_stencil_kernels_against_one_step_kernels(hip_library, s
 
 def test_random_systems_through_the_api_against_the_oracle(hip_library):
     assert fuzz_api.run(seed=103, n_cases=40) == 0
+
+
+def test_random_matrices_through_the_own_dense_route(hip_library):
+    assert fuzz_dense.run(seed=104, n_cases=60) == 0

@@ -433,6 +433,88 @@ def test_three_step_sweep_with_streamed_onsite_blocks(api, solver_cls, knobs, bl
                 assert np.abs(got[0] - other[0]).max() <= 1e-12 * n and np.abs(got[1] - other[1]).max() <= 1e-12 * n
 
 
+def _ssd_system(api, shape, kind, seed=0):
+    """Every term of the s-wave model scaled by a position-dependent factor: "ssd" = the reference's sine-squared
+    deformation (ref hamiltonian.py:488-531: φ at the site for on-site terms, at the bond midpoint for hopping),
+    "bond_disorder" = random hopping amplitudes and spin splitting on every bond, "ssd_dwave" = ssd on a model with
+    pairing on the bonds (bond blocks no longer diagonal)."""
+    lattice = api.CubicLattice(shape)
+    system = api.Hamiltonian(lattice)
+    rng = np.random.default_rng(seed)
+    sites = np.stack(np.unravel_index(np.arange(lattice.size), shape), axis=-1)
+    pairs = lattice.bond_array(coords=True)
+    φ = api.ssd(system)
+    with system as (H, Δ):
+        if kind in ("ssd", "ssd_dwave"):
+            on_site, on_bond = φ(sites, sites)[:, None, None], φ(pairs[:, 0], pairs[:, 1])[:, None, None]
+            H.set_sites(on_site * (3.0 * api.σ0 - 0.05 * api.σ3))
+            H.set_bonds(-on_bond * api.σ0)
+            if kind == "ssd":
+                Δ.set_sites(-0.1 * on_site * api.jσ2)
+            else:
+                Δ.set_bonds(-0.1 * on_bond * api.dwave()(pairs[:, 0], pairs[:, 1]))
+        else:
+            idx = lattice.bond_array()
+            lo, hi = idx.min(axis=1), idx.max(axis=1)  # the same amplitude both ways
+            t = (0.8 + 0.4 * ((lo * 7919 + hi * 104729) % 1009) / 1009.0)[:, None, None]
+            dt = (0.1 * ((lo * 31 + hi * 17) % 101) / 101.0)[:, None, None]
+            H.set_sites((3.0 + rng.uniform(-0.5, 0.5, lattice.size))[:, None, None] * api.σ0)
+            Δ.set_sites(-0.1 * api.jσ2)
+            H.set_bonds(-t * api.σ0 + dt * api.σ3)
+    return system
+
+
+@pytest.mark.parametrize("shape,kind", [((48, 50, 1), "ssd"), ((33, 61, 1), "bond_disorder"), ((30, 1, 44), "ssd")])
+def test_three_step_sweep_with_streamed_bond_blocks(api, solver_cls, knobs, block_storage, shape, kind):
+    """cheb_sweep3<RealPHMode, 4, ., ., OS = 2>: matrices in which the BOND blocks differ from bond to bond as well - what the
+    reference's `ssd()` makes of a model - as long as they are real and diagonal as 4x4 matrices (spin-diagonal hopping, no
+    bond pairing).  No table: every site streams a 128-byte record (on-site block + its four bond blocks).  Against the oracle
+    and the one-step kernels; complex start vectors (no real arithmetic) and bond pairing must fall back by themselves."""
+    system = _ssd_system(api, shape, kind)
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    n = bsr.shape[0]
+    with solver_cls.from_hamiltonian(system) as dev:
+        for steps, vectors, extra in [(9, 8, {}), (7, 3, {}), (8, 11, {"BODGE_AMD_SWEEP_ZIGZAG": "0"}),
+                                      (6, 2, {"BODGE_AMD_ALTERNATE": "0", "BODGE_AMD_SWEEP_SEGMENTS": "3"}),
+                                      (9, 8, {"BODGE_AMD_SWEEP_GEN": "0"}), (1, 3, {}), (2, 8, {})]:
+            ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 5, range(vectors)))
+            knobs.set("BODGE_AMD_SWEEP", "0")
+            one = dev.dots_random(scale, steps, vectors, seed=5)
+            assert dev.perf()["steps_per_launch"] == 1 and dev.perf()["onsite_streamed"] == 0
+            knobs.set("BODGE_AMD_SWEEP", "1")
+            knobs.update(extra)
+            got = dev.dots_random(scale, steps, vectors, seed=5)
+            perf = dev.perf()
+            again = dev.dots_random(scale, steps, vectors, seed=5)
+            for key in extra:
+                knobs.unset(key)
+            if block_storage == "dictionary":
+                # (the envelope is symmetric: on a small lattice its bond blocks may still number <= 254 and fit a table)
+                assert perf["onsite_streamed"] in ((2,) if kind == "bond_disorder" or shape == (48, 50, 1) else (1, 2)), perf
+                assert perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == 4, perf
+                assert perf["real_arithmetic"] == 1 and perf["launches"] == -(-vectors // 8) * -(-steps // 3)
+            else:
+                assert perf["onsite_streamed"] == 0 and perf["steps_per_launch"] == 1
+            assert np.array_equal(got[0], again[0]) and np.array_equal(got[1], again[1])
+            for other in (ref, one):
+                assert np.abs(got[0] - other[0]).max() <= 1e-12 * n and np.abs(got[1] - other[1]).max() <= 1e-12 * n
+        # complex start vectors: the records exist in real arithmetic only
+        ref = cheb_ref.recurrence_dots(bsr, scale, 12, cheb_ref.random_block(n, 5, range(3), cheb_ref.VEC_Z4))
+        got = dev.dots_random(scale, 6, 3, seed=5, kind=cheb_ref.VEC_Z4)
+        assert dev.perf()["steps_per_launch"] == 1 and dev.perf()["real_arithmetic"] == 0
+        assert np.abs(got[0] - ref[0]).max() <= 1e-12 * n and np.abs(got[1] - ref[1]).max() <= 1e-12 * n
+    # pairing on the bonds: the bond blocks are not diagonal, every block is distinct - one step per launch
+    other = _ssd_system(api, (24, 30, 1), "ssd_dwave")
+    bsr = other.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    ref = cheb_ref.recurrence_dots(bsr, scale, 10, cheb_ref.random_block(bsr.shape[0], 5, range(4)))
+    with solver_cls.from_hamiltonian(other) as dev:
+        got = dev.dots_random(scale, 5, 4, seed=5)
+        assert dev.perf()["steps_per_launch"] == 1 and dev.perf()["onsite_streamed"] == 0
+    assert np.abs(got[0] - ref[0]).max() <= 1e-12 * bsr.shape[0] and np.abs(got[1] - ref[1]).max() <= 1e-12 * bsr.shape[0]
+
+
 def test_streamed_onsite_blocks_need_exactly_hermitian_diagonal_blocks_and_few_bond_blocks(api, solver_cls, knobs, block_storage):
     """The packed on-site record assumes A = A^†, C = B^† to the last bit.  A diagonal block that is
     Hermitian only to 1e-9 (it passes the reference's 1e-6 test, ref hamiltonian.py:121-122), a missing
@@ -473,7 +555,7 @@ def test_streamed_onsite_blocks_need_exactly_hermitian_diagonal_blocks_and_few_b
     assert system.bsr_arrays()[1].size < 5 * n_sites - 2 * (shape[0] + shape[1])
     perf = run(system)
     assert perf["onsite_streamed"] == (1 if block_storage == "dictionary" else 0)
-    # (c) every bond different as well: nothing to put in a table
+    # (c) every bond different as well and not spin-diagonal: nothing to put in a table, nothing to stream per bond
     system = api.Hamiltonian(lattice)
     with system as (H, Δ):
         H.set_sites((3.0 + v) * api.σ0)
@@ -481,7 +563,7 @@ def test_streamed_onsite_blocks_need_exactly_hermitian_diagonal_blocks_and_few_b
         pairs = lattice.bond_array()  # directed pairs: the hopping must be the same both ways
         lo, hi = pairs.min(axis=1), pairs.max(axis=1)
         t = (0.8 + 0.4 * ((lo * 7919 + hi * 104729) % 1009) / 1009.0)[:, None, None]
-        H.set_bonds(-t * api.σ0)
+        H.set_bonds(-t * api.σ0 + 0.1 * t * api.σ1)
     perf = run(system)
     assert perf["onsite_streamed"] == 0 and perf["steps_per_launch"] == 1
 

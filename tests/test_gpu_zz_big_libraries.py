@@ -107,13 +107,15 @@ def test_rccl_single_rank_communicator(hip_library, rccl_library):
     comm.close()
 
 
-@pytest.mark.timeout(900)
+@pytest.mark.timeout(600)
 def test_bench_launch_path_with_two_ranks_on_one_gpu(rccl_library):
-    """`bench.py --gpus 2` exactly as the driver launches it (torch.distributed.run, one rank per
-    process), rehearsed on this one-GPU box with --allow-gloo: both ranks map to GPU 0, RCCL refuses
-    the duplicate device, the ranks agree on that through the rendezvous store and carry the three
-    scalar reductions over the host.  The JSON line must say so (rccl_ranks 0) and carry the fields
-    the multi-GPU record needs (rccl_load_s, host threads per rank, whole-job vector count)."""
+    """`bench.py --gpus 2` with the environment a `torch.distributed.run` launch gives its ranks (RANK, LOCAL_RANK,
+    WORLD_SIZE, MASTER_ADDR, MASTER_PORT - all the script reads; the launcher itself is exercised by the CPU test
+    test_rccl_rendezvous_under_torchrun, and importing torch on a cold box costs minutes this suite does not have),
+    rehearsed on this one-GPU box with --allow-gloo: both ranks map to GPU 0, RCCL refuses the duplicate device,
+    the ranks agree on that through the rendezvous store and carry the three scalar reductions over the host.
+    The JSON line must say so (rccl_ranks 0) and carry the fields the multi-GPU record needs (rccl_load_s,
+    host threads per rank, whole-job vector count)."""
     import json
     import socket
     import subprocess
@@ -123,13 +125,17 @@ def test_bench_launch_path_with_two_ranks_on_one_gpu(rccl_library):
     with socket.socket() as sock:
         sock.bind(("127.0.0.1", 0))
         port = sock.getsockname()[1]
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--allow-gloo", "--lattice", "64,64,1",
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--allow-gloo", "--lattice", "64,64,1",
            "--steps", "12", "--warmup", "3", "--cpu-seconds", "0"]
-    proc = subprocess.run(cmd, cwd=root, capture_output=True, text=True, timeout=800)
-    assert proc.returncode == 0, proc.stderr[-3000:]
-    lines = [line for line in proc.stdout.splitlines() if line.startswith("{")]
-    assert len(lines) == 1, proc.stdout[-2000:]  # rank 0 prints the one line
+    ranks = []
+    for rank in range(2):
+        env = dict(os.environ, RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE="2", LOCAL_WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), TORCHELASTIC_RUN_ID="rehearsal")
+        ranks.append(subprocess.Popen(cmd, cwd=root, env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True))
+    outputs = [proc.communicate(timeout=500) for proc in ranks]
+    assert [proc.returncode for proc in ranks] == [0, 0], [err[-2000:] for _, err in outputs]
+    lines = [line for line in outputs[0][0].splitlines() if line.startswith("{")]
+    assert len(lines) == 1 and not outputs[1][0].strip(), outputs[0][0][-2000:]  # rank 0 prints the one line
     record = json.loads(lines[0])
     assert record["n_gpus"] == 2 and record["steps"] == 12 and record["scaling"] == "weak" and record["value"] > 0
     config = record["config"]

@@ -54,7 +54,7 @@ def test_sweep_kernels_fit_two_waves_per_simd_without_spilling(resources):
                 assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, reverse, row)
             for lanes in (2, 4):
                 for gen in ("false", "true") if reverse == "false" else ("false",):  # (GEN: start block made in registers)
-                    row = _row(resources, f"cheb_sweep3<bdg::{mode}, {lanes}, {reverse}, {gen}, false>")
+                    row = _row(resources, f"cheb_sweep3<bdg::{mode}, {lanes}, {reverse}, {gen}, 0>")
                     assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, reverse, gen, row)
         for lanes in (2, 4):
             row = _row(resources, f"cheb_roll3<bdg::{mode}, {lanes}>")
@@ -69,5 +69,8 @@ def test_streamed_onsite_sweep_keeps_two_waves_per_simd(resources):
     next to ~30 global loads per iteration), and that must not grow unnoticed."""
     for mode, limit in (("RealPHMode", 24), ("ComplexPHMode", 64)):
         for reverse, gen in (("false", "false"), ("true", "false"), ("false", "true")):
-            row = _row(resources, f"cheb_sweep3<bdg::{mode}, 4, {reverse}, {gen}, true>")
+            row = _row(resources, f"cheb_sweep3<bdg::{mode}, 4, {reverse}, {gen}, 1>")
             assert row["scratch"] <= limit and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, reverse, gen, row)
+    for reverse, gen in (("false", "false"), ("true", "false"), ("false", "true")):  # bond blocks streamed as well: no table code
+        row = _row(resources, f"cheb_sweep3<bdg::RealPHMode, 4, {reverse}, {gen}, 2>")
+        assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (reverse, gen, row)

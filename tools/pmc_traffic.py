@@ -26,11 +26,11 @@ import re
 def kernel_key(name: str) -> str:
     # cheb_sweep3<Mode, lanes, REV, GEN, OS>: both marching directions count as one kernel; the
     # start-block-generating first sweep of a run (GEN) reads no t_n and is not the typical launch
-    m = re.search(r"cheb_sweep3<bdg::(\w+), (\d), (?:true|false), (true|false), (true|false)>", name)
+    m = re.search(r"cheb_sweep3<bdg::(\w+), (\d), (?:true|false), (true|false), (\d)>", name)
     if m:
         if m.group(3) == "true":
             return ""
-        return f"cheb_sweep3<{m.group(1)},{m.group(2)}{',onsite-streamed' if m.group(4) == 'true' else ''}>"
+        return f"cheb_sweep3<{m.group(1)},{m.group(2)}{ {'0': '', '1': ',onsite-streamed', '2': ',all-blocks-streamed'}[m.group(4)] }>"
     m = re.search(r"cheb_sweep<bdg::(\w+), (\d), (?:true|false)>", name)
     if m:
         return f"cheb_sweep<{m.group(1)},{m.group(2)}>"
