@@ -194,7 +194,7 @@ def cpu_baseline(system, scale, r_local, kind, seconds):
 
     bsr = system.matrix("bsr")
     logical = os.cpu_count() or 2
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    usable = cpu_share()
     short = max(2.0, seconds / 4)
     real = (not bsr.data.imag.any()) and kind == cheb_ref.VEC_RADEMACHER
     start = cheb_ref.random_block(bsr.shape[0], 0, range(r_local), kind)
@@ -219,7 +219,7 @@ def cpu_baseline(system, scale, r_local, kind, seconds):
     if real:
         extra["scipy_csr_real_1core_steps_per_s"] = cheb_ref.time_recurrence(
             bsr, scale, r_local, seconds=short / 2, kind=kind, fmt="csr", real=True)[0]
-    workers = max(1, min(physical_cores(usable), 128))
+    workers = max(1, min(physical_cores(usable), usable, 128))
     extra["scipy_bsr_whole_host_steps_per_s"] = cheb_ref.time_recurrence_processes(bsr, scale, 1, workers, seconds=short)
     extra["scipy_bsr_whole_host_processes"] = workers
     return {
@@ -230,10 +230,34 @@ def cpu_baseline(system, scale, r_local, kind, seconds):
         "sample": f"{best[1]} timed block-steps of the same {r_local} vectors on the same H: C + OpenMP "
                   f"restatement (oracle/cheb_c.c), {'float64' if real else 'complex128'} arithmetic, best of "
                   f"{sorted(int(t) for t in sweep)} threads = {best[2]} (host: {logical} logical cores, {usable} usable by this "
-                  f"process; threads unpinned, pages of matrix and vectors placed by first touch from the compute "
+                  f"process - affinity mask and cgroup quota; threads unpinned, pages of matrix and vectors placed by first touch from the compute "
                   f"threads; {gbps:.0f} GB/s of algorithmic traffic)",
         "other_cpu_variants": extra,
     }
+
+
+def cpu_share() -> int:
+    """CPUs this process can actually keep busy: its affinity mask, cut by the cgroup's CPU quota
+    (a container on a 256-thread host may own 16 of them; threads beyond the quota are throttled,
+    measured 28 instead of 1065 steps/s with 256 threads on such a box)."""
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    for path in ("/sys/fs/cgroup/cpu.max", "/sys/fs/cgroup/cpu/cpu.cfs_quota_us"):
+        try:
+            with open(path) as fh:
+                fields = fh.read().split()
+            if path.endswith("cpu.max"):
+                if fields[0] != "max":
+                    usable = min(usable, max(1, int(float(fields[0]) / float(fields[1]) + 0.5)))
+            else:
+                quota = int(fields[0])
+                with open("/sys/fs/cgroup/cpu/cpu.cfs_period_us") as fh:
+                    period = int(fh.read())
+                if quota > 0:
+                    usable = min(usable, max(1, int(quota / period + 0.5)))
+            break
+        except (OSError, ValueError, IndexError):
+            continue
+    return usable
 
 
 def physical_cores(usable: int) -> int:
@@ -290,7 +314,7 @@ def main():
         build.build_library()
     if store is not None:
         store.barrier()
-    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    usable = cpu_share()
     t_rccl = time.perf_counter()
     if world > 1:
         # The first RCCL call reads a 573 MB shared object; from cold storage that takes minutes.  Start the
