@@ -288,6 +288,21 @@ struct ComplexMode {
             acc[al].y = fma(m.y, x[al].x, acc[al].y);
         }
     }
+    // compact copy of the diagonal for the stencil kernels (no saving here: four complex entries either way)
+    static constexpr int kDiagSlots = 4;
+    __device__ static inline void pack_diag(double2* d, const double2* blk) {
+        d[0] = blk[0], d[1] = blk[5], d[2] = blk[10], d[3] = blk[15];
+    }
+    __device__ static inline void mac_diag_compact(double2 acc[4], const double2* d, const double2 x[4]) {
+#pragma unroll
+        for (int al = 0; al < 4; ++al) {
+            const double2 m = d[al];
+            acc[al].x = fma(m.x, x[al].x, acc[al].x);
+            acc[al].x = fma(-m.y, x[al].y, acc[al].x);
+            acc[al].y = fma(m.x, x[al].y, acc[al].y);
+            acc[al].y = fma(m.y, x[al].x, acc[al].y);
+        }
+    }
     // dot[0] = <c|c>, dot[1] = Re<n|c> for the lane's single vector
     __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
         dot[0] = fma(c.x, c.x, dot[0]);
@@ -323,6 +338,19 @@ struct RealMode {
     __device__ static inline void rfma_(double2& acc, const double m, const double2 x) {
         acc.x = fma(m, x.x, acc.x);
         acc.y = fma(m, x.y, acc.y);
+    }
+    // compact copy of the diagonal: (m00, m11), (m22, m33) - two 16-byte LDS reads per block instead of four
+    static constexpr int kDiagSlots = 2;
+    __device__ static inline void pack_diag(double2* d, const double2* blk) {
+        d[0] = make_double2(blk[0].x, blk[2].y);
+        d[1] = make_double2(blk[5].x, blk[7].y);
+    }
+    __device__ static inline void mac_diag_compact(double2 acc[4], const double2* d, const double2 x[4]) {
+        const double2 lo = d[0], hi = d[1];
+        rfma_(acc[0], lo.x, x[0]);
+        rfma_(acc[1], lo.y, x[1]);
+        rfma_(acc[2], hi.x, x[2]);
+        rfma_(acc[3], hi.y, x[3]);
     }
     // dot[0], dot[1] for the first vector (.x), dot[2], dot[3] for the second (.y)
     __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
@@ -376,6 +404,15 @@ struct ComplexPHMode {
         cfma(acc[1], blk[3], x[1]);       // A11
         cfms_conj(acc[2], blk[0], x[2]);  // -conj(A00)
         cfms_conj(acc[3], blk[3], x[3]);  // -conj(A11)
+    }
+    // compact copy of the diagonal (A00, A11): the two entries mac_diag reads, side by side
+    static constexpr int kDiagSlots = 2;
+    __device__ static inline void pack_diag(double2* d, const double2* blk) { d[0] = blk[0], d[1] = blk[3]; }
+    __device__ static inline void mac_diag_compact(double2 acc[4], const double2* d, const double2 x[4]) {
+        cfma(acc[0], d[0], x[0]);
+        cfma(acc[1], d[1], x[1]);
+        cfms_conj(acc[2], d[0], x[2]);
+        cfms_conj(acc[3], d[1], x[3]);
     }
     // Streamed on-site blocks (sweep.hpp, cheb_sweep3 with OS): a diagonal block of H is Hermitian as
     // well as particle-hole symmetric, A = A^†, C = B^†, so 12 doubles describe it:
@@ -437,6 +474,16 @@ struct RealPHMode {
         rfma(acc[1], blk[1].y, x[1]);   // A11
         rfma(acc[2], -blk[0].x, x[2]);  // -A00
         rfma(acc[3], -blk[1].y, x[3]);  // -A11
+    }
+    // the same from a compact copy of the diagonal, d = (A00, A11): one 16-byte LDS read per block instead of two
+    static constexpr int kDiagSlots = 1;
+    __device__ static inline void pack_diag(double2* d, const double2* blk) { d[0] = make_double2(blk[0].x, blk[1].y); }
+    __device__ static inline void mac_diag_compact(double2 acc[4], const double2* d, const double2 x[4]) {
+        const double2 a = d[0];
+        rfma(acc[0], a.x, x[0]);
+        rfma(acc[1], a.y, x[1]);
+        rfma(acc[2], -a.x, x[2]);
+        rfma(acc[3], -a.y, x[3]);
     }
     // Streamed on-site blocks (see ComplexPHMode): A symmetric, C = B^T, 8 doubles
     //   slot 0 = (A00, A01), slot 1 = (A11, 0), slot 2 = (B00, B01), slot 3 = (B10, B11)   (64 B instead of 96)

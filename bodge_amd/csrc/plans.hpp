@@ -607,6 +607,8 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
     if (table > table_limit(sys)) return fail(BDG_EINVAL, "block table too large for the sweep kernel");
     size_t rows = (size_t)bdg::kSweepWaves * depth * bdg::kWave * 4 * sizeof(double2);
+    if (depth == 3)  // compact diagonals behind the table (cheb_sweep3)
+        rows += (size_t)sys->n_unique * (mode.id == 0 ? 4 : mode.id == 3 ? 1 : 2) * sizeof(double2);
     if (streamed)  // ring of three planes of per-site records per wave (stride 9: on-site + four bond blocks)
         rows += (size_t)bdg::kSweepWaves * 3 * (bdg::kWave / lanes) *
                 (bonds ? 9 : mode.real ? RealPHMode::kOnsiteStride : ComplexPHMode::kOnsiteStride) * sizeof(double2);

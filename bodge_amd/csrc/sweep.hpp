@@ -429,6 +429,9 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
 //     step 2 on plane k-1   from level 1 [k-2, k-1, k]           -> level 2   (k was just made)
 //     step 3 on plane k-2   from level 2 [k-3, k-2, k-1]         -> level 3
 // a launch may make fewer (steps = 1 or 2: the tail of a run whose length is not a multiple of 3).
+#ifndef BDG_COMPACT_DIAG
+#define BDG_COMPACT_DIAG 1  // (0: A/B builds that read diagonal blocks from the full table entries)
+#endif
 constexpr int kSweep3Owned = kSweepSlots - 6;  // 10 owned positions per wave window (4 lanes per site)
 constexpr int sweep3_owned(int rl) { return kWave / rl - 6; }
 
@@ -489,10 +492,17 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
     const double2* table = static_cast<const double2*>(a.dict_table);
     for (int e = threadIdx.x; e < a.n_unique * SPB; e += kBlockThreads)
         lds[(e / SPB) * STRIDE + (e % SPB)] = table[e];
-    double2* row_0 = lds + a.n_unique * STRIDE + wave * (3 * kWave * 4 + RING);
+    // compact copies of the block diagonals behind the table: a block flagged diagonal (plain hopping: four of the
+    // five blocks of a row in the s-wave models) then costs Mode::kDiagSlots 16-byte LDS reads instead of mac_diag's
+    // (1 instead of 2 in real particle-hole arithmetic: a tenth of the kernel's LDS operations)
+    constexpr int DSL = Mode::kDiagSlots;
+    double2* diag = lds + a.n_unique * STRIDE;
+    double2* row_0 = diag + a.n_unique * DSL + wave * (3 * kWave * 4 + RING);
     double2* row_1 = row_0 + kWave * 4;
     double2* row_2 = row_1 + kWave * 4;
     [[maybe_unused]] double2* os_ring = row_2 + kWave * 4;
+    __syncthreads();
+    for (int id = threadIdx.x; id < a.n_unique; id += kBlockThreads) Mode::pack_diag(diag + id * DSL, lds + id * STRIDE);
     __syncthreads();
 
     const int n_units = a.n_cols * a.n_segs;
@@ -586,7 +596,11 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
         auto mac = [&](uint2 w, int slot, const double2 x[4], double2 acc[4]) {
             const unsigned id = id_of(w, slot);
             if (id == kNoBlock) return;
+#if BDG_COMPACT_DIAG
+            if ((w.y >> (8 + slot)) & 1u) Mode::mac_diag_compact(acc, diag + id * DSL, x);
+#else
             if ((w.y >> (8 + slot)) & 1u) Mode::mac_diag(acc, lds + id * STRIDE, x);
+#endif
             else Mode::mac_row(acc, lds + id * STRIDE, x);
         };
         auto own_of = [&](const double2* row, double2 out[4]) {
