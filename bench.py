@@ -14,8 +14,14 @@ generation, K launches, the dot reductions, and for N > 1 the RCCL all-reduce
 of the moment vector - with the matrix already resident in HBM.
 
 `value` = (N x vectors-per-GPU x K) / wall seconds = vector-steps per second.
-`roofline.achieved` = algorithmic bytes of one launch / mean launch time from
-HIP events on the library's stream.  `cpu_baseline` times the C + OpenMP
+`roofline.achieved` = algorithmic bytes of the launches in the timed call / their
+time from HIP events on the library's stream.  The bytes are what each launch has
+to move (`bdg_perf.bytes_moved`): a full launch reads two buffers and writes two
+(`bytes_full_launch`), the first sweep of a run reads none (t_0 is generated in
+registers, t_{-1} = 0) and the last launch stores none (nothing reads the vectors
+of the last step; the call returns moments), so short runs average less per launch
+(`bytes_per_launch`).  `roofline.effective_GBps` prices the same time at a full
+launch's bytes per step.  `cpu_baseline` times the C + OpenMP
 restatement (oracle/cheb_c.c) on this host on a bounded sample, with the
 single-core scipy.sparse restatement beside it.
 
@@ -419,9 +425,10 @@ def main():
             "launch_ms": launch,
             "steps_per_launch": pf["steps_per_launch"],
             "vectors_per_launch": pf["vectors_per_launch"],
-            "bytes_per_launch": pf["bytes_per_launch"],
-            "achieved_GBps": pf["bytes_per_launch"] / (launch * 1e-3) / 1e9,
-            "frac": pf["bytes_per_launch"] / (launch * 1e-3) / 1e9 / HBM_PEAK_GBS,
+            "bytes_per_launch": pf["bytes_moved"] / max(1, pf["launches"]),
+            "bytes_full_launch": pf["bytes_per_launch"],
+            "achieved_GBps": pf["bytes_moved"] / (pf["kernel_ms"] * 1e-3) / 1e9,
+            "frac": pf["bytes_moved"] / (pf["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS,
             "traffic": measured_traffic(kernel_label(pf), lattice_shape, vectors),
         }
 
@@ -485,7 +492,10 @@ def main():
 
     value = total_vectors * args.steps / elapsed
     launch_ms = perf["kernel_ms"] / max(1, perf["launches"])
-    achieved = perf["bytes_per_launch"] / (launch_ms * 1e-3) / 1e9
+    # algorithmic bytes of the launches inside the event window / their time.  bytes_moved is what the launches of
+    # this call have to move: the first sweep reads no vectors (t_0 is generated, t_{-1} = 0) and the last launch
+    # stores none (nothing reads them), so the average launch is lighter than a full one (bytes_full_launch)
+    achieved = perf["bytes_moved"] / (perf["kernel_ms"] * 1e-3) / 1e9
     free_energy = chebyshev.free_energy_series(mu / total_vectors, scale, args.temperature)
     kernel_name = kernel_label(perf)
     model_label = {"swave": "s-wave+Zeeman", "dwave": "d-wave"}[args.model]
@@ -536,7 +546,13 @@ def main():
             "vectors_per_launch": perf["vectors_per_launch"],
             "x_neighbours_in_registers": bool(perf["steps_per_launch"] >= 2 or perf["rolling"]),
             "launches": perf["launches"],
-            "bytes_per_launch": perf["bytes_per_launch"],
+            "bytes_per_launch": perf["bytes_moved"] / max(1, perf["launches"]),
+            "bytes_full_launch": perf["bytes_per_launch"],
+            # the same time priced at the algorithmic bytes of a full launch per `steps_per_launch` steps (what the
+            # steps would cost without the savings at the two ends of a run): vector-steps in the event window x
+            # bytes per vector-step / kernel time
+            "effective_GBps": perf["bytes_per_launch"] / max(1, perf["steps_per_launch"]) * args.steps
+                              * (r_local / perf["vectors_per_launch"]) / (perf["kernel_ms"] * 1e-3) / 1e9,
             "grid": perf["grid"],
             "lds_bytes": perf["lds_bytes"],
             "strip_rows": perf["strip_rows"],

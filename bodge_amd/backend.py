@@ -47,6 +47,7 @@ class Perf(C.Structure):
         ("dict_skipped", C.c_int32),
         ("onsite_streamed", C.c_int32),
         ("reserved", C.c_int32),
+        ("bytes_moved", C.c_double),
     ]
 
 

@@ -235,6 +235,9 @@ struct StepArgs {
     // first tile of the launch when only a band of block rows is swept (natural order only):
     // unit start vectors spread by at most the matrix bandwidth per step, the rest is still zero
     int tile_base;
+    // 1 = t_{n+1} is not stored: the last step of a run, whose vectors nothing reads any more (the
+    // call returns the dot products only).  The step is computed and dotted as any other.
+    int discard;
 };
 
 // Arithmetic modes.  A lane's 16-byte payload is either one complex number of
@@ -652,7 +655,8 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step(StepArgs a) {
                 double2 nx;
                 nx.x = fma(ls.c.x, acc[al].x, -(ls.s.x * p.x));
                 nx.y = fma(ls.c.y, acc[al].y, -(ls.s.y * p.y));
-                if (a.stream_vectors & 2) store_stream(a.prev + own, nx);
+                if (a.discard) {
+                } else if (a.stream_vectors & 2) store_stream(a.prev + own, nx);
                 else a.prev[own] = nx;
                 Mode::dots(dot, c, nx);
             }
@@ -810,7 +814,8 @@ __global__ __launch_bounds__(kBlockThreads) void cheb_step_pipelined(StepArgs a)
                 double2 nx;
                 nx.x = fma(ls.c.x, acc[al].x, -(ls.s.x * p.x));
                 nx.y = fma(ls.c.y, acc[al].y, -(ls.s.y * p.y));
-                if (a.stream_vectors & 2) store_stream(a.prev + own, nx);
+                if (a.discard) {
+                } else if (a.stream_vectors & 2) store_stream(a.prev + own, nx);
                 else a.prev[own] = nx;
                 Mode::dots(dot, c, nx);
             }
@@ -978,7 +983,8 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
                 p[al] = nx;
                 Mode::dots(dot, share[SHARE_SLOT(lane, al)], nx);
             }
-            if (a.stream_vectors & 2) {
+            if (a.discard) {
+            } else if (a.stream_vectors & 2) {
 #pragma unroll
                 for (int al = 0; al < 4; ++al) store_stream(a.prev + vslot(al, (size_t)i, r, a.ncols, RL), p[al]);
             } else {

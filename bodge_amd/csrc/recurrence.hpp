@@ -44,6 +44,12 @@ struct Batch {
     const double2 *ext_lo = nullptr, *ext_hi = nullptr;
     int64_t ext_lo_site0 = 0, ext_lo_ld = 0, ext_hi_site0 = 0, ext_hi_ld = 0;
     int launch_grid = 0;   // workgroups whose dot partials one recurrence step leaves behind
+    // The last launch of a run does not store its vectors: the calls built on Batch return dot products only,
+    // and nothing reads t_{n_steps} (BODGE_AMD_KEEP_LAST=1 stores them all the same, for A/B runs).
+    bool discard_last = true;
+    double bytes_moved = 0.0;  // algorithmic bytes of the launches made so far (perf.bytes_moved)
+    // one buffer of the batch: what a launch reads for t_n (or t_{n-1}) or writes for one new level
+    double vector_bytes() const { return 4.0 * rl * sizeof(double2) * (double)sys->nb; }
     int n_launches = 0;
 
     int begin(bdg_system* system, double scale_in, int steps, int active, const StartSpec& start,
@@ -124,6 +130,7 @@ struct Batch {
         }
         launch_grid = sweep ? splan.grid : roll ? rplan.grid : plan.grid;
         n_launches = 0;
+        bytes_moved = 0.0;
 
         vec_count = (size_t)4 * sys->ncols * rl;  // 16-byte lane payloads
         // t_n and t_{n-1} together beyond the 256 MB Infinity Cache: the write of t_{n+1} and the
@@ -134,6 +141,8 @@ struct Batch {
         if (const char* env = knob::raw("BODGE_AMD_STREAM_VECTORS")) args.stream_vectors = std::atoi(env);
         alternate = true;
         if (const char* env = knob::raw("BODGE_AMD_ALTERNATE")) alternate = std::atoi(env) != 0;
+        discard_last = true;
+        if (const char* env = knob::raw("BODGE_AMD_KEEP_LAST")) discard_last = std::atoi(env) == 0;
         if (int rc = sys->vec_a.reserve(vec_count)) return rc;
         if (int rc = sys->vec_b.reserve(vec_count)) return rc;
         if (sweep) {
@@ -346,6 +355,8 @@ struct Batch {
         args.cur = cur;
         args.prev = prev;
         args.coef = (n == 0 ? 1.0 : 2.0) / scale;
+        args.discard = discard_last && n == n_steps - 1;
+        bytes_moved += algorithmic_bytes(sys, rv, mode, plan.dictionary) - (args.discard ? vector_bytes() : 0.0);
         double* slot = sys->partial.ptr + (size_t)in_chunk * per_step;
         bdg::StepArgs part = args;
         part.tile_order = sys->tiles_interior.ptr;
@@ -409,6 +420,9 @@ struct Batch {
         args.cur = cur;
         args.prev = prev;
         args.coef = (n == 0 ? 1.0 : 2.0) / scale;
+        args.discard = discard_last && n == n_steps - 1;
+        bytes_moved += (roll ? roll_bytes(sys, mode, rl) : algorithmic_bytes(sys, rv, mode, plan.dictionary)) -
+                       (args.discard ? vector_bytes() : 0.0);
         args.partial = sys->partial.ptr + (size_t)in_chunk * per_step;
         args.reverse = alternate ? (n & 1) : 0;
         args.tile_base = 0;
@@ -431,6 +445,7 @@ struct Batch {
             ra.partial = args.partial;
             ra.reverse = args.reverse;
             ra.stream = args.stream_vectors;
+            ra.discard = args.discard;
             ra.lo_buf = ra.hi_buf = nullptr;
             if (sys->stencil_lo_base >= 0) {
                 ra.lo_buf = ext_lo ? ext_lo : cur;
@@ -483,12 +498,17 @@ struct Batch {
         a.coef2 = 2.0 / scale;
         a.two = now >= 2 ? 1 : 0;
         a.steps = now;
+        a.discard = discard_last && n + now == n_steps;
         a.partial1 = sys->partial.ptr + (size_t)in_chunk * per_step;
         a.partial2 = a.partial1 + per_step;
         a.partial3 = a.partial2 + per_step;
         const SweepKernel kernel = n == 0 && gen_start ? splan.kernel_gen
                                    : alternate && (n_launches & 1) ? splan.kernel_reverse : splan.kernel;
         if (n == 0 && gen_start) a.cur = nullptr;  // (never read)
+        // sweep_bytes counts two buffers read and two written: t_{-1} = 0 is never read, a generated t_0 neither,
+        // a lone step makes one new level, the last sweep of a run stores nothing
+        bytes_moved += sweep_bytes(sys, mode, rl) -
+                       vector_bytes() * ((n == 0 ? 1 : 0) + (n == 0 && gen_start ? 1 : 0) + (a.discard ? 2 : now == 1 ? 1 : 0));
         kernel<<<splan.grid, bdg::kSweepThreads, splan.lds_bytes, st>>>(a);
         ++n_launches;
         double2* old_cur = cur;
@@ -556,6 +576,7 @@ struct Batch {
         if (first_batch) p = bdg_perf{};
         p.kernel_ms += kernel_ms;
         p.launches += sweep ? n_launches : n_steps;
+        p.bytes_moved += bytes_moved;
         p.vector_steps += (int64_t)n_steps * n_active;
         p.bytes_per_launch = sweep  ? sweep_bytes(sys, mode, rl)
                              : roll ? roll_bytes(sys, mode, rl)

@@ -80,6 +80,9 @@ struct SweepArgs {
     uint64_t gen_seed, gen_first_id;
     int gen_kind;            // BDG_VEC_* (real modes: Rademacher)
     int gen_active;          // vectors of the launch that exist (the others are zero)
+    // 1 = nothing is stored: the last sweep of a run, whose vectors nothing reads any more (the call returns the
+    // dot products only).  Every step is computed and dotted as in any other launch.
+    int discard;
 };
 
 // Stencil table + eligibility test, on the device from the uploaded arrays.  `words` is the
@@ -353,7 +356,8 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
                     const size_t site = (size_t)act(k) * a.plane + p;
 #pragma unroll
                     for (int al = 0; al < 4; ++al) {
-                        if (nt_store) store_stream(a.out1 + vslot(al, site, r, nb, RL), new1[al]);
+                        if (a.discard) {
+                        } else if (nt_store) store_stream(a.out1 + vslot(al, site, r, nb, RL), new1[al]);
                         else a.out1[vslot(al, site, r, nb, RL)] = new1[al];
                         Mode::dots(dot1, cn_0[al], new1[al]);
                     }
@@ -374,7 +378,8 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
                         double2 nx;
                         nx.x = fma(a.coef2, acc[al].x, -cn_m[al].x);
                         nx.y = fma(a.coef2, acc[al].y, -cn_m[al].y);
-                        if (nt_store) store_stream(a.out2 + vslot(al, site, r, nb, RL), nx);
+                        if (a.discard) {
+                        } else if (nt_store) store_stream(a.out2 + vslot(al, site, r, nb, RL), nx);
                         else a.out2[vslot(al, site, r, nb, RL)] = nx;
                         Mode::dots(dot2, c1_0[al], nx);
                     }
@@ -556,6 +561,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
             }
         };
         auto store_plane = [&](double2* buf, int k, const double2 v[4]) {
+            if (a.discard) return;  // (uniform: the last sweep of a run)
             const size_t site = (size_t)act(k) * a.plane + p;
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
@@ -850,6 +856,7 @@ struct RollArgs {
     int n_segs;
     int stream;              // non-temporal hints: bit 0 t_{n-1} loads, bit 1 stores
     int reverse;             // 1 = march every segment from its far end (launches alternate)
+    int discard;             // 1 = t_{n+1} is not stored (last step of a run: only its dot products are wanted)
     // Row slabs (a stack of whole x-planes of a larger lattice, one handle per slab): the vector buffers
     // have `ld` block rows per component plane (own rows + halo rows), and t_n of the plane below plane 0 /
     // above plane lx-1 is read where the neighbouring slab keeps it - `lo_buf` / `hi_buf` point into that
@@ -1039,7 +1046,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
                     double2 nx;
                     nx.x = fma(a.coef, acc[al].x, -pv[al].x);
                     nx.y = fma(a.coef, acc[al].y, -pv[al].y);
-                    if (nt_store) store_stream(a.prev + vslot(al, site, r, nb, RL), nx);
+                    if (a.discard) {
+                    } else if (nt_store) store_stream(a.prev + vslot(al, site, r, nb, RL), nx);
                     else a.prev[vslot(al, site, r, nb, RL)] = nx;
                     Mode::dots(dot, cn_0[al], nx);
                 }

@@ -69,6 +69,11 @@ typedef struct bdg_perf {
                                 (dict_blocks then counts the distinct bond blocks); 2 = the bond blocks are
                                 streamed as well (real matrices with spin-diagonal hopping: no table)      */
     int32_t reserved;      /* keeps the struct a multiple of 8 bytes */
+    double bytes_moved;    /* algorithmic HBM bytes of all `launches` together.  Less than launches x
+                              bytes_per_launch: the first sweep of a run reads no t_{-1} (and no t_0 when it
+                              makes the random start block itself), and the last launch of a run stores no
+                              vectors - nothing reads them, the call returns dot products (BODGE_AMD_KEEP_LAST=1
+                              stores them all the same).  Divide by kernel_ms for the achieved rate. */
 } bdg_perf;
 
 const char* bdg_last_error(void);

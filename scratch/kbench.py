@@ -33,7 +33,7 @@ for rnd in range(rounds + 1):
             solver.dots_random(scale, steps, vectors, seed=rnd, kind=kind)
             p = solver.perf()
         if rnd:
-            results[name].append((p["kernel_ms"] / p["launches"], p["bytes_per_launch"], p))
+            results[name].append((p["kernel_ms"] / p["launches"], p["bytes_moved"] / p["launches"], p))
 for name, _ in variants:
     ms = np.array([r[0] for r in results[name]]); b = results[name][0][1]; p = results[name][0][2]
     print(f"{name:28s} median {np.median(ms):.4f} ms  min {ms.min():.4f}  -> {b/np.median(ms)/1e6:7.1f} GB/s (best {b/ms.min()/1e6:7.1f})"

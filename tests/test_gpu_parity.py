@@ -614,6 +614,41 @@ def test_batches_of_one_call_enqueued_back_to_back_change_no_bit(api, solver_cls
     assert np.abs(queued[0][0] - ref[0]).max() <= 1e-12 * bsr.shape[0] and np.abs(queued[0][1] - ref[1]).max() <= 1e-12 * bsr.shape[0]
 
 
+@pytest.mark.parametrize("shape,model,knob_set,steps", [
+    ((64, 48, 1), "swave", {"BODGE_AMD_SWEEP": "1"}, 7),                                 # K7b: 3 + 3 + 1
+    ((64, 48, 1), "swave", {"BODGE_AMD_SWEEP": "1"}, 6),                                 # K7b: 3 + 3
+    ((64, 48, 1), "swave", {"BODGE_AMD_SWEEP": "1", "BODGE_AMD_SWEEP_STEPS": "2"}, 5),   # K7: 2 + 2 + 1
+    ((64, 48, 1), "swave", {"BODGE_AMD_SWEEP": "0"}, 5),                                 # K1 dictionary
+    ((64, 48, 1), "swave", {"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0"}, 5),          # K1 streamed
+    ((12, 14, 16), "dwave", {"BODGE_AMD_SWEEP": "1"}, 5),                                # K8
+])
+def test_last_launch_of_a_run_stores_no_vectors_and_changes_no_bit(api, solver_cls, knobs, shape, model, knob_set, steps):
+    """Nothing reads the vectors of the last step of a run (the calls return dot products), so the last
+    launch does not store them.  Same bits as with the stores (BODGE_AMD_KEEP_LAST=1), also in a second
+    call on the same handle (whose buffers the first one left half written), and the perf record counts
+    the bytes that were not moved."""
+    system = _sweep_system(api, shape, model)
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    for key, value in knob_set.items():
+        knobs.set(key, value)
+    with solver_cls.from_hamiltonian(system) as dev:
+        dev.set_lattice_shape(shape)
+        lean = dev.dots_random(scale, steps, 8, seed=5)
+        lean_perf = dev.perf()
+        again = dev.dots_random(scale, steps, 8, seed=5)
+        knobs.set("BODGE_AMD_KEEP_LAST", "1")
+        kept = dev.dots_random(scale, steps, 8, seed=5)
+        kept_perf = dev.perf()
+    for a, b, c in zip(lean, again, kept):
+        assert np.array_equal(a, b) and np.array_equal(a, c)
+    assert lean_perf["launches"] == kept_perf["launches"]
+    assert 0 < lean_perf["bytes_moved"] < kept_perf["bytes_moved"] <= kept_perf["launches"] * kept_perf["bytes_per_launch"]
+    n = bsr.shape[0]
+    ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 5, range(8), cheb_ref.VEC_RADEMACHER))
+    assert np.abs(lean[0] - ref[0]).max() <= 1e-12 * n and np.abs(lean[1] - ref[1]).max() <= 1e-12 * n
+
+
 @pytest.mark.parametrize("name,n_vectors,kind", [
     ("random357", 6, cheb_ref.VEC_Z4),          # complex blocks, periodic
     ("complex235", 3, cheb_ref.VEC_RADEMACHER),  # complex H with real start vectors
