@@ -33,9 +33,10 @@ for rnd in range(rounds + 1):
             solver.dots_random(scale, steps, vectors, seed=rnd, kind=kind)
             p = solver.perf()
         if rnd:
-            results[name].append((p["kernel_ms"] / p["launches"], p["bytes_moved"] / p["launches"], p))
+            results[name].append((p["kernel_ms"] / p["launches"], p["bytes_moved"] / p["launches"], p, p["vector_steps"] / p["kernel_ms"]))
 for name, _ in variants:
     ms = np.array([r[0] for r in results[name]]); b = results[name][0][1]; p = results[name][0][2]
-    print(f"{name:28s} median {np.median(ms):.4f} ms  min {ms.min():.4f}  -> {b/np.median(ms)/1e6:7.1f} GB/s (best {b/ms.min()/1e6:7.1f})"
+    rate = np.median([r[3] for r in results[name]])
+    print(f"{name:28s} {rate:7.2f} k vsteps/s (kernel time)  launches {p['launches']} rolling {p['rolling']}  median {np.median(ms):.4f} ms  min {ms.min():.4f}  -> {b/np.median(ms)/1e6:7.1f} GB/s (best {b/ms.min()/1e6:7.1f})"
           f"  grid {p['grid']} lds {p['lds_bytes']} rl {p['lanes_per_row']} real {p['real_arithmetic']} pipe {p['pipelined']}"
           f" steps/launch {p['steps_per_launch']} onsite {p['onsite_streamed']} -> {vectors * p['steps_per_launch'] / np.median(ms) :.1f} k vector-steps/s")
