@@ -486,6 +486,14 @@ struct SweepPlan {
     int grid = 0;
     size_t lds_bytes = 0;
     bdg::SweepArgs args{};
+    int waves = 0;  // resident waves of a launch (what a launch over a band of planes cuts its segments for)
+    int whole_segs = 1;  // segments of a launch over the whole lattice
+    // segments of a launch over planes [lo, hi): as for the whole lattice, for that many planes
+    int segments_for(int planes) const {
+        if (planes >= args.lx) return whole_segs;
+        // (a band of few planes: short segments - a launch that leaves waves idle is as long as one wave's march)
+        return std::max(1, std::min(choose_segments(args.n_cols, planes, waves, 2 * depth, 2), planes / 2));
+    }
 };
 
 // Smallest lattices the stencil kernels are chosen for by default.  Below, the x-segments get so
@@ -570,12 +578,13 @@ int ensure_stencil(bdg_system* sys, int* kind) {
     return BDG_OK;
 }
 
-// Should this batch run a stencil form, and which (see ensure_stencil)?  Whole square matrix,
-// random start vectors (unit vectors use the band-limited one-step sweeps), no per-column scalars.
-int sweep_wanted(bdg_system* sys, bool random_start, bool col_scalars, int* kind) {
+// Should this batch run a stencil form, and which (see ensure_stencil)?  Whole square matrix (or a slab of a
+// same-process group), no per-column scalars; unit start vectors when their band of planes gets wide
+// (unit_run_wants_stencil).
+int sweep_wanted(bdg_system* sys, bool col_scalars, int* kind) {
     *kind = 0;
     const char* env = knob::raw("BODGE_AMD_SWEEP");
-    if ((env && env[0] == '0') || !random_start || col_scalars) return BDG_OK;
+    if ((env && env[0] == '0') || col_scalars) return BDG_OK;
     // Row slabs: members of a same-process group may run the 3-D rolling kernel, which reads the neighbouring
     // slabs' boundary planes where they are; slabs exchanging halos through RCCL keep the one-step kernels
     // (their exchange is overlapped with the rows that do not need it, Batch::step_overlapped).
@@ -643,6 +652,10 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     int n_segs = choose_segments(a.n_cols, a.lx, waves, 2 * depth, 8);
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
     a.n_segs = std::max(1, std::min(n_segs, a.lx / 8));
+    a.x_lo = 0;
+    a.x_hi = a.lx;
+    plan->waves = waves;
+    plan->whole_segs = a.n_segs;
     a.zigzag = 1;
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_ZIGZAG")) a.zigzag = atoi(env) != 0;
     a.wrap_p = sys->stencil_wrap_p ? 1 : 0;
@@ -686,15 +699,33 @@ int sweep_depth_for(const bdg_system* sys, int lanes) {
 // slots with 2 lanes, 10 of 16 with 4: less recomputed halo per useful site) at the price of
 // shorter x-segments.  Measured on 1000x1000, 8 real vectors: 2 lanes 106.6 k vector-steps/s,
 // 4 lanes 99.9 k (profiles/r02_sweep_experiments.log).
-int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane) {
+int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane, bool unit_start = false) {
     if (sys->onsite_streamed) return 4;  // 16 site slots per wave: the ring of on-site records fits beside the rows
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_LANES")) {
         const int forced = atoi(env);
         if (forced == 1 || forced == 2 || forced == 4) return forced;
     }
-    (void)n_active;
-    (void)per_lane;
+    // unit start vectors run inside a band of planes for most of their steps: launches of few planes, bound by the
+    // length of a wave's march and not by bytes - all the vectors of a lane group in one launch, then
+    if (unit_start && n_active > 2 * per_lane) return 4;
     return sys->nb >= kSweepTwoLaneSites ? 2 : 4;  // small lattices: more work per launch matters more
+}
+
+// Unit start vectors (LDOS) spread by one plane per step.  Inside a narrow band of planes a stencil launch is as long
+// as a wave's march over its segment (a few tens of microseconds), where a one-step launch over the band's rows
+// takes a few: the stencil kernels pay when the band ends up wide.  Rule (scratch/r3_unit_band.py): the band of the
+// last step covers at least 30 % of the planes.
+bool unit_run_wants_stencil(const bdg_system* sys, const int64_t* rows, int count, int n_steps) {
+    const char* env = knob::raw("BODGE_AMD_SWEEP");
+    if (env && env[0] == '1') return true;
+    if (sys->ncols != sys->nb || sys->group_rows != 0 || sys->shape[0] <= 0) return true;  // (slabs: no band either way)
+    const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
+    int64_t lo = sys->shape[0], hi = 0;
+    for (int r = 0; r < count; ++r) {
+        lo = std::min<int64_t>(lo, (rows[r] >> 2) / plane);
+        hi = std::max<int64_t>(hi, (rows[r] >> 2) / plane);
+    }
+    return (double)(hi - lo + 1 + 2 * (int64_t)n_steps) >= 0.3 * sys->shape[0];
 }
 
 // ---- 3-D: one step per launch with the x-neighbours in registers (cheb_roll3)
@@ -735,6 +766,12 @@ struct RollPlan {
     int grid = 0;
     size_t lds_bytes = 0;
     bdg::RollArgs args{};
+    int waves = 0;
+    int whole_segs = 1;
+    int segments_for(int planes) const {
+        if (planes >= args.lx) return whole_segs;
+        return std::max(1, std::min(choose_segments(args.n_cols, planes, waves, 2, 4), planes / 4));
+    }
 };
 
 int make_roll_plan(bdg_system* sys, const ModeInfo& mode, int lanes, RollPlan* plan) {
@@ -765,6 +802,10 @@ int make_roll_plan(bdg_system* sys, const ModeInfo& mode, int lanes, RollPlan* p
     int n_segs = choose_segments(a.n_cols, a.lx, waves, 2, 4);
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
     a.n_segs = std::max(1, std::min(n_segs, a.lx / 4));
+    a.x_lo = 0;
+    a.x_hi = a.lx;
+    plan->waves = waves;
+    plan->whole_segs = a.n_segs;
     const int64_t units = (int64_t)a.n_cols * a.n_segs;
     const int grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus,
                                             (units + bdg::kWavesPerBlock - 1) / bdg::kWavesPerBlock);
@@ -785,6 +826,7 @@ struct StartSpec {
     uint64_t seed = 0, first_id = 0;
     int vec_kind = 0;
     const int64_t* rows = nullptr;  // host
+    int stencil = -1;  // unit starts: 1 / 0 = the call has decided for / against the stencil kernels, -1 = each batch decides
 };
 
 void dots_to_moments(const double* d, const double* e, int n_steps, int n_vectors, double* mu) {

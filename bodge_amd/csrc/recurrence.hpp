@@ -20,6 +20,9 @@ struct Batch {
     // unit start vectors: block rows that can be non-zero after n steps are within
     // (n + 1) * bandwidth of [band_lo, band_hi]; -1 = no band (random vectors, slabs, strip order)
     int64_t band_lo = -1, band_hi = -1;
+    // the same for the lattice-stencil kernels: planes of the start sites (-1 = none); a launch that ends with
+    // t_m advances planes [plane_lo - m, plane_hi + m] only
+    int plane_lo = -1, plane_hi = -1;
     ModeInfo mode{};
     int rl = 0, rv = 0, n_active = 0, n_steps = 0, chunk = 1, strip_rows = 0;
     size_t width = 0, per_step = 0, vec_count = 0;
@@ -79,14 +82,17 @@ struct Batch {
         sweep = roll = false;
         int stencil_kind = 0;
         if (sys->lanes_override == 0 && rl == 4)
-            if (int rc = sweep_wanted(sys, start.kind == StartKind::Random, col_scalars, &stencil_kind)) return rc;
+            if (int rc = sweep_wanted(sys, col_scalars, &stencil_kind)) return rc;
         // (the stencil kernels keep the whole block table in LDS; a matrix with many distinct blocks in a
         // wide arithmetic mode can exceed that: it takes the one-step kernels, which then stream its blocks)
         if ((size_t)sys->n_unique * mode.stride * sizeof(double2) > table_limit(sys)) stencil_kind = 0;
         if (sys->onsite_streamed && !mode.ph) stencil_kind = 0;  // (packed on-site records assume the Nambu form)
         if (sys->bonds_streamed && !mode.real) stencil_kind = 0;  // (bond records exist in real arithmetic only: Z4 vectors take the one-step kernels)
+        if (stencil_kind != 0 && start.kind == StartKind::Unit &&
+            !(start.stencil >= 0 ? start.stencil != 0 : unit_run_wants_stencil(sys, start.rows, n_active, n_steps)))
+            stencil_kind = 0;
         if (stencil_kind == 1) {
-            const int lanes = sweep_lanes_for(sys, n_active, per_lane);
+            const int lanes = sweep_lanes_for(sys, n_active, per_lane, start.kind == StartKind::Unit);
             if (n_active <= lanes * per_lane) {
                 sweep = true;
                 rl = lanes;
@@ -212,6 +218,13 @@ struct Batch {
                 }
             }
             bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, (int64_t)vec_count);
+            if (sweep) {
+                // the sweeps rotate four buffers and, inside the band of a unit start, write only the band's planes:
+                // what lies outside must read as the zeros it is
+                bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)vec_count);
+                bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_c.ptr, (int64_t)vec_count);
+                bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_d.ptr, (int64_t)vec_count);
+            }
             if (real)
                 bdg::set_unit_real<<<1, 64, 0, st>>>(reinterpret_cast<double*>(sys->vec_a.ptr), sys->nb,
                                                      sys->ncols, rv, n_active, sys->rows.ptr,
@@ -230,8 +243,15 @@ struct Batch {
                                             (real ? 32.0 : 64.0) * rv, &args.tile_order, &strip_rows))
                 return rc;
         if (args.tile_order) band_lo = band_hi = -1;  // the band is a range of naturally ordered tiles
+        plane_lo = plane_hi = -1;
         if (sweep || roll) {
             strip_rows = 0;
+            const bool ring = sweep ? splan.args.wrap_x != 0 : false;  // (a ring of planes has no band)
+            if (band_lo >= 0 && band_lo <= band_hi && !ring && sys->ncols == sys->nb && sys->group_rows == 0) {
+                const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
+                plane_lo = (int)(band_lo / plane);
+                plane_hi = (int)(band_hi / plane);
+            }
             band_lo = band_hi = -1;
         }
         cur = sys->vec_a.ptr;
@@ -436,6 +456,7 @@ struct Batch {
             const int last = (int)((hi + plan.rows_per_tile - 1) / plan.rows_per_tile);
             args.tile_base = first;
             args.n_tiles = std::min(plan.n_tiles, last) - first;
+            bytes_moved -= algorithmic_bytes(sys, rv, mode, plan.dictionary) * (1.0 - (double)args.n_tiles / plan.n_tiles);
         }
         if (roll) {
             bdg::RollArgs& ra = rplan.args;
@@ -446,6 +467,15 @@ struct Batch {
             ra.reverse = args.reverse;
             ra.stream = args.stream_vectors;
             ra.discard = args.discard;
+            ra.x_lo = 0;
+            ra.x_hi = ra.lx;
+            ra.n_segs = rplan.segments_for(ra.lx);
+            if (plane_lo >= 0) {
+                ra.x_lo = std::max(0, plane_lo - (n + 1));
+                ra.x_hi = std::min(ra.lx, plane_hi + n + 2);
+                ra.n_segs = rplan.segments_for(ra.x_hi - ra.x_lo);
+                bytes_moved -= roll_bytes(sys, mode, rl) * (1.0 - (double)(ra.x_hi - ra.x_lo) / ra.lx);
+            }
             ra.lo_buf = ra.hi_buf = nullptr;
             if (sys->stencil_lo_base >= 0) {
                 ra.lo_buf = ext_lo ? ext_lo : cur;
@@ -505,10 +535,18 @@ struct Batch {
         const SweepKernel kernel = n == 0 && gen_start ? splan.kernel_gen
                                    : alternate && (n_launches & 1) ? splan.kernel_reverse : splan.kernel;
         if (n == 0 && gen_start) a.cur = nullptr;  // (never read)
+        a.x_lo = 0;
+        a.x_hi = a.lx;
+        if (plane_lo >= 0) {
+            a.x_lo = std::max(0, plane_lo - (n + now));
+            a.x_hi = std::min(a.lx, plane_hi + n + now + 1);
+        }
+        a.n_segs = splan.segments_for(a.x_hi - a.x_lo);
         // sweep_bytes counts two buffers read and two written: t_{-1} = 0 is never read, a generated t_0 neither,
-        // a lone step makes one new level, the last sweep of a run stores nothing
-        bytes_moved += sweep_bytes(sys, mode, rl) -
-                       vector_bytes() * ((n == 0 ? 1 : 0) + (n == 0 && gen_start ? 1 : 0) + (a.discard ? 2 : now == 1 ? 1 : 0));
+        // a lone step makes one new level, the last sweep of a run stores nothing; a band is its share of the planes
+        bytes_moved += (sweep_bytes(sys, mode, rl) -
+                        vector_bytes() * ((n == 0 ? 1 : 0) + (n == 0 && gen_start ? 1 : 0) + (a.discard ? 2 : now == 1 ? 1 : 0))) *
+                       ((double)(a.x_hi - a.x_lo) / a.lx);
         kernel<<<splan.grid, bdg::kSweepThreads, splan.lds_bytes, st>>>(a);
         ++n_launches;
         double2* old_cur = cur;
@@ -620,17 +658,18 @@ StartSpec batch_start(const StartSpec& start, int col) {
 // to 200x200 sites, 32 at 300x300, 16 at 400x400, 8 from 64^3 on (10^6 sites: 18.0 us per
 // vector-step at 8 per batch, 21.3 us at 64).  Rule: the largest power of two that keeps one
 // vector buffer within 96 MB, at least one full lane group (8 real / 4 complex), at most 64.
-int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors) {
+int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors, int n_steps) {
     if (const char* env = knob::raw("BODGE_AMD_BATCH")) return std::clamp(atoi(env), 1, 64);
     const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
     const char* real_env = knob::raw("BODGE_AMD_REAL");
     const bool real = (sys->slab_comm ? sys->slab_all_real : sys->is_real) && start_is_real &&
                       !(real_env && real_env[0] == '0');
     int stencil_kind = 0;
-    if (sys->lanes_override == 0 && sweep_wanted(sys, start.kind == StartKind::Random, false, &stencil_kind) == BDG_OK &&
-        stencil_kind != 0) {
+    const bool unit = start.kind == StartKind::Unit;
+    if (sys->lanes_override == 0 && sweep_wanted(sys, false, &stencil_kind) == BDG_OK && stencil_kind != 0 &&
+        !(unit && !(start.stencil >= 0 ? start.stencil != 0 : unit_run_wants_stencil(sys, start.rows, n_vectors, n_steps)))) {
         const int per_lane = real ? 2 : 1;
-        const int lanes = stencil_kind == 1 ? sweep_lanes_for(sys, n_vectors, per_lane) : roll_lanes_for(sys, n_vectors, per_lane);
+        const int lanes = stencil_kind == 1 ? sweep_lanes_for(sys, n_vectors, per_lane, unit) : roll_lanes_for(sys, n_vectors, per_lane);
         return std::min(lanes * per_lane, std::max(n_vectors, 1));  // one lane group per launch
     }
     // (slabs: the widest slab of the run decides, so that every rank cuts the same batches)
@@ -650,7 +689,9 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
     const bool trace = knob::raw("BODGE_AMD_TRACE") != nullptr;
     auto now = [] { return std::chrono::steady_clock::now(); };
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
-    const int width = batch_width(sys, start, n_vectors);
+    if (start.kind == StartKind::Unit)  // one decision for all the batches of the call (their widths follow from it)
+        start.stencil = unit_run_wants_stencil(sys, start.rows, n_vectors, n_steps) ? 1 : 0;
+    const int width = batch_width(sys, start, n_vectors, n_steps);
     // Batches are enqueued back to back and waited for once (whole matrices; a slab's batches are
     // paced by its halo exchange anyway): the GPU does not idle while the host turns a batch around.
     const int n_batches = (n_vectors + width - 1) / width;
@@ -750,7 +791,7 @@ int run_group(bdg_group* group, double scale, int n_steps, int n_vectors, StartS
         return false;
     };
 
-    const int width = batch_width(group->members[0], start, n_vectors);
+    const int width = batch_width(group->members[0], start, n_vectors, n_steps);
     for (int col = 0; col < n_vectors; col += width) {
         std::vector<Batch> batch(n_members);
         for (size_t m = 0; m < n_members; ++m)

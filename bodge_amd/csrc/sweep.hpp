@@ -83,6 +83,9 @@ struct SweepArgs {
     // 1 = nothing is stored: the last sweep of a run, whose vectors nothing reads any more (the call returns the
     // dot products only).  Every step is computed and dotted as in any other launch.
     int discard;
+    // Planes [x_lo, x_hi) are advanced by this launch (0, lx = the whole lattice).  Unit start vectors spread by one
+    // plane per step: outside the band everything is zero, and the buffers hold zeros there (recurrence.hpp).
+    int x_lo, x_hi;
 };
 
 // Stencil table + eligibility test, on the device from the uploaded arrays.  `words` is the
@@ -251,8 +254,8 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
 
     for (int u = u_lo + (int)(blockIdx.x >> 3) * kSweepWaves + wave; u < u_hi; u += waves_per_xcd) {
         const int seg = u / a.n_cols, col = u - seg * a.n_cols;
-        const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
-        const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
+        const int x0 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * seg) / a.n_segs);
+        const int x1 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * (seg + 1)) / a.n_segs);
         const int p = col * OWNED - 2 + s;
         const bool inside = p >= 0 && p < a.plane;
         const bool valid = inside || a.wrap_p;  // a ring has no edge: halo slots beyond it hold the far side
@@ -534,8 +537,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
 
     for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
         const int seg = u / a.n_cols, col = u - seg * a.n_cols;
-        const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
-        const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
+        const int x0 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * seg) / a.n_segs);
+        const int x1 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * (seg + 1)) / a.n_segs);
         const int p = col * OWNED3 - 3 + s;
         const bool inside = p >= 0 && p < a.plane;
         const bool valid = inside || a.wrap_p;  // a ring has no edge: halo slots beyond it hold the far side
@@ -857,6 +860,7 @@ struct RollArgs {
     int stream;              // non-temporal hints: bit 0 t_{n-1} loads, bit 1 stores
     int reverse;             // 1 = march every segment from its far end (launches alternate)
     int discard;             // 1 = t_{n+1} is not stored (last step of a run: only its dot products are wanted)
+    int x_lo, x_hi;          // planes advanced by this launch (0, lx = all; unit start vectors: the band that can be non-zero)
     // Row slabs (a stack of whole x-planes of a larger lattice, one handle per slab): the vector buffers
     // have `ld` block rows per component plane (own rows + halo rows), and t_n of the plane below plane 0 /
     // above plane lx-1 is read where the neighbouring slab keeps it - `lo_buf` / `hi_buf` point into that
@@ -942,8 +946,8 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
 
     for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
         const int seg = u / a.n_cols, col = u - seg * a.n_cols;
-        const int x0 = (int)(((int64_t)a.lx * seg) / a.n_segs);
-        const int x1 = (int)(((int64_t)a.lx * (seg + 1)) / a.n_segs);
+        const int x0 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * seg) / a.n_segs);
+        const int x1 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * (seg + 1)) / a.n_segs);
         const int p = col * OWNED - 1 + s;
         const bool valid = p >= 0 && p < a.plane;
         const bool owned = valid && s >= 1 && s <= SLOTS - 2;

@@ -614,6 +614,58 @@ def test_batches_of_one_call_enqueued_back_to_back_change_no_bit(api, solver_cls
     assert np.abs(queued[0][0] - ref[0]).max() <= 1e-12 * bsr.shape[0] and np.abs(queued[0][1] - ref[1]).max() <= 1e-12 * bsr.shape[0]
 
 
+@pytest.mark.parametrize("shape,model,knob_set,sites,steps", [
+    ((64, 48, 1), "swave", {}, [(30, 20, 0)], 50),                                   # K7b: the band reaches both ends of x
+    ((64, 48, 1), "swave", {}, [(0, 0, 0), (63, 47, 0), (31, 5, 0)], 10),            # corners: clipped bands, several sites
+    ((64, 48, 1), "swave", {"BODGE_AMD_SWEEP_LANES": "4"}, [(12, 40, 0), (50, 3, 0)], 17),
+    ((64, 48, 1), "swave", {}, [(31, 40, 0), (33, 3, 0)], 11),                        # a narrow band all the way
+    ((64, 48, 1), "peierls", {}, [(40, 11, 0)], 23),                                 # complex blocks: ComplexPHMode
+    ((64, 48, 1), "swave", {"BODGE_AMD_SWEEP_STEPS": "2"}, [(20, 20, 0)], 21),        # K7
+    ((30, 30, 1), "periodic", {}, [(3, 3, 0)], 12),                                  # ring of planes: no band
+    ((40, 12, 14), "dwave", {}, [(20, 6, 7)], 30),                                   # K8
+    ((40, 12, 14), "dwave", {}, [(0, 0, 0), (39, 11, 13)], 9),
+])
+def test_unit_start_vectors_on_the_stencil_kernels_with_a_band_of_planes(api, solver_cls, knobs, block_storage, shape, model, knob_set, sites, steps):
+    """Unit start vectors (LDOS: ref hamiltonian.py:341-387 restated as a Chebyshev resolvent) take the
+    lattice-stencil kernels as well.  t_n of a unit vector at plane x_s is zero outside planes x_s +- n, so
+    a launch advances only that band of planes and the four rotating buffers hold zeros outside it.  Same
+    dot products as the one-step kernels to round-off and as the oracle; fewer bytes than whole launches
+    until the band has reached both ends."""
+    system = _sweep_system(api, shape, model)
+    bsr = system.matrix("bsr")
+    n = bsr.shape[0]
+    scale = cheb_ref.spectral_bound(bsr)
+    rows = np.array([4 * ((x * shape[1] + y) * shape[2] + z) + (i % 4) for i, (x, y, z) in enumerate(sites)])
+    for key, value in knob_set.items():
+        knobs.set(key, value)
+    with solver_cls.from_hamiltonian(system) as dev:
+        dev.set_lattice_shape(shape)
+        knobs.set("BODGE_AMD_SWEEP", "0")
+        plain = dev.dots_unit(scale, steps, rows)
+        assert dev.perf()["steps_per_launch"] == 1 and dev.perf()["rolling"] == 0
+        knobs.set("BODGE_AMD_SWEEP", "1")
+        dev.dots_random(scale, 5, 8, seed=1)  # (leaves all four buffers full of another run's vectors)
+        banded = dev.dots_unit(scale, steps, rows)
+        perf = dev.perf()
+        again = dev.dots_unit(scale, steps, rows)
+    three_d = shape[1] > 1 and shape[2] > 1
+    stencil = block_storage == "dictionary"  # (the stencil forms read the block dictionary; without it: one-step kernels, row band)
+    assert perf["rolling"] == (1 if three_d and stencil else 0)
+    assert perf["steps_per_launch"] == (1 if three_d or not stencil else int(knob_set.get("BODGE_AMD_SWEEP_STEPS", 3)))
+    whole = perf["launches"] * perf["bytes_per_launch"]
+    if not stencil:
+        pass
+    elif model == "periodic":
+        assert perf["bytes_moved"] > 0.8 * whole
+    elif max(x for x, _, _ in sites) - min(x for x, _, _ in sites) + 2 * steps < shape[0] // 2:  # (the last band is half the planes)
+        assert perf["bytes_moved"] < 0.6 * whole, (perf["bytes_moved"], whole)
+    for a, b, c in zip(plain, banded, again):
+        assert np.array_equal(b, c)
+        assert np.abs(a - b).max() <= 1e-13 * max(1.0, np.abs(a).max())
+    ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.unit_block(n, rows))
+    assert np.abs(banded[0] - ref[0]).max() <= 1e-13 and np.abs(banded[1] - ref[1]).max() <= 1e-13
+
+
 @pytest.mark.parametrize("shape,model,knob_set,steps", [
     ((64, 48, 1), "swave", {"BODGE_AMD_SWEEP": "1"}, 7),                                 # K7b: 3 + 3 + 1
     ((64, 48, 1), "swave", {"BODGE_AMD_SWEEP": "1"}, 6),                                 # K7b: 3 + 3
