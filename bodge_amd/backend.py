@@ -46,8 +46,9 @@ class Perf(C.Structure):
         ("rolling", C.c_int32),
         ("dict_skipped", C.c_int32),
         ("onsite_streamed", C.c_int32),
-        ("reserved", C.c_int32),
+        ("streams", C.c_int32),
         ("bytes_moved", C.c_double),
+        ("window_ms", C.c_double),
     ]
 
 

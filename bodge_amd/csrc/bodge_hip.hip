@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <string_view>
@@ -494,6 +495,12 @@ int bdg_destroy(bdg_system* sys) {
     if (!sys) return BDG_OK;
     (void)hipSetDevice(sys->device);
     if (sys->stream) (void)hipStreamSynchronize(sys->stream);
+    for (auto& side : sys->side_sets) {
+        if (side->stream) (void)hipStreamSynchronize(side->stream);
+        side->release_set();
+    }
+    sys->side_sets.clear();
+    if (sys->ev_side) (void)hipEventDestroy(sys->ev_side);
     lanczos_free(sys);
     sys->indptr.release();
     sys->indices.release();
@@ -505,14 +512,7 @@ int bdg_destroy(bdg_system* sys) {
     sys->dict_ids.release();
     sys->dict_diagonal.release();
     sys->dict_full.release();
-    sys->vec_a.release();
-    sys->vec_b.release();
-    sys->vec_c.release();
-    sys->vec_d.release();
     sys->stencil.release();
-    sys->partial.release();
-    sys->dots.release();
-    sys->rows.release();
     if (sys->host_dots) (void)hipHostFree(sys->host_dots);
     sys->host_dots = nullptr;
     sys->tile_order.release();
@@ -526,8 +526,7 @@ int bdg_destroy(bdg_system* sys) {
     sys->recv_buf.release();
     if (sys->ev_start) (void)hipEventDestroy(sys->ev_start);
     if (sys->ev_stop) (void)hipEventDestroy(sys->ev_stop);
-    for (hipEvent_t ev : sys->ev_pool) (void)hipEventDestroy(ev);
-    if (sys->stream) (void)hipStreamDestroy(sys->stream);
+    sys->release_set();
     delete sys;
     return BDG_OK;
 }

@@ -73,11 +73,37 @@ struct ExchangePeer {
     int64_t recv_count = 0;
 };
 
-struct bdg_system {
-    int device = 0;
+// What a batch of vectors in flight needs for itself: a stream, the rotating vector buffers, the dot partials.
+// The handle is the first such set; a call with several batches runs them side by side on further ones
+// (`side_sets`, created on first use) - the start and the end of a launch leave the memory system idle, and
+// launches of independent batches fill each other's gaps (recurrence.hpp: run_recurrence).
+struct StreamSet {
     hipStream_t stream = nullptr;
+    std::vector<hipEvent_t> ev_pool;  // (start, stop) pairs: one per reduction chunk of a call
+    DeviceBuffer<double2> vec_a, vec_b;
+    DeviceBuffer<double2> vec_c, vec_d;  // multi-step sweeps: the new levels are written out of place
+    DeviceBuffer<double> partial, dots;
+    DeviceBuffer<int64_t> rows;
+    void release_set() {
+        vec_a.release();
+        vec_b.release();
+        vec_c.release();
+        vec_d.release();
+        partial.release();
+        dots.release();
+        rows.release();
+        for (hipEvent_t ev : ev_pool) (void)hipEventDestroy(ev);
+        ev_pool.clear();
+        if (stream) (void)hipStreamDestroy(stream);
+        stream = nullptr;
+    }
+};
+
+struct bdg_system : StreamSet {
+    int device = 0;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
-    std::vector<hipEvent_t> ev_pool;  // extra (start, stop) pairs: one per reduction chunk of a call
+    std::vector<std::unique_ptr<StreamSet>> side_sets;
+    hipEvent_t ev_side = nullptr;  // recorded on `stream` once a call's shared tables exist: the side streams wait for it
     int64_t nb = 0, nnzb = 0;
     int64_t ncols = 0;       // block rows of the vector buffers: nb owned + halo
     int64_t row_offset = 0;  // global block row of local row 0 (slab mode)
@@ -141,17 +167,13 @@ struct bdg_system {
     DeviceBuffer<int> dict_diagonal;      // per distinct block: 1 = diagonal as a 4x4 matrix (stencil kernels)
     DeviceBuffer<double2> dict_full;      // n_unique x 16 complex entries
     DeviceBuffer<double2> dict_table[4];  // packed per storage mode, built on first use
-    DeviceBuffer<double2> vec_a, vec_b;
-    DeviceBuffer<double2> vec_c, vec_d;  // two-steps-per-sweep form: t_{n+1}, t_{n+2} are written out of place
     // lattice-stencil form of the matrix (sweep.hpp): 0 = not examined, 1 = 5-point table built (planes
     // are lines), 2 = 7-point table built (3-D), -1 = not a stencil
     DeviceBuffer<uint2> stencil;
     int stencil_state = 0;
     bool stencil_wrap_p = false, stencil_wrap_x = false;  // periodic edge blocks: planes / stack of planes are rings
-    DeviceBuffer<double> partial, dots;
     double* host_dots = nullptr;  // pinned staging for the dot products (sized like `dots`)
     size_t host_dots_count = 0;
-    DeviceBuffer<int64_t> rows;
     // lattice geometry hint (rows = z + lz*(y + ly*x)) and the cached strip-major tile order
     int shape[3] = {0, 0, 0};
     DeviceBuffer<int> tile_order;

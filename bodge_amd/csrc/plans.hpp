@@ -753,6 +753,9 @@ RollKernel roll_kernel(const ModeInfo& mode, int lanes) {
 // x-segments, more segment-end planes), so wide batches stay with 4.  BODGE_AMD_SWEEP_LANES overrides.
 int roll_lanes_for(const bdg_system* sys, int n_vectors, int per_lane) {
     int lanes = n_vectors <= 2 * per_lane ? 2 : bdg::kSweepLanes;
+    // (One lane group as two 2-lane batches side by side on two streams was tried for whole matrices: 54.2 against
+    // 51.4 k vector-steps/s in a 63-step loop, nothing through bench.py, and 1.28 x instead of 1.08 x the algorithmic
+    // traffic - twice the segment-end planes.  Not kept; calls of two lane groups and more run them side by side.)
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_LANES")) {
         const int want = atoi(env);
         if (want == 2 || want == 4) lanes = want;

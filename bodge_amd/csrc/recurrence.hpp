@@ -13,6 +13,8 @@ namespace {
 //   finish() reduce partials (done per chunk inside step), copy dots to the host
 struct Batch {
     bdg_system* sys = nullptr;
+    StreamSet* ss = nullptr;  // stream + vector buffers + dot partials of this batch: the handle itself, or one of its side sets
+    int next = 0;             // next recurrence step to launch (advance)
     StepPlan plan;
     bdg::StepArgs args{};
     bool real = false;
@@ -56,12 +58,22 @@ struct Batch {
     int n_launches = 0;
 
     int begin(bdg_system* system, double scale_in, int steps, int active, const StartSpec& start,
-              int force_real /* -1 auto, 0 complex, 1 real */, bool col_scalars = false) {
+              int force_real /* -1 auto, 0 complex, 1 real */, bool col_scalars = false, int set_index = 0) {
         sys = system;
         scale = scale_in;
         n_steps = steps;
         n_active = active;
+        next = 0;
         HIP_TRY(hipSetDevice(sys->device));
+        ss = sys;
+        if (set_index > 0) {
+            while ((int)sys->side_sets.size() < set_index) {
+                auto side = std::make_unique<StreamSet>();
+                HIP_TRY(hipStreamCreateWithFlags(&side->stream, hipStreamNonBlocking));
+                sys->side_sets.push_back(std::move(side));
+            }
+            ss = sys->side_sets[(size_t)set_index - 1].get();
+        }
         // Real arithmetic applies when H has no imaginary part and the start vectors are real
         // (±1 or unit vectors): every t_n then stays real.  BODGE_AMD_REAL=0 forces complex.
         const bool start_is_real = start.kind == StartKind::Unit || start.vec_kind == BDG_VEC_RADEMACHER;
@@ -149,13 +161,13 @@ struct Batch {
         if (const char* env = knob::raw("BODGE_AMD_ALTERNATE")) alternate = std::atoi(env) != 0;
         discard_last = true;
         if (const char* env = knob::raw("BODGE_AMD_KEEP_LAST")) discard_last = std::atoi(env) == 0;
-        if (int rc = sys->vec_a.reserve(vec_count)) return rc;
-        if (int rc = sys->vec_b.reserve(vec_count)) return rc;
+        if (int rc = ss->vec_a.reserve(vec_count)) return rc;
+        if (int rc = ss->vec_b.reserve(vec_count)) return rc;
         if (sweep) {
-            if (int rc = sys->vec_c.reserve(vec_count)) return rc;
-            if (int rc = sys->vec_d.reserve(vec_count)) return rc;
-            spare1 = sys->vec_c.ptr;
-            spare2 = sys->vec_d.ptr;
+            if (int rc = ss->vec_c.reserve(vec_count)) return rc;
+            if (int rc = ss->vec_d.reserve(vec_count)) return rc;
+            spare1 = ss->vec_c.ptr;
+            spare2 = ss->vec_d.ptr;
             splan.args.stream = 2 * vec_count * sizeof(double2) > kStreamVectorBytes ? 1 : 0;
             if (const char* env = knob::raw("BODGE_AMD_SWEEP_STREAM")) splan.args.stream = std::atoi(env);
         }
@@ -166,13 +178,14 @@ struct Batch {
         per_step = (size_t)(overlapped ? grid_interior + grid_boundary : launch_grid) * width;
         constexpr int kChunk = 64;
         chunk = std::min(n_steps, sweep && splan.depth == 3 ? 63 : kChunk);  // a sweep must not straddle two chunks
-        if (int rc = sys->partial.reserve((size_t)kChunk * per_step)) return rc;
+        if (int rc = ss->partial.reserve((size_t)kChunk * per_step)) return rc;
         const size_t dots_count = (size_t)std::max(n_steps, 1024) * width;
-        if (int rc = sys->dots.reserve(dots_count)) return rc;
+        if (int rc = ss->dots.reserve(dots_count)) return rc;
         host_stride = dots_count;
         ev_base = slot * ((n_steps + chunk - 1) / chunk);
         if (sys->host_dots_count < dots_count * n_slots) {
             HIP_TRY(hipStreamSynchronize(sys->stream));  // (an earlier batch of this call may still be copying into it)
+            for (auto& side : sys->side_sets) HIP_TRY(hipStreamSynchronize(side->stream));
             if (sys->host_dots) (void)hipHostFree(sys->host_dots);
             sys->host_dots = nullptr;
             sys->host_dots_count = 0;
@@ -184,7 +197,7 @@ struct Batch {
         if (sys->recv_total > 0)
             if (int rc = sys->recv_buf.reserve((size_t)sys->recv_total * 4 * rl)) return rc;
 
-        hipStream_t st = sys->stream;
+        hipStream_t st = ss->stream;
         const int fill_grid = (int)std::min<size_t>(4096, (vec_count + 255) / 256);
         // Three-step sweeps make a random t_0 in registers during the first sweep (cheb_sweep3 GEN):
         // no fill kernel, and vec_a is only ever a spare buffer.  BODGE_AMD_SWEEP_GEN=0: fill and read.
@@ -199,15 +212,15 @@ struct Batch {
         } else if (start.kind == StartKind::Random) {
             if (real)
                 bdg::fill_random_real<<<fill_grid, 256, 0, st>>>(
-                    reinterpret_cast<double*>(sys->vec_a.ptr), sys->nb, sys->ncols, rv, n_active,
+                    reinterpret_cast<double*>(ss->vec_a.ptr), sys->nb, sys->ncols, rv, n_active,
                     start.seed, start.first_id, sys->row_offset);
             else
-                bdg::fill_random<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, sys->nb, sys->ncols, rv,
+                bdg::fill_random<<<fill_grid, 256, 0, st>>>(ss->vec_a.ptr, sys->nb, sys->ncols, rv,
                                                             n_active, start.seed, start.first_id,
                                                             start.vec_kind, sys->row_offset);
         } else {
-            if (int rc = sys->rows.reserve(64)) return rc;
-            HIP_TRY(hipMemcpyAsync(sys->rows.ptr, start.rows, sizeof(int64_t) * n_active,
+            if (int rc = ss->rows.reserve(64)) return rc;
+            HIP_TRY(hipMemcpyAsync(ss->rows.ptr, start.rows, sizeof(int64_t) * n_active,
                                    hipMemcpyHostToDevice, st));
             if (sys->ncols == sys->nb && !knob::raw("BODGE_AMD_NO_BAND")) {
                 band_lo = sys->nb;
@@ -217,24 +230,24 @@ struct Batch {
                     band_hi = std::max<int64_t>(band_hi, start.rows[r] >> 2);
                 }
             }
-            bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_a.ptr, (int64_t)vec_count);
+            bdg::fill_zero<<<fill_grid, 256, 0, st>>>(ss->vec_a.ptr, (int64_t)vec_count);
             if (sweep) {
                 // the sweeps rotate four buffers and, inside the band of a unit start, write only the band's planes:
                 // what lies outside must read as the zeros it is
-                bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)vec_count);
-                bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_c.ptr, (int64_t)vec_count);
-                bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_d.ptr, (int64_t)vec_count);
+                bdg::fill_zero<<<fill_grid, 256, 0, st>>>(ss->vec_b.ptr, (int64_t)vec_count);
+                bdg::fill_zero<<<fill_grid, 256, 0, st>>>(ss->vec_c.ptr, (int64_t)vec_count);
+                bdg::fill_zero<<<fill_grid, 256, 0, st>>>(ss->vec_d.ptr, (int64_t)vec_count);
             }
             if (real)
-                bdg::set_unit_real<<<1, 64, 0, st>>>(reinterpret_cast<double*>(sys->vec_a.ptr), sys->nb,
-                                                     sys->ncols, rv, n_active, sys->rows.ptr,
+                bdg::set_unit_real<<<1, 64, 0, st>>>(reinterpret_cast<double*>(ss->vec_a.ptr), sys->nb,
+                                                     sys->ncols, rv, n_active, ss->rows.ptr,
                                                      sys->row_offset);
             else
-                bdg::set_unit<<<1, 64, 0, st>>>(sys->vec_a.ptr, sys->nb, sys->ncols, rv, n_active,
-                                                sys->rows.ptr, sys->row_offset);
+                bdg::set_unit<<<1, 64, 0, st>>>(ss->vec_a.ptr, sys->nb, sys->ncols, rv, n_active,
+                                                ss->rows.ptr, sys->row_offset);
         }
         if (!sweep)  // (the sweep kernels are told that t_{-1} = 0 instead of reading 256 MB of zeros)
-            bdg::fill_zero<<<fill_grid, 256, 0, st>>>(sys->vec_b.ptr, (int64_t)vec_count);
+            bdg::fill_zero<<<fill_grid, 256, 0, st>>>(ss->vec_b.ptr, (int64_t)vec_count);
         HIP_TRY(hipGetLastError());
 
         // bytes of t_n per block row that neighbouring rows re-read: 4 entries per vector
@@ -254,8 +267,8 @@ struct Batch {
             }
             band_lo = band_hi = -1;
         }
-        cur = sys->vec_a.ptr;
-        prev = sys->vec_b.ptr;
+        cur = ss->vec_a.ptr;
+        prev = ss->vec_b.ptr;
         kernel_ms = 0.f;
         n_chunks = 0;
         return BDG_OK;
@@ -264,7 +277,7 @@ struct Batch {
     // Halo exchange, split so that a same-process group can interleave its members.
     int pack(hipStream_t st = nullptr) {
         if (sys->send_total == 0) return BDG_OK;
-        if (!st) st = sys->stream;
+        if (!st) st = ss->stream;
         HIP_TRY(hipSetDevice(sys->device));
         const int64_t total = sys->send_total * 4 * rl;
         bdg::halo_pack<<<(unsigned)std::min<int64_t>(2048, (total + 255) / 256), 256, 0, st>>>(
@@ -273,7 +286,7 @@ struct Batch {
         return BDG_OK;
     }
     int unpack(hipStream_t st = nullptr) {
-        if (!st) st = sys->stream;
+        if (!st) st = ss->stream;
         HIP_TRY(hipSetDevice(sys->device));
         for (const ExchangePeer& peer : sys->peers) {
             if (peer.recv_count == 0) continue;
@@ -355,13 +368,13 @@ struct Batch {
 
     int step_overlapped(int n) {
         HIP_TRY(hipSetDevice(sys->device));
-        hipStream_t st = sys->stream, cs = sys->comm_stream;
+        hipStream_t st = ss->stream, cs = sys->comm_stream;
         const int in_chunk = n % chunk;
         const int chunk_id = n / chunk;
-        while ((int)sys->ev_pool.size() < 2 * (ev_base + chunk_id + 1)) {
+        while ((int)ss->ev_pool.size() < 2 * (ev_base + chunk_id + 1)) {
             hipEvent_t ev = nullptr;
             HIP_TRY(hipEventCreate(&ev));
-            sys->ev_pool.push_back(ev);
+            ss->ev_pool.push_back(ev);
         }
         // exchange of t_n on the communication stream, after everything that produced t_n
         HIP_TRY(hipEventRecord(sys->ev_step_done, st));
@@ -371,13 +384,13 @@ struct Batch {
         if (int rc = unpack(cs)) return rc;
         HIP_TRY(hipEventRecord(sys->ev_halo_ready, cs));
 
-        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id)], st));
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(ss->ev_pool[2 * (ev_base + chunk_id)], st));
         args.cur = cur;
         args.prev = prev;
         args.coef = (n == 0 ? 1.0 : 2.0) / scale;
         args.discard = discard_last && n == n_steps - 1;
         bytes_moved += algorithmic_bytes(sys, rv, mode, plan.dictionary) - (args.discard ? vector_bytes() : 0.0);
-        double* slot = sys->partial.ptr + (size_t)in_chunk * per_step;
+        double* slot = ss->partial.ptr + (size_t)in_chunk * per_step;
         bdg::StepArgs part = args;
         part.tile_order = sys->tiles_interior.ptr;
         part.n_tiles = sys->n_interior;
@@ -392,8 +405,8 @@ struct Batch {
         std::swap(cur, prev);
         if (in_chunk == chunk - 1 || n == n_steps - 1) {
             const int s0 = n - in_chunk;
-            HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id) + 1], st));
-            bdg::reduce_partials<<<in_chunk + 1, 256, 0, st>>>(sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width,
+            HIP_TRY(hipEventRecord(ss->ev_pool[2 * (ev_base + chunk_id) + 1], st));
+            bdg::reduce_partials<<<in_chunk + 1, 256, 0, st>>>(ss->partial.ptr, ss->dots.ptr + (size_t)s0 * width,
                                                               grid_interior + grid_boundary, (int)width);
             HIP_TRY(hipGetLastError());
             n_chunks = chunk_id + 1;
@@ -415,11 +428,11 @@ struct Batch {
             if (peer.send_count > 0)
                 NCCL_TRY(api, api->send(sys->send_buf.ptr + (size_t)peer.send_begin * 4 * rl,
                                         (size_t)peer.send_count * unit, ncclDouble, peer.rank, comm->comm,
-                                        sys->stream));
+                                        ss->stream));
             if (peer.recv_count > 0)
                 NCCL_TRY(api, api->recv(sys->recv_buf.ptr + (size_t)peer.recv_begin * 4 * rl,
                                         (size_t)peer.recv_count * unit, ncclDouble, peer.rank, comm->comm,
-                                        sys->stream));
+                                        ss->stream));
         }
         NCCL_TRY(api, api->group_end());
         return unpack();
@@ -427,23 +440,23 @@ struct Batch {
 
     int step(int n) {
         HIP_TRY(hipSetDevice(sys->device));
-        hipStream_t st = sys->stream;
+        hipStream_t st = ss->stream;
         const int in_chunk = n % chunk;
         const int chunk_id = n / chunk;
         // one event pair per chunk, read back in finish(): the host never waits inside the loop
-        while ((int)sys->ev_pool.size() < 2 * (ev_base + chunk_id + 1)) {
+        while ((int)ss->ev_pool.size() < 2 * (ev_base + chunk_id + 1)) {
             hipEvent_t ev = nullptr;
             HIP_TRY(hipEventCreate(&ev));
-            sys->ev_pool.push_back(ev);
+            ss->ev_pool.push_back(ev);
         }
-        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id)], st));
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(ss->ev_pool[2 * (ev_base + chunk_id)], st));
         args.cur = cur;
         args.prev = prev;
         args.coef = (n == 0 ? 1.0 : 2.0) / scale;
         args.discard = discard_last && n == n_steps - 1;
         bytes_moved += (roll ? roll_bytes(sys, mode, rl) : algorithmic_bytes(sys, rv, mode, plan.dictionary)) -
                        (args.discard ? vector_bytes() : 0.0);
-        args.partial = sys->partial.ptr + (size_t)in_chunk * per_step;
+        args.partial = ss->partial.ptr + (size_t)in_chunk * per_step;
         args.reverse = alternate ? (n & 1) : 0;
         args.tile_base = 0;
         args.n_tiles = plan.n_tiles;
@@ -494,9 +507,9 @@ struct Batch {
         std::swap(cur, prev);
         if (in_chunk == chunk - 1 || n == n_steps - 1) {
             const int s0 = n - in_chunk;
-            HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id) + 1], st));
+            HIP_TRY(hipEventRecord(ss->ev_pool[2 * (ev_base + chunk_id) + 1], st));
             bdg::reduce_partials<<<in_chunk + 1, 256, 0, st>>>(
-                sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, launch_grid, (int)width);
+                ss->partial.ptr, ss->dots.ptr + (size_t)s0 * width, launch_grid, (int)width);
             HIP_TRY(hipGetLastError());
             n_chunks = chunk_id + 1;
         }
@@ -508,17 +521,17 @@ struct Batch {
     // (t_n, t_{n-1}, spare, spare) -> (t_{n+k}, t_{n+k-1}, spare, spare).
     int step_sweep(int n, int* made) {
         HIP_TRY(hipSetDevice(sys->device));
-        hipStream_t st = sys->stream;
+        hipStream_t st = ss->stream;
         const int in_chunk = n % chunk;
         const int chunk_id = n / chunk;
         const int now = std::min({splan.depth, n_steps - n, chunk - in_chunk});
         *made = now;
-        while ((int)sys->ev_pool.size() < 2 * (ev_base + chunk_id + 1)) {
+        while ((int)ss->ev_pool.size() < 2 * (ev_base + chunk_id + 1)) {
             hipEvent_t ev = nullptr;
             HIP_TRY(hipEventCreate(&ev));
-            sys->ev_pool.push_back(ev);
+            ss->ev_pool.push_back(ev);
         }
-        if (in_chunk == 0) HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id)], st));
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(ss->ev_pool[2 * (ev_base + chunk_id)], st));
         bdg::SweepArgs& a = splan.args;
         a.cur = cur;
         a.prev = n == 0 ? nullptr : prev;
@@ -529,7 +542,7 @@ struct Batch {
         a.two = now >= 2 ? 1 : 0;
         a.steps = now;
         a.discard = discard_last && n + now == n_steps;
-        a.partial1 = sys->partial.ptr + (size_t)in_chunk * per_step;
+        a.partial1 = ss->partial.ptr + (size_t)in_chunk * per_step;
         a.partial2 = a.partial1 + per_step;
         a.partial3 = a.partial2 + per_step;
         const SweepKernel kernel = n == 0 && gen_start ? splan.kernel_gen
@@ -569,28 +582,49 @@ struct Batch {
         const int last_in_chunk = last % chunk;
         if (last_in_chunk == chunk - 1 || last == n_steps - 1) {
             const int s0 = last - last_in_chunk;
-            HIP_TRY(hipEventRecord(sys->ev_pool[2 * (ev_base + chunk_id) + 1], st));
+            HIP_TRY(hipEventRecord(ss->ev_pool[2 * (ev_base + chunk_id) + 1], st));
             bdg::reduce_partials<<<last_in_chunk + 1, 256, 0, st>>>(
-                sys->partial.ptr, sys->dots.ptr + (size_t)s0 * width, launch_grid, (int)width);
+                ss->partial.ptr, ss->dots.ptr + (size_t)s0 * width, launch_grid, (int)width);
             HIP_TRY(hipGetLastError());
             n_chunks = chunk_id + 1;
         }
         return BDG_OK;
     }
 
+    // The next launch of this batch (single handle: whole matrix, or a slab exchanging its halo through RCCL).
+    int advance() {
+        if (sweep) {
+            int made = 1;
+            if (int rc = step_sweep(next, &made)) return rc;
+            next += made;
+            return BDG_OK;
+        }
+        if (overlapped) {
+            if (int rc = step_overlapped(next)) return rc;
+        } else {
+            if (int rc = exchange_rccl()) return rc;
+            if (int rc = step(next)) return rc;
+        }
+        ++next;
+        return BDG_OK;
+    }
+    // first start / last stop event of the batch (after finish_enqueue): the ends of its launches on its stream
+    hipEvent_t first_event() const { return ss->ev_pool[2 * (size_t)ev_base]; }
+    hipEvent_t last_event() const { return ss->ev_pool[2 * (size_t)(ev_base + n_chunks - 1) + 1]; }
+
     // d/e of this handle's rows into columns [col0, col0 + n_active) of (n_steps x ld) arrays;
     // accumulate = true adds to what is there (summing the slabs of a group).
     int finish(double* d_out, double* e_out, int ld, int col0, bool accumulate, bool first_batch) {
         if (int rc = finish_enqueue()) return rc;
-        HIP_TRY(hipStreamSynchronize(sys->stream));
+        HIP_TRY(hipStreamSynchronize(ss->stream));
         return finish_collect(d_out, e_out, ld, col0, accumulate, first_batch);
     }
     // copy of the batch's dot products to the host, enqueued behind its last reduction
     int finish_enqueue() {
         HIP_TRY(hipSetDevice(sys->device));
         // pinned: a pageable target costs ~8 ms on its first use
-        HIP_TRY(hipMemcpyAsync(sys->host_dots + (size_t)slot * host_stride, sys->dots.ptr,
-                               (size_t)n_steps * width * sizeof(double), hipMemcpyDeviceToHost, sys->stream));
+        HIP_TRY(hipMemcpyAsync(sys->host_dots + (size_t)slot * host_stride, ss->dots.ptr,
+                               (size_t)n_steps * width * sizeof(double), hipMemcpyDeviceToHost, ss->stream));
         return BDG_OK;
     }
     // after the stream has been waited for
@@ -599,7 +633,7 @@ struct Batch {
         const double* host = sys->host_dots + (size_t)slot * host_stride;
         for (int c = 0; c < n_chunks; ++c) {
             float ms = 0.f;
-            HIP_TRY(hipEventElapsedTime(&ms, sys->ev_pool[2 * (ev_base + c)], sys->ev_pool[2 * (ev_base + c) + 1]));
+            HIP_TRY(hipEventElapsedTime(&ms, ss->ev_pool[2 * (ev_base + c)], ss->ev_pool[2 * (ev_base + c) + 1]));
             kernel_ms += ms;
         }
         for (int n = 0; n < n_steps; ++n)
@@ -615,6 +649,8 @@ struct Batch {
         p.kernel_ms += kernel_ms;
         p.launches += sweep ? n_launches : n_steps;
         p.bytes_moved += bytes_moved;
+        p.window_ms = p.kernel_ms;  // (batches side by side on several streams: run_recurrence measures the window)
+        p.streams = 1;
         p.vector_steps += (int64_t)n_steps * n_active;
         p.bytes_per_launch = sweep  ? sweep_bytes(sys, mode, rl)
                              : roll ? roll_bytes(sys, mode, rl)
@@ -698,55 +734,99 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
     const size_t staged = (size_t)n_batches * std::max(n_steps, 1024) * 2 * (size_t)width;  // doubles of pinned memory
     const bool pipelined = n_batches > 1 && n_batches <= 64 && staged <= ((size_t)4 << 20) && sys->ncols == sys->nb &&
                            !knob::raw("BODGE_AMD_NO_BATCH_PIPELINE");
-    std::vector<Batch> queued(pipelined ? (size_t)n_batches : 0);
+    // ... and side by side: the batches of a call are independent, and a launch of the marching kernels leaves the
+    // memory system idle while its waves load their first planes and again while the last ones drain.  Batches
+    // alternate between the handle's stream and a side stream with its own vector buffers, their launches enqueued
+    // in turn: the gaps of one fill with the other's work (1000x1000, two lane groups of 4 vectors: 100.4 -> 112 k
+    // vector-steps/s, scratch/r3_two_streams.py).  BODGE_AMD_STREAMS=1..4 (default 2).
+    // The marching kernels gain (K7b with 2 lanes per site +13-15 %, with 4 lanes +7 %, streamed on-site blocks +6 %,
+    // K8 on 100^3 +11 %; a third stream adds nothing); the one-step kernels lose 6-9 % (their launches have no idle
+    // ends, two of them only share the caches) and stay on one stream (profiles/r03_streams.log).
+    int n_streams = 1;
+    const char* streams_env = knob::raw("BODGE_AMD_STREAMS");
+    if (pipelined) {
+        n_streams = 2;
+        if (streams_env) n_streams = std::clamp(atoi(streams_env), 1, 4);
+        n_streams = std::min(n_streams, n_batches);
+    }
+    if (!pipelined) {
+        for (int col = 0; col < n_vectors; col += width) {
+            Batch batch;
+            const auto t0 = now();
+            if (int rc = batch.begin(sys, scale, n_steps, std::min(width, n_vectors - col), batch_start(start, col), -1))
+                return rc;
+            const auto t1 = now();
+            while (batch.next < n_steps)
+                if (int rc = batch.advance()) return rc;
+            const auto t2 = now();
+            if (int rc = batch.finish(d_out, e_out, n_vectors, col, false, col == 0)) return rc;
+            if (trace)
+                fprintf(stderr, "[bdg] begin %.3f ms, steps %.3f ms (kernels %.3f), finish %.3f ms\n", ms(t0, t1),
+                        ms(t1, t2), batch.kernel_ms, ms(t2, now()));
+        }
+        sys->perf.window_ms = sys->perf.kernel_ms;
+        sys->perf.streams = 1;
+        return BDG_OK;
+    }
+
+    HIP_TRY(hipSetDevice(sys->device));
+    while ((int)sys->side_sets.size() < n_streams - 1) {
+        auto side = std::make_unique<StreamSet>();
+        HIP_TRY(hipStreamCreateWithFlags(&side->stream, hipStreamNonBlocking));
+        sys->side_sets.push_back(std::move(side));
+    }
+    if (!sys->ev_side) HIP_TRY(hipEventCreateWithFlags(&sys->ev_side, hipEventDisableTiming));
+    std::vector<Batch> queued((size_t)n_batches);
     size_t stride0 = 0;
-    for (int col = 0, index = 0; col < n_vectors; col += width, ++index) {
-        Batch single;
-        Batch& batch = pipelined ? queued[(size_t)index] : single;
-        if (pipelined) {
+    for (int first = 0, last = 0; first < n_batches; first = last) {
+        const auto t0 = now();
+        for (last = first; last < std::min(n_batches, first + n_streams); ++last) {  // (n_streams may drop to 1 below)
+            const int index = last;
+            Batch& batch = queued[(size_t)index];
             batch.slot = index;
             batch.n_slots = n_batches;
-        }
-        const auto t0 = now();
-        if (int rc = batch.begin(sys, scale, n_steps, std::min(width, n_vectors - col),
-                                 batch_start(start, col), -1))
-            return rc;
-        if (pipelined) {  // one spacing of the result pieces for the whole call: the first batch is the widest
-            if (index == 0) stride0 = batch.host_stride;
+            const int col = index * width;
+            if (int rc = batch.begin(sys, scale, n_steps, std::min(width, n_vectors - col), batch_start(start, col), -1, false,
+                                     index - first))
+                return rc;
+            if (index == 0) {  // one spacing of the result pieces for the whole call: the first batch is the widest
+                stride0 = batch.host_stride;
+                if (!streams_env && !batch.sweep && !batch.roll) n_streams = 1;
+                // the first begin() has built whatever tables the kernels share (on the handle's stream)
+                HIP_TRY(hipEventRecord(sys->ev_side, sys->stream));
+                for (int side = 0; side < n_streams - 1; ++side)
+                    HIP_TRY(hipStreamWaitEvent(sys->side_sets[(size_t)side]->stream, sys->ev_side, 0));
+            }
             batch.host_stride = stride0;
         }
         const auto t1 = now();
-        for (int n = 0; n < n_steps; ++n) {
-            if (batch.sweep) {
-                int made = 1;
-                if (int rc = batch.step_sweep(n, &made)) return rc;
-                n += made - 1;
-                continue;
+        for (bool more = true; more;) {
+            more = false;
+            for (int index = first; index < last; ++index) {
+                Batch& batch = queued[(size_t)index];
+                if (batch.next >= n_steps) continue;
+                if (int rc = batch.advance()) return rc;
+                more = true;
             }
-            if (batch.overlapped) {
-                if (int rc = batch.step_overlapped(n)) return rc;
-                continue;
-            }
-            if (int rc = batch.exchange_rccl()) return rc;
-            if (int rc = batch.step(n)) return rc;
         }
-        const auto t2 = now();
-        if (pipelined) {
-            if (int rc = batch.finish_enqueue()) return rc;
-        } else if (int rc = batch.finish(d_out, e_out, n_vectors, col, false, col == 0)) {
+        for (int index = first; index < last; ++index)
+            if (int rc = queued[(size_t)index].finish_enqueue()) return rc;
+        if (trace) fprintf(stderr, "[bdg] batches %d..%d: begin %.3f ms, enqueue %.3f ms\n", first, last - 1, ms(t0, t1), ms(t1, now()));
+    }
+    HIP_TRY(hipStreamSynchronize(sys->stream));
+    for (int side = 0; side < n_streams - 1; ++side) HIP_TRY(hipStreamSynchronize(sys->side_sets[(size_t)side]->stream));
+    for (int index = 0; index < n_batches; ++index)
+        if (int rc = queued[(size_t)index].finish_collect(d_out, e_out, n_vectors, index * width, false, index == 0))
             return rc;
-        }
-        if (trace)
-            fprintf(stderr, "[bdg] begin %.3f ms, steps %.3f ms (kernels %.3f), finish %.3f ms\n", ms(t0, t1),
-                    ms(t1, t2), batch.kernel_ms, ms(t2, now()));
+    // the window all launches of the call fell into: first start event to the latest stop event of any stream
+    float window = 0.f;
+    for (int index = 0; index < n_batches; ++index) {
+        float t = 0.f;
+        HIP_TRY(hipEventElapsedTime(&t, queued[0].first_event(), queued[(size_t)index].last_event()));
+        window = std::max(window, t);
     }
-    if (pipelined) {
-        HIP_TRY(hipSetDevice(sys->device));
-        HIP_TRY(hipStreamSynchronize(sys->stream));
-        for (int index = 0; index < n_batches; ++index)
-            if (int rc = queued[(size_t)index].finish_collect(d_out, e_out, n_vectors, index * width, false, index == 0))
-                return rc;
-    }
+    sys->perf.window_ms = window;
+    sys->perf.streams = n_streams;
     return BDG_OK;
 }
 

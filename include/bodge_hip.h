@@ -46,7 +46,7 @@ typedef struct bdg_group bdg_group;   /* several slabs driven by one process */
 
 /* Performance record of the most recent Chebyshev call on a handle. */
 typedef struct bdg_perf {
-    double kernel_ms;      /* HIP-event time around the recurrence launches          */
+    double kernel_ms;      /* HIP-event time around the recurrence launches, summed over the streams */
     int64_t launches;      /* number of recurrence-kernel launches in that window    */
     int64_t vector_steps;  /* launches x vectors advanced per launch                 */
     double bytes_per_launch; /* algorithmic HBM bytes of one launch      */
@@ -68,12 +68,18 @@ typedef struct bdg_perf {
                                 streamed from HBM once per launch, only the bond blocks sit in the table
                                 (dict_blocks then counts the distinct bond blocks); 2 = the bond blocks are
                                 streamed as well (real matrices with spin-diagonal hopping: no table)      */
-    int32_t reserved;      /* keeps the struct a multiple of 8 bytes */
+    int32_t streams;       /* HIP streams the batches of the call ran on side by side (1 = back to back) */
     double bytes_moved;    /* algorithmic HBM bytes of all `launches` together.  Less than launches x
                               bytes_per_launch: the first sweep of a run reads no t_{-1} (and no t_0 when it
                               makes the random start block itself), and the last launch of a run stores no
                               vectors - nothing reads them, the call returns dot products (BODGE_AMD_KEEP_LAST=1
-                              stores them all the same).  Divide by kernel_ms for the achieved rate. */
+                              stores them all the same).  Divide by window_ms for the achieved rate. */
+    double window_ms;      /* HIP-event time from the first launch of the call to the end of its last one.  A call
+                              with several batches of vectors runs them on `streams` streams side by side (the
+                              idle start and end of one launch fill with another batch's work): kernel_ms then
+                              sums the streams' own times (kernel_ms / launches = duration of one launch, what a
+                              profiler reports) and window_ms is the elapsed time they share.  One stream:
+                              window_ms = kernel_ms. */
 } bdg_perf;
 
 const char* bdg_last_error(void);

@@ -33,7 +33,7 @@ for rnd in range(rounds + 1):
             solver.dots_random(scale, steps, vectors, seed=rnd, kind=kind)
             p = solver.perf()
         if rnd:
-            results[name].append((p["kernel_ms"] / p["launches"], p["bytes_moved"] / p["launches"], p, p["vector_steps"] / p["kernel_ms"]))
+            results[name].append((p["kernel_ms"] / p["launches"], p["bytes_moved"] / p["launches"], p, p["vector_steps"] / p["window_ms"]))
 for name, _ in variants:
     ms = np.array([r[0] for r in results[name]]); b = results[name][0][1]; p = results[name][0][2]
     rate = np.median([r[3] for r in results[name]])
