@@ -26,6 +26,7 @@
 //     BODGE_AMD_SWEEP_ZIGZAG=0               all segments march the same way
 //     BODGE_AMD_ALTERNATE=0                  launches do not alternate their marching direction
 //     BODGE_AMD_KEEP_LAST=1                  the last launch of a run stores its vectors like any other
+//     BODGE_AMD_STREAMS=1..4                 streams the batches of one call run on side by side (default: 2 for the marching kernels)
 //     BODGE_AMD_SWEEP_STREAM=bits            non-temporal hints of the sweep kernels (1 t_{n-1} loads, 2 stores, 4 t_n loads, 8 on-site records)
 //     BODGE_AMD_STREAM_VECTORS=bits          the same for the one-step and rolling kernels
 //     BODGE_AMD_L2_BUDGET=bytes              per-XCD budget behind the strip width of the tile order
