@@ -411,14 +411,14 @@ SweepKernel sweep_kernel(const ModeInfo& mode, int lanes, bool reverse) {
 // units in rounds, so the launch lasts  ceil(units / waves) x (planes per segment + the planes a
 // unit recomputes at its ends);  fewer, longer segments also re-read less.  Smallest count within
 // 3 % of the best duration.
-int choose_segments(int n_cols, int lx, int waves, int extra_planes, int min_planes) {
+int choose_segments(int n_cols, int lx, int waves, int extra_planes, int min_planes, double keep = 0.97) {
     int best = 1;
     double best_cost = 0.0;
     for (int segs = 1; segs <= std::max(1, lx / min_planes); ++segs) {
         const int64_t units = (int64_t)n_cols * segs;
         const double rounds = (double)((units + waves - 1) / waves);
         const double cost = rounds * ((double)((lx + segs - 1) / segs) + extra_planes);
-        if (segs == 1 || cost < 0.97 * best_cost) {
+        if (segs == 1 || cost < keep * best_cost) {
             best = segs;
             best_cost = cost;
         }
@@ -601,7 +601,11 @@ int sweep_wanted(bdg_system* sys, bool col_scalars, int* kind) {
     return BDG_OK;
 }
 
-int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth, SweepPlan* plan) {
+// `share`: launches of this many batches are in flight together (run_recurrence runs the lane groups of a call side
+// by side on as many streams): each gets that fraction of the wave slots, i.e. fewer, longer segments - 1000x1000, two
+// streams: 26 segments of 38 planes instead of 52 of 19 (1014 units per launch, two launches fill the 2048 slots) is
+// 116.7 against 111.8 k vector-steps/s and recomputes half as many planes (profiles/r03_segments.log).
+int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth, SweepPlan* plan, int share = 1) {
     plan->lanes = lanes;
     plan->depth = depth;
     const bool streamed = sys->onsite_streamed, bonds = sys->bonds_streamed;
@@ -648,8 +652,12 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     const int owned = depth == 3 ? bdg::sweep3_owned(lanes) : bdg::sweep_owned(lanes);
     a.n_cols = (int)((plane + owned - 1) / owned);
     // one unit (segment x window) per resident wave, segments of at least 8 planes
-    const int waves = per_cu * sys->num_cus * bdg::kSweepWaves;
-    int n_segs = choose_segments(a.n_cols, a.lx, waves, 2 * depth, 8);
+    // (not with streamed on-site blocks: their complex form keeps one workgroup per CU, and half the segments took the
+    // texture matrix from 35.5 to 23.2 k vector-steps/s; the real form gains 1.7 % - within the noise)
+    if (streamed) share = 1;
+    const int waves = std::max(bdg::kSweepWaves, per_cu * sys->num_cus * bdg::kSweepWaves / std::max(1, share));
+    // (launches side by side: the count that fills the share of the slots - 26 against 25 segments is the 2 % the model says)
+    int n_segs = choose_segments(a.n_cols, a.lx, waves, 2 * depth, 8, share > 1 ? 0.985 : 0.97);
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
     a.n_segs = std::max(1, std::min(n_segs, a.lx / 8));
     a.x_lo = 0;

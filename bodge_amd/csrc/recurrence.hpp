@@ -15,6 +15,7 @@ struct Batch {
     bdg_system* sys = nullptr;
     StreamSet* ss = nullptr;  // stream + vector buffers + dot partials of this batch: the handle itself, or one of its side sets
     int next = 0;             // next recurrence step to launch (advance)
+    int stream_share = 1;     // batches of the call in flight together (set before begin: the sweep plan sizes its segments for it)
     StepPlan plan;
     bdg::StepArgs args{};
     bool real = false;
@@ -133,7 +134,7 @@ struct Batch {
             plan.mode = mode;
             plan.dictionary = true;
             args = bdg::StepArgs{};
-            if (int rc = make_sweep_plan(sys, mode, rl, sweep_depth_for(sys, rl), &splan)) return rc;
+            if (int rc = make_sweep_plan(sys, mode, rl, sweep_depth_for(sys, rl), &splan, stream_share)) return rc;
         } else if (roll) {
             // (as for the sweeps: no one-step plan; the table was seen to fit its LDS budget above)
             plan = StepPlan{};
@@ -785,6 +786,7 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
             Batch& batch = queued[(size_t)index];
             batch.slot = index;
             batch.n_slots = n_batches;
+            batch.stream_share = std::min(n_streams, n_batches - first);  // (a last batch on its own has the GPU to itself)
             const int col = index * width;
             if (int rc = batch.begin(sys, scale, n_steps, std::min(width, n_vectors - col), batch_start(start, col), -1, false,
                                      index - first))
