@@ -209,17 +209,25 @@ def cpu_baseline(system, scale, r_local, kind, seconds):
     # thread sweep; matrix and vectors placed by first touch from the compute threads (NUMA)
     sweep = {}
     best = None
-    for threads in sorted({min(t, usable) for t in (16, 64, 128, usable)}):
+    # (counts up to the CPUs this process may keep busy; two below the quota as well: a quota is CPU time, and the
+    # interpreter's own thread counts against it)
+    # (counts up to the CPUs this process may keep busy; two below the quota as well: a quota is CPU time, and the
+    # interpreter's own thread counts against it.  Each count with the threads bound one per physical core, spread
+    # over the host, and unbound: a GPU box is shared with other tenants' host work, and on it the same configuration
+    # has measured anything between 130 and 1100 steps/s within a minute (profiles/r03_cpu_probe.log) - the
+    # baseline is the best of the lot.)
+    for threads in sorted({max(1, min(t, usable)) for t in (16, 64, 128, usable, usable - 2)}):
         cheb_c.set_threads(threads)
-        rate, steps, _ = cheb_c.time_recurrence(bsr, scale, start, seconds=max(1.5, short / 2), real=real, numa=True)
-        sweep[str(threads)] = rate
-        if best is None or rate > best[0]:
-            best = (rate, steps, threads)
+        for pin in (True, False):
+            rate, steps, _ = cheb_c.time_recurrence(bsr, scale, start, seconds=max(1.5, short / 3), real=real, numa=True, pin=pin)
+            sweep[f"{threads}{' bound' if pin else ''}"] = rate
+            if best is None or rate > best[0]:
+                best = (rate, steps, threads, pin)
     gbps = best[0] / r_local * cheb_c.step_bytes(bsr, r_local, real) / 1e9
     extra = {"c_openmp_thread_sweep_steps_per_s": sweep, "c_openmp_achieved_GBps": gbps}
     if real:
         cheb_c.set_threads(best[2])
-        extra["c_openmp_complex128_steps_per_s"] = cheb_c.time_recurrence(bsr, scale, start, seconds=short / 2, numa=True)[0]
+        extra["c_openmp_complex128_steps_per_s"] = cheb_c.time_recurrence(bsr, scale, start, seconds=short / 2, numa=True, pin=best[3])[0]
     # the numpy/scipy restatement the parity tests use: one core, its variants, and the whole host
     # (P forked workers with one vector each on the shared matrix, P = physical cores, BASELINE.md §5 ii)
     extra["scipy_bsr_1core_steps_per_s"] = cheb_ref.time_recurrence(bsr, scale, r_local, seconds=short / 2, kind=kind)[0]
@@ -237,9 +245,9 @@ def cpu_baseline(system, scale, r_local, kind, seconds):
         "kind": "port",
         "sample": f"{best[1]} timed block-steps of the same {r_local} vectors on the same H: C + OpenMP "
                   f"restatement (oracle/cheb_c.c), {'float64' if real else 'complex128'} arithmetic, best of "
-                  f"{sorted(int(t) for t in sweep)} threads = {best[2]} (host: {logical} logical cores, {usable} usable by this "
-                  f"process - affinity mask and cgroup quota; threads unpinned, pages of matrix and vectors placed by first touch from the compute "
-                  f"threads; {gbps:.0f} GB/s of algorithmic traffic)",
+                  f"{list(sweep)} thread configurations = {best[2]} threads{', bound one per physical core spread over the host' if best[3] else ', unbound'} "
+                  f"(host: {logical} logical cores, {usable} usable by this process - affinity mask and cgroup quota; pages of "
+                  f"matrix and vectors placed by first touch from the compute threads; {gbps:.0f} GB/s of algorithmic traffic)",
         "other_cpu_variants": extra,
     }
 

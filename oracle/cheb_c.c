@@ -13,6 +13,8 @@
  * Build: gcc -O3 -mavx2 -mfma -fopenmp -shared -fPIC (oracle/cheb_c.py:build; no -march=native,
  * the object travels from the build container to the GPU box's host).
  */
+#define _GNU_SOURCE
+#include <sched.h>
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
@@ -42,6 +44,48 @@ void cheb_c_copy_rows(int64_t nb, const int64_t* row_begin /* nb + 1 byte offset
 }
 
 int cheb_c_threads(void) { return omp_get_max_threads(); }
+
+/*
+ * Thread placement for the timed baseline.  Unpinned, the scheduler may pile the threads of a 16-thread run onto
+ * one or two core complexes of a 256-thread host (measured on the GPU box: 93 to 984 steps/s for 8 to 14 threads
+ * depending on where they landed, scratch/r3_cpu_probe.py) - a memory-bound loop then runs at the bandwidth of those
+ * complexes.  cheb_c_pin_threads binds thread t of the pool to cpus[t] (the caller passes CPUs spread evenly over
+ * the physical cores) and remembers every thread's previous mask; cheb_c_unpin_threads puts the masks back - the
+ * calling Python thread is thread 0 of the pool, and a mask left on it would be inherited by every BLAS thread and
+ * forked worker of the process (why OMP_PROC_BIND is not used).  Returns the number of threads bound.
+ */
+#define CHEB_C_MAX_PINNED 1024
+static cpu_set_t cheb_c_saved_mask[CHEB_C_MAX_PINNED];
+static int cheb_c_saved_count = 0;
+
+int cheb_c_pin_threads(const int* cpus, int n_cpus) {
+    int bound = 0;
+    if (n_cpus <= 0) return 0;
+    cheb_c_saved_count = 0;
+#pragma omp parallel reduction(+ : bound)
+    {
+        const int t = omp_get_thread_num();
+        if (t < CHEB_C_MAX_PINNED && t < n_cpus && sched_getaffinity(0, sizeof(cpu_set_t), &cheb_c_saved_mask[t]) == 0) {
+            cpu_set_t want;
+            CPU_ZERO(&want);
+            CPU_SET(cpus[t], &want);
+            if (sched_setaffinity(0, sizeof(cpu_set_t), &want) == 0) bound = 1;
+        }
+#pragma omp single
+        cheb_c_saved_count = omp_get_num_threads() < CHEB_C_MAX_PINNED ? omp_get_num_threads() : CHEB_C_MAX_PINNED;
+    }
+    return bound;
+}
+
+void cheb_c_unpin_threads(void) {
+    const int count = cheb_c_saved_count;
+#pragma omp parallel
+    {
+        const int t = omp_get_thread_num();
+        if (t < count) (void)sched_setaffinity(0, sizeof(cpu_set_t), &cheb_c_saved_mask[t]);
+    }
+    cheb_c_saved_count = 0;
+}
 
 void cheb_c_set_threads(int n) {
 #ifdef _OPENMP

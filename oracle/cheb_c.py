@@ -50,6 +50,9 @@ def load():
             fn.argtypes = [C.c_int64, i32p, i32p, f64p, C.c_int, C.c_double, f64p, f64p, f64p, f64p]
         _lib.cheb_c_threads.restype = C.c_int
         _lib.cheb_c_set_threads.argtypes = [C.c_int]
+        _lib.cheb_c_pin_threads.restype = C.c_int
+        _lib.cheb_c_pin_threads.argtypes = [C.POINTER(C.c_int), C.c_int]
+        _lib.cheb_c_unpin_threads.restype = None
     return _lib
 
 
@@ -59,6 +62,42 @@ def threads() -> int:
 
 def set_threads(n: int) -> None:
     load().cheb_c_set_threads(int(n))
+
+
+def spread_cpus(count: int) -> list[int]:
+    """`count` CPUs of this process's affinity mask, one per physical core and evenly spaced over them (SMT siblings
+    only once the cores are used up), in the kernel's numbering - which walks package by package, complex by complex."""
+    allowed = sorted(os.sched_getaffinity(0))
+    firsts, rest, seen = [], [], set()
+    for cpu in allowed:
+        try:
+            base = f"/sys/devices/system/cpu/cpu{cpu}/topology/"
+            with open(base + "physical_package_id") as a, open(base + "core_id") as b:
+                key = (a.read().strip(), b.read().strip())
+        except OSError:
+            key = (cpu,)
+        (rest if key in seen else firsts).append(cpu)
+        seen.add(key)
+    pool = firsts if count <= len(firsts) else firsts + rest
+    count = min(count, len(pool))
+    return [pool[(i * len(pool)) // count] for i in range(count)]
+
+
+class pinned_threads:
+    """Context: the OpenMP threads bound one per CPU of `spread_cpus(threads())`, previous masks restored on exit
+    (the calling thread's included)."""
+
+    def __enter__(self):
+        lib = load()
+        cpus = spread_cpus(threads())
+        self.cpus = cpus
+        array = (C.c_int * len(cpus))(*cpus)
+        self.bound = lib.cheb_c_pin_threads(array, len(cpus))
+        return self
+
+    def __exit__(self, *exc):
+        load().cheb_c_unpin_threads()
+        return False
 
 
 def _p(a, t):
@@ -134,8 +173,13 @@ def step_bytes(bsr, n_vectors: int, real: bool) -> float:
     return (16 * element + 4) * bsr.indices.size + 4.0 * (bsr.shape[0] // 4 + 1) + 3 * element * bsr.shape[0] * n_vectors
 
 
-def time_recurrence(bsr, scale, start, seconds: float = 8.0, real: bool = False, warmup: int = 2, numa: bool = False):
-    """(vector_steps_per_second, block_steps_timed, threads) of the OpenMP recurrence on this host."""
+def time_recurrence(bsr, scale, start, seconds: float = 8.0, real: bool = False, warmup: int = 2, numa: bool = False,
+                    pin: bool = False):
+    """(vector_steps_per_second, block_steps_timed, threads) of the OpenMP recurrence on this host.
+    `pin`: threads bound one per core, spread evenly over the host, for the duration of the call."""
+    if pin:
+        with pinned_threads():
+            return time_recurrence(bsr, scale, start, seconds, real, warmup, numa)
     run = Recurrence(bsr, start, real, numa=numa)
     run.step(1.0 / scale)
     done, t0 = 0, None
