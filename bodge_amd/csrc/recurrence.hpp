@@ -771,6 +771,13 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
     }
 
     HIP_TRY(hipSetDevice(sys->device));
+    if (n_streams > 1 && !streams_env) {
+        // a side set is four more vector buffers (up to 256 B per site each): only where the device has the room
+        size_t free_bytes = 0, total_bytes = 0;
+        HIP_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
+        const bool have = (int)sys->side_sets.size() >= n_streams - 1 && sys->side_sets[0]->vec_a.count > 0;
+        if (!have && (double)free_bytes < 1.25 * (n_streams - 1) * 4.0 * 256.0 * (double)sys->ncols + (64 << 20)) n_streams = 1;
+    }
     while ((int)sys->side_sets.size() < n_streams - 1) {
         auto side = std::make_unique<StreamSet>();
         HIP_TRY(hipStreamCreateWithFlags(&side->stream, hipStreamNonBlocking));
