@@ -592,7 +592,7 @@ def test_stencil_kernels_step_aside_when_the_block_table_exceeds_lds(api, solver
 
 
 @pytest.mark.parametrize("sweep", ["0", "1"])
-def test_batches_of_one_call_enqueued_back_to_back_change_no_bit(api, solver_cls, knobs, sweep):
+def test_batches_of_one_call_enqueued_back_to_back_change_no_bit(api, solver_cls, knobs, block_storage, sweep):
     """A call with more vectors than one launch carries is cut into batches; whole matrices enqueue
     them back to back (own timing events, own piece of the pinned result buffer) and wait once.
     Same numbers as one batch at a time, for random and for unit starts, ragged last batch included."""
@@ -601,13 +601,28 @@ def test_batches_of_one_call_enqueued_back_to_back_change_no_bit(api, solver_cls
     scale = cheb_ref.spectral_bound(bsr)
     rows = np.arange(0, 4 * 64 * 48, 97)[:70]  # 70 unit vectors: two batches of the one-step kernels
     knobs.set("BODGE_AMD_SWEEP", sweep)
-    knobs.set("BODGE_AMD_BATCH", "32")
+    if sweep == "0":
+        knobs.set("BODGE_AMD_BATCH", "32")  # (the stencil kernels cut their own batches: one lane group each)
     with solver_cls.from_hamiltonian(system) as dev:
-        queued = dev.dots_random(scale, 7, 27, seed=3), dev.dots_unit(scale, 6, rows)
+        dev.set_lattice_shape((64, 48, 1))
+        queued_random = dev.dots_random(scale, 7, 27, seed=3)
+        side_by_side = dev.perf()
+        queued = queued_random, dev.dots_unit(scale, 6, rows)
         launches = dev.perf()["launches"]
+        # the marching kernels run two batches at a time on two streams (their launches fill each other's idle ends),
+        # the one-step kernels stay on one; the window both streams share is shorter than their summed times
+        marching = sweep == "1" and block_storage == "dictionary"
+        assert (side_by_side["steps_per_launch"] == 3) == marching
+        assert side_by_side["streams"] == (2 if marching else 1), side_by_side
+        assert 0 < side_by_side["window_ms"] and (not marching or side_by_side["window_ms"] < side_by_side["kernel_ms"])
+        knobs.set("BODGE_AMD_STREAMS", "3")
+        three = dev.dots_random(scale, 7, 27, seed=3)
+        assert dev.perf()["streams"] == (3 if marching else 1)  # (the 27 vectors are one batch of the one-step kernels)
+        assert np.array_equal(three[0], queued_random[0]) and np.array_equal(three[1], queued_random[1])
+        knobs.unset("BODGE_AMD_STREAMS")
         knobs.set("BODGE_AMD_NO_BATCH_PIPELINE", "1")
         single = dev.dots_random(scale, 7, 27, seed=3), dev.dots_unit(scale, 6, rows)
-        assert dev.perf()["launches"] == launches
+        assert dev.perf()["launches"] == launches and dev.perf()["streams"] == 1
     for a, b in zip(queued, single):
         assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1])
     ref = cheb_ref.recurrence_dots(bsr, scale, 14, cheb_ref.random_block(bsr.shape[0], 3, range(27), cheb_ref.VEC_RADEMACHER))
