@@ -104,8 +104,13 @@ def _run(seed, n_cases, size, lanczos) -> int:
         # diagonalize
         E, X = system.diagonalize(format="raw")
         w = np.linalg.eigvalsh(dense)
-        wpos = w[w > 0]
-        check(len(E) == len(wpos) and np.abs(np.sort(E) - wpos).max(initial=0) <= 1e-10 * max(1.0, np.abs(w).max()), "diagonalize values", case, f"{tag} {len(E)} vs {len(wpos)}")
+        # (the reference keeps the eigenvalues in (0, inf] - hamiltonian.py:228-231 - so a zero mode is in or out by the
+        # sign of its round-off, there as here: the levels above round-off must agree one by one, zero modes only in number)
+        tol = 1e-10 * max(1.0, np.abs(w).max())
+        Es = np.sort(E)
+        wpos, zero_modes = w[w > tol], int((np.abs(w) <= tol).sum())
+        check(len(Es[Es > tol]) == len(wpos) and np.abs(Es[Es > tol] - wpos).max(initial=0) <= tol and len(Es[Es <= tol]) <= zero_modes,
+              "diagonalize values", case, f"{tag} {len(E)} vs {len(wpos)} + at most {zero_modes} zero modes")
         if len(E):
             res = np.abs(dense @ X - X * E[None, :]).max()
             check(res <= 1e-9 * max(1.0, np.abs(w).max()) and np.isfinite(X).all(), "diagonalize residual", case, f"{tag} {res}")

@@ -62,17 +62,32 @@ def _run(seed, n_cases, size, lanczos) -> int:
         if rng.random() < 0.2: env["BODGE_AMD_SWEEP_SEGMENTS"] = str(int(rng.integers(1, 5)))
         if rng.random() < 0.2: env["BODGE_AMD_SWEEP_ZIGZAG"] = "0"
         if rng.random() < 0.2: env["BODGE_AMD_ALTERNATE"] = "0"
-        disorder_has_dict = True
+        if rng.random() < 0.3: env["BODGE_AMD_STREAMS"] = str(rng.choice([1, 2, 3, 4]))  # batches side by side on that many streams
+        if rng.random() < 0.15: env["BODGE_AMD_KEEP_LAST"] = "1"
+        # a third of the cases start from unit vectors (LDOS): the stencil kernels then advance a band of planes only
+        unit = rng.random() < 0.33
+        if unit:
+            steps = int(rng.integers(1, 40))
+            near = rng.random() < 0.5  # start sites close together (narrow band) or anywhere
+            x0 = int(rng.integers(0, shape[0]))
+            xs = np.clip(x0 + rng.integers(-2, 3, vectors), 0, shape[0] - 1) if near else rng.integers(0, shape[0], vectors)
+            rows = np.array([4 * ((int(x) * shape[1] + int(rng.integers(0, shape[1]))) * shape[2] + int(rng.integers(0, shape[2])))
+                             + int(rng.integers(0, 4)) for x in xs])
         with DeviceSolver(indptr, indices, data) as dev:
             dev.set_lattice_shape(shape)
+            call = (lambda: dev.dots_unit(scale, steps, rows)) if unit else (lambda: dev.dots_random(scale, steps, vectors, seed=case, kind=kind))
             with backend.options(BODGE_AMD_SWEEP="0"):
-                one = dev.dots_random(scale, steps, vectors, seed=case, kind=kind)
+                one = call()
+            if rng.random() < 0.3:  # (leave the buffers full of another run's vectors)
+                with backend.options(BODGE_AMD_SWEEP="1"):
+                    dev.dots_random(scale, 4, 9, seed=1)
             with backend.options(BODGE_AMD_SWEEP="1", **env):
-                got = dev.dots_random(scale, steps, vectors, seed=case, kind=kind)
+                got = call()
                 perf = dev.perf()
         n = 4 * lat.size
-        err = max(np.abs(got[0] - one[0]).max(), np.abs(got[1] - one[1]).max()) / n
-        tag = f"case {case}: {shape} {model} steps={steps} vectors={vectors} kind={kind} {env} -> steps/launch {perf['steps_per_launch']} rolling {perf['rolling']} onsite-streamed {perf['onsite_streamed']}"
+        err = max(np.abs(got[0] - one[0]).max(), np.abs(got[1] - one[1]).max()) / (1.0 if unit else n)
+        tag = (f"case {case}: {shape} {model} steps={steps} vectors={vectors} {'unit' if unit else f'kind={kind}'} {env} -> steps/launch "
+               f"{perf['steps_per_launch']} rolling {perf['rolling']} onsite-streamed {perf['onsite_streamed']} streams {perf['streams']}")
         if not err <= 1e-12:
             failures += 1
             print("FAIL", tag, "err", err, flush=True)
