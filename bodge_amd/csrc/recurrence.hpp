@@ -718,6 +718,8 @@ int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors, int n_st
     return std::min(width, std::max(n_vectors, 1));
 }
 
+constexpr double kSideBySideOneStepLimit = 1.6e6;  // site-vectors per launch up to which one-step batches run side by side
+
 // Single handle (whole matrix, or one slab of a multi-process run with RCCL halos).
 int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, StartSpec start,
                    double* d_out, double* e_out) {
@@ -741,8 +743,11 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
     // in turn: the gaps of one fill with the other's work (1000x1000, two lane groups of 4 vectors: 100.4 -> 112 k
     // vector-steps/s, scratch/r3_two_streams.py).  BODGE_AMD_STREAMS=1..4 (default 2).
     // The marching kernels gain (K7b with 2 lanes per site +13-15 %, with 4 lanes +7 %, streamed on-site blocks +6 %,
-    // K8 on 100^3 +11 %; a third stream adds nothing); the one-step kernels lose 6-9 % (their launches have no idle
-    // ends, two of them only share the caches) and stay on one stream (profiles/r03_streams.log).
+    // K8 on 100^3 +11 %; a third stream adds nothing); the one-step kernels lose 6-9 % on large launches (no idle
+    // ends, two of them only share the caches: profiles/r03_streams.log) and gain on small ones, which leave most of
+    // the GPU empty: 64-vector batches on 32^2 / 64^2 / 100^2 / 140^2 sites +80 / +68 / +32 / +20 %, on 200^2 -9 %
+    // (profiles/r03_small_lattice_streams.log; four streams are worse than two).  They take two streams up to
+    // 1.6 M site-vectors per launch.
     int n_streams = 1;
     const char* streams_env = knob::raw("BODGE_AMD_STREAMS");
     if (pipelined) {
@@ -786,6 +791,12 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
     if (!sys->ev_side) HIP_TRY(hipEventCreateWithFlags(&sys->ev_side, hipEventDisableTiming));
     std::vector<Batch> queued((size_t)n_batches);
     size_t stride0 = 0;
+    // (an error leaves nothing in flight: later calls reuse the streams' buffers)
+    auto drained = [&](int rc) {
+        (void)hipStreamSynchronize(sys->stream);
+        for (auto& side : sys->side_sets) (void)hipStreamSynchronize(side->stream);
+        return rc;
+    };
     for (int first = 0, last = 0; first < n_batches; first = last) {
         const auto t0 = now();
         for (last = first; last < std::min(n_batches, first + n_streams); ++last) {  // (n_streams may drop to 1 below)
@@ -797,10 +808,11 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
             const int col = index * width;
             if (int rc = batch.begin(sys, scale, n_steps, std::min(width, n_vectors - col), batch_start(start, col), -1, false,
                                      index - first))
-                return rc;
+                return drained(rc);
             if (index == 0) {  // one spacing of the result pieces for the whole call: the first batch is the widest
                 stride0 = batch.host_stride;
-                if (!streams_env && !batch.sweep && !batch.roll) n_streams = 1;
+                // one-step kernels: two streams only while one launch leaves the GPU part empty (sites x vectors of a batch)
+                if (!streams_env && !batch.sweep && !batch.roll && (double)sys->ncols * batch.rv > kSideBySideOneStepLimit) n_streams = 1;
                 // the first begin() has built whatever tables the kernels share (on the handle's stream)
                 HIP_TRY(hipEventRecord(sys->ev_side, sys->stream));
                 for (int side = 0; side < n_streams - 1; ++side)
@@ -814,12 +826,12 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
             for (int index = first; index < last; ++index) {
                 Batch& batch = queued[(size_t)index];
                 if (batch.next >= n_steps) continue;
-                if (int rc = batch.advance()) return rc;
+                if (int rc = batch.advance()) return drained(rc);
                 more = true;
             }
         }
         for (int index = first; index < last; ++index)
-            if (int rc = queued[(size_t)index].finish_enqueue()) return rc;
+            if (int rc = queued[(size_t)index].finish_enqueue()) return drained(rc);
         if (trace) fprintf(stderr, "[bdg] batches %d..%d: begin %.3f ms, enqueue %.3f ms\n", first, last - 1, ms(t0, t1), ms(t1, now()));
     }
     HIP_TRY(hipStreamSynchronize(sys->stream));
