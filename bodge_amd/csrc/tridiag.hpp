@@ -66,51 +66,128 @@ __device__ inline T td_block_sum(T value, T* scratch) {
     return total;
 }
 
-// One workgroup.  Step j: (i) finish w of step j-1 from q = B' v  (ii) row j of the lazily updated matrix:
-// d_j and x  (iii) the Householder vector of step j.  v_prev / w / q are indexed by absolute row (>= j),
-// v_new by absolute row (>= j+1).
+// Reflector pairs (v_i, w_i) whose rank-2 update B - v w^H - w v^H has not been applied to the stored matrix yet.
+// Applying every update at once (one read + one write of the trailing block per step) moves 16 B per real element and
+// step; kept pending, a step only READS the block (its product with the new reflector, corrected by 2 P short dot
+// products), and every kTdDefer-th step applies the pending pairs together: (kTdDefer + 1) / kTdDefer reads and 1 / kTdDefer
+// writes per step - LAPACK's blocked sytrd / hetrd (latrd panels), restated for the lazily updated row-major matrix.
+constexpr int kTdDefer = 4;
+
+template <typename T>
+struct TdPending {
+    T* v[kTdDefer];
+    T* w[kTdDefer];
+    int count;  // finished pairs in slots 0 .. count-1
+};
+
+// One workgroup.  Step j: (i) finish w of step j-1 from q = (stored B) v_{j-1}, corrected for the pairs that were
+// pending during that product, and file (v_{j-1}, w_{j-1}) as pending pair `pend.count`  (ii) row j of the matrix with
+// every pending pair applied: d_j and x  (iii) the Householder vector of step j.  v_unf / q / the pending vectors are
+// indexed by absolute row (>= j), v_new by absolute row (>= j+1).
 // The reflector is also kept for the back-transformation of eigenvectors: v_j(j+2:) in row j of the matrix
 // (dead from here on: later passes touch rows > j only), v_j(j+1) = 1 implied, tau_j in taus[j].
 template <typename T>
-__global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n, int j, const T* __restrict__ v_prev,
-                                                       T* __restrict__ w, const T* __restrict__ q, T* __restrict__ v_new,
+__global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n, int j, const T* __restrict__ v_unf,
+                                                       const T* __restrict__ q, TdPending<T> pend, T* __restrict__ v_new,
                                                        double* __restrict__ d, double* __restrict__ e, TdScalars<T>* scal,
-                                                       T* __restrict__ taus) {
-    __shared__ T scratch[16];
-    __shared__ T shared_scalar;
+                                                       T* __restrict__ taus, T* __restrict__ pend_dots) {
+    __shared__ T scratch[16 * (2 * kTdDefer + 1)];
+    __shared__ T row_v[kTdDefer], row_w[kTdDefer];
     T zero;
     td_set(zero, 0.0, 0.0);
+    const int np = pend.count;          // pairs pending while q was formed
+    const int now = j > 0 ? np + 1 : 0;  // ... and once (v_{j-1}, w_{j-1}) has joined them
     if (j > 0) {
-        // (i) p = tau q;  w = p - (tau / 2) (p^H v) v      over rows j .. n-1 (v_prev[j] = 1)
+        // (i) q_true = q - sum_i [ v_i (w_i^H v) + w_i (v_i^H v) ];  p = tau q_true;  w = p - (tau / 2) (p^H v) v   over rows j .. n-1
         const T tau = scal->tau;
+        // (w_i^H v and v_i^H v for the pairs i < np: left behind by the step that made v - see (iii))
+        T dots[2 * kTdDefer];
+#pragma unroll
+        for (int k = 0; k < 2 * kTdDefer; ++k) dots[k] = k < 2 * np ? pend_dots[k] : zero;
+        T* w_out = pend.w[np];
+        T* v_out = pend.v[np];
         T dot = zero;
-        for (int r = j + threadIdx.x; r < n; r += blockDim.x) dot = td_add(dot, td_mul(td_conj(td_mul(tau, q[r])), v_prev[r]));
+        for (int r = j + threadIdx.x; r < n; r += blockDim.x) {
+            T qt = q[r];
+#pragma unroll
+            for (int i = 0; i < kTdDefer; ++i)
+                if (i < np) qt = td_sub(qt, td_add(td_mul(pend.v[i][r], dots[2 * i]), td_mul(pend.w[i][r], dots[2 * i + 1])));
+            const T p = td_mul(tau, qt);
+            w_out[r] = p;  // (finished below)
+            dot = td_add(dot, td_mul(td_conj(p), v_unf[r]));
+        }
         dot = td_block_sum(dot, scratch);
         T half_tau;
         td_set(half_tau, -0.5 * td_re(tau), -0.5 * td_im(tau));
         const T alpha2 = td_mul(half_tau, dot);
-        for (int r = j + threadIdx.x; r < n; r += blockDim.x) w[r] = td_add(td_mul(tau, q[r]), td_mul(alpha2, v_prev[r]));
+        for (int r = j + threadIdx.x; r < n; r += blockDim.x) {
+            const T x = v_unf[r];
+            w_out[r] = td_add(w_out[r], td_mul(alpha2, x));
+            v_out[r] = x;
+        }
         __syncthreads();
     }
-    // (ii) row j with the pending update B'(j, c) = B(j, c) - v_j conj(w_c) - w_j conj(v_c)
+    // (ii) row j with every pending update: B'(j, c) = B(j, c) - sum_i [ v_i[j] conj(w_i[c]) + w_i[j] conj(v_i[c]) ]
+    if (threadIdx.x < kTdDefer && (int)threadIdx.x < now) {
+        row_v[threadIdx.x] = pend.v[threadIdx.x][j];
+        row_w[threadIdx.x] = pend.w[threadIdx.x][j];
+    }
+    __syncthreads();
     auto entry = [&](int c) {
         T value = a[(size_t)j * n + c];
-        if (j > 0) value = td_sub(value, td_add(td_mul(v_prev[j], td_conj(w[c])), td_mul(w[j], td_conj(v_prev[c]))));
+#pragma unroll
+        for (int i = 0; i < kTdDefer; ++i)
+            if (i < now) value = td_sub(value, td_add(td_mul(row_v[i], td_conj(pend.w[i][c])), td_mul(row_w[i], td_conj(pend.v[i][c]))));
         return value;
     };
     if (threadIdx.x == 0) d[j] = td_re(entry(j));
     const int m = n - j - 1;
     if (m == 0) return;
-    // (iii) x_c = conj(B'(j, c)), c = j+1 .. n-1;  alpha = x_{j+1}
+    // (iii) x_c = conj(B'(j, c)), c = j+1 .. n-1;  alpha = x_{j+1}.  The same loop takes w_i^H x and v_i^H x of the
+    // pending pairs (their entries are loaded for the row anyway): what step j+1 corrects q with.
+    T sums[2 * kTdDefer + 1];  // [2 i] = w_i^H x, [2 i + 1] = v_i^H x over c >= j+2, [2 K] = |x|^2
+#pragma unroll
+    for (int k = 0; k < 2 * kTdDefer + 1; ++k) sums[k] = zero;
     double norm2 = 0.0;
     for (int c = j + 2 + threadIdx.x; c < n; c += blockDim.x) {
-        const T x = td_conj(entry(c));
+        T value = a[(size_t)j * n + c];
+        T wc[kTdDefer], vc[kTdDefer];
+#pragma unroll
+        for (int i = 0; i < kTdDefer; ++i)
+            if (i < now) {
+                wc[i] = td_conj(pend.w[i][c]);
+                vc[i] = td_conj(pend.v[i][c]);
+                value = td_sub(value, td_add(td_mul(row_v[i], wc[i]), td_mul(row_w[i], vc[i])));
+            }
+        const T x = td_conj(value);
         v_new[c] = x;  // (scaled below)
         norm2 += td_abs2(x);
+#pragma unroll
+        for (int i = 0; i < kTdDefer; ++i)
+            if (i < now) {
+                sums[2 * i] = td_add(sums[2 * i], td_mul(wc[i], x));
+                sums[2 * i + 1] = td_add(sums[2 * i + 1], td_mul(vc[i], x));
+            }
     }
-    T packed;
-    td_set(packed, norm2, 0.0);
-    norm2 = td_re(td_block_sum(packed, scratch));
+    td_set(sums[2 * kTdDefer], norm2, 0.0);
+    {   // wave sums of the 2 `now` + 1 values in use, one row of `scratch` per wave; every thread adds up |x|^2, thread k
+        // (below) the k-th dot product: fixed order, bit reproducible
+        constexpr int N = 2 * kTdDefer + 1;
+        const int lane = threadIdx.x & (kWave - 1), wave = threadIdx.x / kWave;
+#pragma unroll
+        for (int k = 0; k < N; ++k)
+            if (k < 2 * now || k == N - 1)
+                for (int off = kWave / 2; off >= 1; off >>= 1) sums[k] = td_add(sums[k], td_shfl(sums[k], off));
+        __syncthreads();  // (scratch may still be read from the sum in (i))
+        if (lane == 0)
+#pragma unroll
+            for (int k = 0; k < N; ++k)
+                if (k < 2 * now || k == N - 1) scratch[wave * N + k] = sums[k];
+        __syncthreads();
+        double total = 0.0;
+        for (int w = 0; w < (int)blockDim.x / kWave; ++w) total += td_re(scratch[w * N + N - 1]);
+        norm2 = total;
+    }
     const T alpha = td_conj(entry(j + 1));
     if (norm2 == 0.0 && td_im(alpha) == 0.0) {  // nothing to annihilate: H = I
         if (threadIdx.x == 0) {
@@ -119,6 +196,8 @@ __global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n,
             taus[j] = zero;
             td_set(v_new[j + 1], 1.0, 0.0);
         }
+        if ((int)threadIdx.x < 2 * now)  // v = e_{j+1}; tau = 0 makes the next w vanish whatever these are
+            pend_dots[threadIdx.x] = td_conj((threadIdx.x & 1) ? pend.v[threadIdx.x >> 1][j + 1] : pend.w[threadIdx.x >> 1][j + 1]);
         __syncthreads();  // (every thread has read row j by now)
         for (int c = j + 2 + threadIdx.x; c < n; c += blockDim.x) a[(size_t)j * n + c] = zero;
         return;
@@ -143,61 +222,107 @@ __global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n,
         taus[j] = tau;
         td_set(v_new[j + 1], 1.0, 0.0);
     }
-    (void)shared_scalar;
+    // v = (1, scale x): w_i^H v = conj(w_i[j+1]) + scale (w_i^H x)
+    if ((int)threadIdx.x < 2 * now) {
+        const int k = threadIdx.x;
+        T total = zero;
+        for (int w = 0; w < (int)blockDim.x / kWave; ++w) total = td_add(total, scratch[w * (2 * kTdDefer + 1) + k]);
+        const T head = td_conj((k & 1) ? pend.v[k >> 1][j + 1] : pend.w[k >> 1][j + 1]);
+        pend_dots[k] = td_add(head, td_mul(scale, total));
+    }
 }
 
-// Trailing block rows / columns j+1 .. n-1: apply the pending update of step j-1, store, multiply by v_new.
-// One wave per row; q[r] = sum_c B'(r, c) v_new[c].  16 bytes per lane and access: a complex entry, or two
-// real ones (n = 4 nb is even, so rows start 16-byte aligned and only the first column of an odd j+1 stands alone).
-template <typename T>
-__device__ inline T td_updated(T value, bool pending, T vr, T wr, T wc, T vc) {
-    if (pending) value = td_sub(value, td_add(td_mul(vr, td_conj(wc)), td_mul(wr, td_conj(vc))));
-    return value;
-}
+// Trailing block rows / columns j+1 .. n-1: q[r] = sum_c B(r, c) v_new[c] with the stored B.  P = 0: read only.
+// P > 0: the P pending pairs are applied first and the block stored (they then count as applied).  One wave per row;
+// 16 bytes per lane and access: a complex entry, or two real ones (n = 4 nb is even, so rows start 16-byte aligned
+// and only the first column of an odd j+1 stands alone).
+// A wave takes ROWS consecutive rows at a time: the chunk of the pending vectors (2 P + 1 loads of 16 B per lane)
+// then serves that many rows - with one row per wave the pass that applies four pairs moved four times the matrix
+// bytes through L2 for the vectors alone (196 us per pass at n = 10^4 against 168 with four rows).  The read-only and
+// one-pair passes keep one row per wave: more waves in flight (53 against 79 us).
+constexpr int td_rows_for(int pending) { return pending >= 4 ? 4 : pending >= 2 ? 2 : 1; }
 
-template <typename T>
-__global__ __launch_bounds__(256) void td_fused_pass(T* __restrict__ a, int n, int j, const T* __restrict__ v_prev,
-                                                     const T* __restrict__ w_prev, const T* __restrict__ v_new,
+template <typename T, int P, int ROWS = td_rows_for(P)>
+__global__ __launch_bounds__(256) void td_fused_pass(T* __restrict__ a, int n, int j, TdPending<T> pend, const T* __restrict__ v_new,
                                                      T* __restrict__ q) {
     const int lane = threadIdx.x & (kWave - 1);
-    const int rows_per_pass = gridDim.x * (blockDim.x / kWave);
-    const bool pending = j > 0;
-    for (int r = j + 1 + blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave; r < n; r += rows_per_pass) {
-        T vr, wr;
-        td_set(vr, 0.0, 0.0);
-        td_set(wr, 0.0, 0.0);
-        if (pending) vr = v_prev[r], wr = w_prev[r];
-        T acc;
-        td_set(acc, 0.0, 0.0);
-        T* row = a + (size_t)r * n;
+    const int waves = gridDim.x * (blockDim.x / kWave);
+    const int wave_id = blockIdx.x * (blockDim.x / kWave) + threadIdx.x / kWave;
+    for (int r0 = j + 1 + wave_id * ROWS; r0 < n; r0 += waves * ROWS) {
+        T vr[ROWS][kTdDefer], wr[ROWS][kTdDefer], acc[ROWS];
+        T* row[ROWS];
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            const int r = min(r0 + k, n - 1);  // (rows past the end repeat the last one and are not stored)
+            row[k] = a + (size_t)r * n;
+            td_set(acc[k], 0.0, 0.0);
+#pragma unroll
+            for (int i = 0; i < kTdDefer; ++i) {
+                td_set(vr[k][i], 0.0, 0.0);
+                td_set(wr[k][i], 0.0, 0.0);
+                if (i < P) vr[k][i] = pend.v[i][r], wr[k][i] = pend.w[i][r];
+            }
+        }
+        const int live = min(ROWS, n - r0);
         if constexpr (sizeof(T) == sizeof(double)) {
             int c0 = j + 1;
             if (c0 & 1) {  // lone first column
                 if (lane == 0) {
-                    const T value = td_updated(row[c0], pending, vr, wr, w_prev[c0], v_prev[c0]);
-                    if (pending) row[c0] = value;
-                    acc = td_mul(value, v_new[c0]);
+#pragma unroll
+                    for (int k = 0; k < ROWS; ++k)
+                        if (k < live) {
+                            T value = row[k][c0];
+#pragma unroll
+                            for (int i = 0; i < P; ++i) value -= vr[k][i] * pend.w[i][c0] + wr[k][i] * pend.v[i][c0];
+                            if (P > 0) row[k][c0] = value;
+                            acc[k] = value * v_new[c0];
+                        }
                 }
                 ++c0;
             }
             for (int c = c0 + 2 * lane; c < n; c += 2 * kWave) {  // (n even: c + 1 < n)
-                double2 pair = *reinterpret_cast<const double2*>(row + c);
-                const double2 wc = *reinterpret_cast<const double2*>(w_prev + c), vc = *reinterpret_cast<const double2*>(v_prev + c);
+                double2 wc[kTdDefer], vc[kTdDefer];
+#pragma unroll
+                for (int i = 0; i < P; ++i) {
+                    wc[i] = *reinterpret_cast<const double2*>(pend.w[i] + c);
+                    vc[i] = *reinterpret_cast<const double2*>(pend.v[i] + c);
+                }
                 const double2 vn = *reinterpret_cast<const double2*>(v_new + c);
-                pair.x = td_updated(pair.x, pending, vr, wr, wc.x, vc.x);
-                pair.y = td_updated(pair.y, pending, vr, wr, wc.y, vc.y);
-                if (pending) *reinterpret_cast<double2*>(row + c) = pair;
-                acc = fma(pair.x, vn.x, fma(pair.y, vn.y, acc));
+#pragma unroll
+                for (int k = 0; k < ROWS; ++k)
+                    if (k < live) {
+                        double2 pair = *reinterpret_cast<const double2*>(row[k] + c);
+#pragma unroll
+                        for (int i = 0; i < P; ++i) {
+                            pair.x -= vr[k][i] * wc[i].x + wr[k][i] * vc[i].x;
+                            pair.y -= vr[k][i] * wc[i].y + wr[k][i] * vc[i].y;
+                        }
+                        if (P > 0) *reinterpret_cast<double2*>(row[k] + c) = pair;
+                        acc[k] = fma(pair.x, vn.x, fma(pair.y, vn.y, acc[k]));
+                    }
             }
         } else {
             for (int c = j + 1 + lane; c < n; c += kWave) {
-                const T value = td_updated(row[c], pending, vr, wr, w_prev[c], v_prev[c]);
-                if (pending) row[c] = value;
-                acc = td_add(acc, td_mul(value, v_new[c]));
+                T wc[kTdDefer], vc[kTdDefer];
+#pragma unroll
+                for (int i = 0; i < P; ++i) wc[i] = td_conj(pend.w[i][c]), vc[i] = td_conj(pend.v[i][c]);
+                const T vn = v_new[c];
+#pragma unroll
+                for (int k = 0; k < ROWS; ++k)
+                    if (k < live) {
+                        T value = row[k][c];
+#pragma unroll
+                        for (int i = 0; i < P; ++i) value = td_sub(value, td_add(td_mul(vr[k][i], wc[i]), td_mul(wr[k][i], vc[i])));
+                        if (P > 0) row[k][c] = value;
+                        acc[k] = td_add(acc[k], td_mul(value, vn));
+                    }
             }
         }
-        for (int off = kWave / 2; off >= 1; off >>= 1) acc = td_add(acc, td_shfl(acc, off));
-        if (lane == 0) q[r] = acc;
+#pragma unroll
+        for (int k = 0; k < ROWS; ++k) {
+            for (int off = kWave / 2; off >= 1; off >>= 1) acc[k] = td_add(acc[k], td_shfl(acc[k], off));
+            if (lane == 0 && k < live) q[r0 + k] = acc[k];
+        }
     }
 }
 
@@ -319,7 +444,9 @@ __global__ __launch_bounds__(64) void td_inverse_iteration(const double* __restr
                 x[i] = (double)(h >> 11) * (2.0 / 9007199254740992.0) - 1.0;
             }
             __syncthreads();
-            for (int iteration = 0; iteration < 3; ++iteration) {
+            // (five solves, dstein's MAXITS: three left one vector in ~250 random periodic lattices with 1e-7 of a level
+            // 4e-5 |T| away - residual 4e-11, overlap 4e-8; scratch/r3_cluster_diag.py)
+            for (int iteration = 0; iteration < 5; ++iteration) {
                 double norm2 = 0.0;
                 for (int i = lane; i < n; i += kWave) norm2 += x[i] * x[i];
                 norm2 = td_wave_sum(norm2);
@@ -600,7 +727,7 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
     const int64_t n = 4 * sys->nb;
     if (n > 46000) return fail(BDG_EINVAL, "dense path limited to 4*nb <= 46000");
     hipStream_t st = sys->stream;
-    DeviceBuffer<T> a, vectors, taus, y, partial;  // vectors: v[2], w, q (n each)
+    DeviceBuffer<T> a, vectors, taus, y, partial;  // vectors: v[2], q, pending v / w (n each)
     DeviceBuffer<double> diag;                    // d, e, e^2, eigenvalues (n each)
     DeviceBuffer<double> zt, scratch;             // tridiagonal eigenvectors, LU work space
     DeviceBuffer<bdg::TdCluster> clusters_dev;
@@ -608,31 +735,54 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
     DeviceBuffer<bdg::TdScalars<T>> scal;
     auto body = [&]() -> int {
         if (int rc = a.reserve((size_t)n * n)) return rc;
-        if (int rc = vectors.reserve((size_t)4 * n)) return rc;
+        constexpr int kVectors = 4 + 2 * bdg::kTdDefer;  // (the last one holds the 2 K dot products handed from step to step)
+        if (int rc = vectors.reserve((size_t)kVectors * n)) return rc;
         if (int rc = taus.reserve((size_t)n)) return rc;
         if (int rc = diag.reserve((size_t)4 * n)) return rc;
         if (int rc = scal.reserve(1)) return rc;
         HIP_TRY(hipMemsetAsync(a.ptr, 0, sizeof(T) * n * n, st));
-        HIP_TRY(hipMemsetAsync(vectors.ptr, 0, sizeof(T) * 4 * n, st));
+        HIP_TRY(hipMemsetAsync(vectors.ptr, 0, sizeof(T) * kVectors * n, st));
         HIP_TRY(hipMemsetAsync(taus.ptr, 0, sizeof(T) * n, st));
         HIP_TRY(hipMemsetAsync(diag.ptr, 0, sizeof(double) * 4 * n, st));
         HIP_TRY(hipMemsetAsync(scal.ptr, 0, sizeof(bdg::TdScalars<T>), st));
         scatter_for_tridiagonal(sys, a.ptr, st);
         T* v[2] = {vectors.ptr, vectors.ptr + n};
-        T* w = vectors.ptr + 2 * n;
-        T* q = vectors.ptr + 3 * n;
+        T* q = vectors.ptr + 2 * n;
+        bdg::TdPending<T> pend{};
+        for (int i = 0; i < bdg::kTdDefer; ++i) {
+            pend.v[i] = vectors.ptr + (size_t)(3 + i) * n;
+            pend.w[i] = vectors.ptr + (size_t)(3 + bdg::kTdDefer + i) * n;
+        }
+        pend.count = 0;
+        T* pend_dots = vectors.ptr + (size_t)(3 + 2 * bdg::kTdDefer) * n;
+        // Deferring costs the one-workgroup vector kernel ~8 us more per step (corrections of q and of row j by the pending
+        // pairs) and saves passes over the block: it pays from n ~ 5000 (n = 3600: 128 against 100 ms, n = 10^4: 1.26 against
+        // 1.58 s).  BODGE_AMD_EIGH_DEFER=1..4 overrides (1 = apply every update in the next pass).
+        int defer = n >= 5000 ? bdg::kTdDefer : 1;
+        if (const char* env = knob::raw("BODGE_AMD_EIGH_DEFER")) defer = std::clamp(atoi(env), 1, bdg::kTdDefer);
         double* d = diag.ptr;
         double* e = diag.ptr + n;
         for (int64_t j = 0; j < n; ++j) {
-            T* v_prev = v[(j + 1) & 1];  // made at step j-1
+            T* v_unf = v[(j + 1) & 1];  // made at step j-1; its w is finished by this step's vector kernel
             T* v_new = v[j & 1];
-            bdg::td_vector_step<T><<<1, 1024, 0, st>>>(a.ptr, (int)n, (int)j, v_prev, w, q, v_new, d, e, scal.ptr, taus.ptr);
+            bdg::td_vector_step<T><<<1, 1024, 0, st>>>(a.ptr, (int)n, (int)j, v_unf, q, pend, v_new, d, e, scal.ptr, taus.ptr, pend_dots);
+            if (j > 0) ++pend.count;  // (v_{j-1}, w_{j-1}) joined the pending pairs
             if (j + 1 < n) {
                 const int64_t rows = n - j - 1;
-                const unsigned grid = (unsigned)std::min<int64_t>(4096, (rows + 3) / 4);
-                bdg::td_fused_pass<T><<<grid, 256, 0, st>>>(a.ptr, (int)n, (int)j, v_prev, w, v_new, q);
+                const int apply = pend.count >= defer ? pend.count : 0;  // apply them all, or read only
+                const int per_block = 4 * bdg::td_rows_for(apply);       // rows a workgroup of four waves takes at a time
+                const unsigned grid = (unsigned)std::min<int64_t>(4096, (rows + per_block - 1) / per_block);
+                switch (apply) {
+                    case 0: bdg::td_fused_pass<T, 0><<<grid, 256, 0, st>>>(a.ptr, (int)n, (int)j, pend, v_new, q); break;
+                    case 1: bdg::td_fused_pass<T, 1><<<grid, 256, 0, st>>>(a.ptr, (int)n, (int)j, pend, v_new, q); break;
+                    case 2: bdg::td_fused_pass<T, 2><<<grid, 256, 0, st>>>(a.ptr, (int)n, (int)j, pend, v_new, q); break;
+                    case 3: bdg::td_fused_pass<T, 3><<<grid, 256, 0, st>>>(a.ptr, (int)n, (int)j, pend, v_new, q); break;
+                    default: bdg::td_fused_pass<T, 4><<<grid, 256, 0, st>>>(a.ptr, (int)n, (int)j, pend, v_new, q); break;
+                }
+                if (apply) pend.count = 0;
             }
         }
+        static_assert(bdg::kTdDefer == 4, "the switch above lists the pass kernels for 0..4 pending pairs");
         HIP_TRY(hipGetLastError());
         std::vector<double> host((size_t)2 * n);
         HIP_TRY(hipMemcpyAsync(host.data(), diag.ptr, sizeof(double) * 2 * n, hipMemcpyDeviceToHost, st));
