@@ -116,6 +116,13 @@ def test_config3_1000x1000_512_moments_full_length_against_cpu_on_the_same_vecto
     (d, e), perf = _with_env(solver, {}, scale, moments // 2, vectors, seed=0)
     # (two batches of 4 vectors; per batch 4 chunks of 63 steps = 21 sweeps each, and 3 + 1 steps at the end)
     assert perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == 2 and perf["launches"] == 2 * (4 * 21 + 2)
+    # ... the two batches side by side on two streams: they share a window shorter than their summed launch times,
+    # and the launches moved less than full launches would (no reads in the first sweep, no stores in the last)
+    assert perf["streams"] == 2 and 0 < perf["window_ms"] < perf["kernel_ms"]
+    assert 0.9 * perf["launches"] * perf["bytes_per_launch"] < perf["bytes_moved"] < perf["launches"] * perf["bytes_per_launch"]
+    (d1s, e1s), perf1 = _with_env(solver, {"BODGE_AMD_STREAMS": "1"}, scale, moments // 2, vectors, seed=0)
+    # (one stream cuts 52 x-segments instead of 26: the workgroups' partial sums group differently, round-off only)
+    assert perf1["streams"] == 1 and np.abs(d1s - d).max() <= 1e-13 * n and np.abs(e1s - e).max() <= 1e-13 * n
     # ... its two-step sibling ...
     (d2s, e2s), perf2 = _with_env(solver, {"BODGE_AMD_SWEEP_STEPS": "2"}, scale, moments // 2, vectors, seed=0)
     assert perf2["steps_per_launch"] == 2 and perf2["launches"] == 2 * (moments // 4)
@@ -267,6 +274,11 @@ def test_config4_100cubed_dwave_256_moments_full_length_whole_and_slabs_against_
     f_ref = chebyshev.free_energy_series(chebyshev.dots_to_moments(d_ref, e_ref).mean(axis=1), scale, temperature)
     with DeviceSolver.from_hamiltonian(system) as whole:
         mono = whole.dots_random(scale, moments // 2, vectors, seed=4)
+        # two lane groups of 8 vectors side by side on two streams (K8 with 4 lanes per site): the first four are the same vectors
+        wide = whole.dots_random(scale, moments // 2, 16, seed=4)
+        wide_perf = whole.perf()
+    assert wide_perf["rolling"] == 1 and wide_perf["streams"] == 2 and wide_perf["lanes_per_row"] == 4 and wide_perf["launches"] == moments
+    assert np.abs(wide[0][:, :vectors] - d_ref).max() <= 1e-12 * n and np.abs(wide[1][:, :vectors] - e_ref).max() <= 1e-12 * n
     with SlabGroup.from_hamiltonian(system, 8) as group:
         split = group.dots_random(scale, moments // 2, vectors, seed=4)
         # slabs of 12 / 13 whole planes: the rolling stencil kernel, neighbours' boundary planes read in place
