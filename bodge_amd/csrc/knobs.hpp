@@ -19,6 +19,7 @@
 //     BODGE_AMD_EIGH=jacobi|tridiagonal|rocsolver|evd|evj|ev   dense solver route (default: Jacobi up to 512 rows, own
 //                                            tridiagonalisation route above);  BODGE_AMD_EIGH_REAL=0  complex arithmetic for a real matrix
 //     BODGE_AMD_EIGH_DEFER=1..4              reflector pairs kept pending in the tridiagonalisation (default 4 from 5000 rows, else 1)
+//     BODGE_AMD_EIGH_CHUNKS=cap[,rows]       row chunks of a back-transformation pass: at most `cap` (default 48) of at least `rows` rows (64)
 //     BODGE_AMD_ONSITE_STREAM=0              (read at upload) no bond-only dictionary + on-site stream for matrices with > 256 distinct blocks
 //     BODGE_AMD_NO_DIAGONAL_BLOCKS           withhold the "diagonal as a 4x4 matrix" flag of dictionary blocks (read at upload)
 //   launch shape and memory hints

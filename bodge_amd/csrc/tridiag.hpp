@@ -31,6 +31,8 @@ __device__ inline double td_mul(double a, double b) { return a * b; }
 __device__ inline double2 td_mul(double2 a, double2 b) {
     return make_double2(fma(a.x, b.x, -a.y * b.y), fma(a.x, b.y, a.y * b.x));
 }
+// (a real scalar times a pair of reals: the back-transformation of a real matrix walks two columns of Z per thread)
+__device__ inline double2 td_mul(double a, double2 b) { return make_double2(a * b.x, a * b.y); }
 __device__ inline double td_add(double a, double b) { return a + b; }
 __device__ inline double2 td_add(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 __device__ inline double td_sub(double a, double b) { return a - b; }
@@ -607,17 +609,19 @@ __global__ __launch_bounds__(256) void td_reflector_gram(const T* __restrict__ a
 }
 
 // column sums of the first group, on Z as it comes from the inverse iteration: partial[chunk][i][c]
-template <typename T>
-__global__ __launch_bounds__(256) void td_reflect_sums(const T* __restrict__ a, int n, int hi, int count, const T* __restrict__ z,
-                                                       int ld, int n_vec, int row0, int rows_per_chunk, T* __restrict__ partial) {
+// Z = the type a thread handles of a row of Z: T itself, or for real matrices double2 = two adjacent real columns
+// (16-byte accesses; n_vec and ld then count pairs).
+template <typename T, typename Z>
+__global__ __launch_bounds__(256) void td_reflect_sums(const T* __restrict__ a, int n, int hi, int count, const Z* __restrict__ z,
+                                                       int ld, int n_vec, int row0, int rows_per_chunk, Z* __restrict__ partial) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_vec) return;
     const int r0 = row0 + blockIdx.y * rows_per_chunk, r1 = min(n, r0 + rows_per_chunk);
-    T acc[kTdGroup];
+    Z acc[kTdGroup];
 #pragma unroll
     for (int i = 0; i < kTdGroup; ++i) td_set(acc[i], 0.0, 0.0);
     for (int r = r0; r < r1; ++r) {
-        const T value = z[(size_t)r * ld + c];
+        const Z value = z[(size_t)r * ld + c];
 #pragma unroll
         for (int i = 0; i < kTdGroup; ++i)
             if (i < count) acc[i] = td_add(acc[i], td_mul(td_conj(td_reflector_entry(a, n, hi - i, r)), value));
@@ -629,20 +633,20 @@ __global__ __launch_bounds__(256) void td_reflect_sums(const T* __restrict__ a, 
 // The group hi, hi-1, ... (count of them) applied to rows row0 .. n-1 (row0 = hi - count + 2) and the sums of the next
 // group (next_hi = hi - count, next_count reflectors) taken on the result; the rows next_row0 .. row0 - 1 that only the
 // next group touches are added by chunk 0.
-template <typename T>
+template <typename T, typename Z>
 __global__ __launch_bounds__(256) void td_reflect_group(const T* __restrict__ a, int n, int hi, int count, const T* __restrict__ taus,
-                                                        const T* __restrict__ cross, T* __restrict__ z, int ld, int n_vec,
-                                                        int row0, int rows_per_chunk, int summed_chunks, const T* __restrict__ partial,
-                                                        int next_count, int next_row0, T* __restrict__ next_partial) {
+                                                        const T* __restrict__ cross, Z* __restrict__ z, int ld, int n_vec,
+                                                        int row0, int rows_per_chunk, int summed_chunks, const Z* __restrict__ partial,
+                                                        int next_count, int next_row0, Z* __restrict__ next_partial) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= n_vec) return;
-    T g[kTdGroup], acc[kTdGroup];
+    Z g[kTdGroup], acc[kTdGroup];
 #pragma unroll
     for (int i = 0; i < kTdGroup; ++i) {
         td_set(g[i], 0.0, 0.0);
         td_set(acc[i], 0.0, 0.0);
         if (i < count) {
-            T s;
+            Z s;
             td_set(s, 0.0, 0.0);
             for (int chunk = 0; chunk < summed_chunks; ++chunk) s = td_add(s, partial[((size_t)chunk * kTdGroup + i) * n_vec + c]);
 #pragma unroll
@@ -654,7 +658,7 @@ __global__ __launch_bounds__(256) void td_reflect_group(const T* __restrict__ a,
     const int next_hi = hi - count;
     if (next_count > 0 && blockIdx.y == 0)
         for (int r = next_row0; r < row0; ++r) {  // rows below this group's reach
-            const T value = z[(size_t)r * ld + c];
+            const Z value = z[(size_t)r * ld + c];
 #pragma unroll
             for (int i = 0; i < kTdGroup; ++i)
                 if (i < next_count) acc[i] = td_add(acc[i], td_mul(td_conj(td_reflector_entry(a, n, next_hi - i, r)), value));
@@ -665,7 +669,7 @@ __global__ __launch_bounds__(256) void td_reflect_group(const T* __restrict__ a,
     constexpr int kRows = 8;
     int r = r0;
     for (; r + kRows <= r1; r += kRows) {
-        T value[kRows];
+        Z value[kRows];
 #pragma unroll
         for (int k = 0; k < kRows; ++k) value[k] = z[(size_t)(r + k) * ld + c];
 #pragma unroll
@@ -682,7 +686,7 @@ __global__ __launch_bounds__(256) void td_reflect_group(const T* __restrict__ a,
                 if (i < next_count) acc[i] = td_add(acc[i], td_mul(td_conj(td_reflector_entry(a, n, next_hi - i, r + k)), value[k]));
     }
     for (; r < r1; ++r) {
-        T value = z[(size_t)r * ld + c];
+        Z value = z[(size_t)r * ld + c];
 #pragma unroll
         for (int i = 0; i < kTdGroup; ++i)
             if (i < count) value = td_sub(value, td_mul(td_reflector_entry(a, n, hi - i, r), g[i]));
@@ -701,9 +705,13 @@ __global__ void td_widen(const double* __restrict__ in, double2* __restrict__ ou
     for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
         out[i] = make_double2(in[i], 0.0);
 }
-__global__ void td_widen(const double* __restrict__ in, double* __restrict__ out, int64_t count) {
-    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < count; i += (int64_t)gridDim.x * blockDim.x)
-        out[i] = in[i];
+// (real: rows padded to an even number of columns - `ld` - so that a thread of the back-transformation takes two
+// columns with one 16-byte access; the padding column is zero)
+__global__ void td_widen(const double* __restrict__ in, double* __restrict__ out, int64_t rows, int64_t n_vec, int64_t ld) {
+    for (int64_t i = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; i < rows * ld; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t r = i / ld, c = i - r * ld;
+        out[i] = c < n_vec ? in[r * n_vec + c] : 0.0;
+    }
 }
 
 // Y (n x n_vec, row-major: eigenvectors of B = conj(H) as columns) -> out[m][i] = conj(Y[i][m]) complex,
@@ -867,20 +875,32 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
         HIP_TRY(hipStreamSynchronize(st));  // (the host lists leave scope; errors of the kernels surface here)
         scratch.release();
         // ---- back-transformation Y = H_0 H_1 ... H_{n-2} Z, last reflector first
-        if (int rc = y.reserve((size_t)n * n_vec)) return rc;
-        bdg::td_widen<<<4096, 256, 0, st>>>(zt.ptr, y.ptr, n * n_vec);
+        // real matrices: Z as rows of column PAIRS (double2), complex ones: of complex entries
+        constexpr bool kPairs = sizeof(T) == sizeof(double);
+        using Z = double2;
+        const int64_t ld = kPairs ? n_vec + (n_vec & 1) : n_vec;      // columns per row of y, in units of T
+        const int64_t z_cols = kPairs ? ld / 2 : n_vec, z_ld = z_cols;  // ... and in units of Z
+        if (int rc = y.reserve((size_t)n * ld)) return rc;
+        if constexpr (kPairs) bdg::td_widen<<<4096, 256, 0, st>>>(zt.ptr, y.ptr, n, n_vec, ld);
+        else bdg::td_widen<<<4096, 256, 0, st>>>(zt.ptr, y.ptr, n * n_vec);
+        Z* yz = reinterpret_cast<Z*>(y.ptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
         zt.release();
         // kTdGroup reflectors per pass over Z; the pass of a group also takes the column sums of the next one
-        constexpr int kChunks = 16, kGroup = bdg::kTdGroup;
-        if (int rc = partial.reserve((size_t)2 * kChunks * kGroup * n_vec + (size_t)kGroup * kGroup)) return rc;
-        T* part[2] = {partial.ptr, partial.ptr + (size_t)kChunks * kGroup * n_vec};
-        T* cross = partial.ptr + (size_t)2 * kChunks * kGroup * n_vec;
-        const unsigned col_blocks = (unsigned)((n_vec + 255) / 256);
+        constexpr int kChunks = 96, kGroup = bdg::kTdGroup;  // (row chunks of a pass: with column pairs a pass has half the column blocks)
+        if (int rc = partial.reserve((size_t)2 * kChunks * kGroup * ld + (size_t)kGroup * kGroup)) return rc;
+        Z* part[2] = {reinterpret_cast<Z*>(partial.ptr), reinterpret_cast<Z*>(partial.ptr + (size_t)kChunks * kGroup * ld)};
+        T* cross = partial.ptr + (size_t)2 * kChunks * kGroup * ld;
+        const unsigned col_blocks = (unsigned)((z_cols + 255) / 256);
+        int chunk_cap = 48, chunk_rows = 64;  // row chunks of a pass (BODGE_AMD_EIGH_CHUNKS=cap[,rows]: A/B runs)
+        if (const char* env = knob::raw("BODGE_AMD_EIGH_CHUNKS")) {
+            chunk_cap = std::clamp(atoi(env), 1, kChunks);
+            if (const char* comma = strchr(env, ',')) chunk_rows = std::max(1, atoi(comma + 1));
+        }
         auto chunks_of = [&](int64_t row0, int* n_chunks, int* rows_per_chunk) {
             const int64_t rows = n - row0;
-            *n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(kChunks, (rows + 63) / 64));
+            *n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(chunk_cap, (rows + chunk_rows - 1) / chunk_rows));
             *rows_per_chunk = (int)((rows + *n_chunks - 1) / *n_chunks);
         };
         if (n >= 2) {
@@ -889,8 +909,8 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
             int64_t row0 = hi - count + 2;
             int n_chunks = 0, rows_per_chunk = 0;
             chunks_of(row0, &n_chunks, &rows_per_chunk);
-            bdg::td_reflect_sums<T><<<dim3(col_blocks, (unsigned)n_chunks), 256, 0, st>>>(a.ptr, (int)n, (int)hi, count, y.ptr, (int)n_vec,
-                                                                                     (int)n_vec, (int)row0, rows_per_chunk, part[0]);
+            bdg::td_reflect_sums<T, Z><<<dim3(col_blocks, (unsigned)n_chunks), 256, 0, st>>>(a.ptr, (int)n, (int)hi, count, yz, (int)z_ld,
+                                                                                        (int)z_cols, (int)row0, rows_per_chunk, part[0]);
             int flip = 0, written_chunks = n_chunks;
             while (hi >= 0) {
                 const int64_t next_hi = hi - count;
@@ -898,8 +918,8 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
                 const int64_t next_row0 = next_count > 0 ? next_hi - next_count + 2 : row0;
                 bdg::td_reflector_gram<T><<<1, 256, 0, st>>>(a.ptr, (int)n, (int)hi, count, cross);
                 chunks_of(row0, &n_chunks, &rows_per_chunk);
-                bdg::td_reflect_group<T><<<dim3(col_blocks, (unsigned)n_chunks), 256, 0, st>>>(
-                    a.ptr, (int)n, (int)hi, count, taus.ptr, cross, y.ptr, (int)n_vec, (int)n_vec, (int)row0, rows_per_chunk,
+                bdg::td_reflect_group<T, Z><<<dim3(col_blocks, (unsigned)n_chunks), 256, 0, st>>>(
+                    a.ptr, (int)n, (int)hi, count, taus.ptr, cross, yz, (int)z_ld, (int)z_cols, (int)row0, rows_per_chunk,
                     written_chunks, part[flip], next_count, (int)next_row0, part[flip ^ 1]);
                 written_chunks = n_chunks;
                 flip ^= 1;
@@ -912,7 +932,7 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
         // eigenvectors of H = conj(B): contiguous per vector, conjugated
         if (int rc = emitted.reserve((size_t)n * n_vec)) return rc;
         const dim3 tiles((unsigned)((n + 31) / 32), (unsigned)((n_vec + 31) / 32));
-        bdg::td_emit_vectors<T><<<tiles, dim3(32, 8), 0, st>>>(y.ptr, (int)n, (int)n_vec, (int)n_vec, emitted.ptr);
+        bdg::td_emit_vectors<T><<<tiles, dim3(32, 8), 0, st>>>(y.ptr, (int)n, (int)ld, (int)n_vec, emitted.ptr);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(z_out, emitted.ptr, sizeof(double2) * n * n_vec, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
