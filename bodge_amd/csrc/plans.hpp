@@ -504,7 +504,7 @@ struct SweepPlan {
 // BODGE_AMD_SWEEP=0 never, =1 whenever the matrix qualifies.
 constexpr int64_t kSweepMinSites = 150000;   // 2-D: multi-step sweeps (K7, K7b)
 constexpr int64_t kRollMinSites = 600000;    // 3-D: rolling one-step kernel (K8)
-constexpr int64_t kSweepTwoLaneSites = 450000;  // from here on 2 lanes per site beat 4
+constexpr int64_t kSweepTwoLaneSites = 250000;  // from here on 2 lanes per site beat 4 (two lane groups side by side)
 
 // Stencil table of the matrix (built once per lattice shape).  *kind = 1: 5-point stencil whose
 // planes are lines (2-D lattice: the two-steps-per-sweep kernel applies), 2: 7-point stencil of a
@@ -707,7 +707,12 @@ int sweep_depth_for(const bdg_system* sys, int lanes) {
 // slots with 2 lanes, 10 of 16 with 4: less recomputed halo per useful site) at the price of
 // shorter x-segments.  Measured on 1000x1000, 8 real vectors: 2 lanes 106.6 k vector-steps/s,
 // 4 lanes 99.9 k (profiles/r02_sweep_experiments.log).
-int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane, bool unit_start = false) {
+// With the lane groups of a call side by side on two streams (run_recurrence) 2 lanes win from 2.5e5 sites (500^2, 16
+// vectors: 386 against 368 k vector-steps/s; 400^2: 468 against 537 k), and a call of ONE 4-lane group (5-8 real
+// vectors) is better cut into two 2-lane groups from the smallest swept lattices on (400^2 / 500^2 / 600^2, 8 vectors:
+// 466 / 388 / 271 k against 447 / 319 / 240 k; profiles/r03_lanes_midsize.log).  `whole_call`: n_active counts the
+// call, which batch_width then cuts; a batch (begin) takes the lanes that hold it.
+int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane, bool unit_start = false, bool whole_call = false) {
     if (sys->onsite_streamed) return 4;  // 16 site slots per wave: the ring of on-site records fits beside the rows
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_LANES")) {
         const int forced = atoi(env);
@@ -716,7 +721,9 @@ int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane, bool unit
     // unit start vectors run inside a band of planes for most of their steps: launches of few planes, bound by the
     // length of a wave's march and not by bytes - all the vectors of a lane group in one launch, then
     if (unit_start && n_active > 2 * per_lane) return 4;
-    return sys->nb >= kSweepTwoLaneSites ? 2 : 4;  // small lattices: more work per launch matters more
+    if (sys->nb >= kSweepTwoLaneSites) return 2;
+    if (sys->nb >= kSweepMinSites && n_active <= (whole_call ? 4 : 2) * per_lane) return 2;
+    return 4;  // small lattices: more work per launch matters more
 }
 
 // Unit start vectors (LDOS) spread by one plane per step.  Inside a narrow band of planes a stencil launch is as long

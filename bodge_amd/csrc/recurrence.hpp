@@ -706,7 +706,7 @@ int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors, int n_st
     if (sys->lanes_override == 0 && sweep_wanted(sys, false, &stencil_kind) == BDG_OK && stencil_kind != 0 &&
         !(unit && !(start.stencil >= 0 ? start.stencil != 0 : unit_run_wants_stencil(sys, start.rows, n_vectors, n_steps)))) {
         const int per_lane = real ? 2 : 1;
-        const int lanes = stencil_kind == 1 ? sweep_lanes_for(sys, n_vectors, per_lane, unit) : roll_lanes_for(sys, n_vectors, per_lane);
+        const int lanes = stencil_kind == 1 ? sweep_lanes_for(sys, n_vectors, per_lane, unit, true) : roll_lanes_for(sys, n_vectors, per_lane);
         return std::min(lanes * per_lane, std::max(n_vectors, 1));  // one lane group per launch
     }
     // (slabs: the widest slab of the run decides, so that every rank cuts the same batches)

@@ -289,7 +289,7 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
                                       (8, per_group, {"BODGE_AMD_SWEEP_STEPS": "2"}),  # cheb_sweep (two steps) instead of cheb_sweep3
                                       (7, 3, {"BODGE_AMD_SWEEP_STEPS": "2", "BODGE_AMD_SWEEP_ZIGZAG": "0"}),
                                       (6, 5, {"BODGE_AMD_SWEEP_LANES": "1"}),  # 60-position windows, 2 real / 1 complex vector per launch
-                                      (5, 3, {"BODGE_AMD_SWEEP_LANES": "2"}),  # 26-position windows (3 steps), the default from 4.5e5 sites
+                                      (5, 3, {"BODGE_AMD_SWEEP_LANES": "2"}),  # 26-position windows (3 steps), the default from 2.5e5 sites
                                       (7, 5, {"BODGE_AMD_SWEEP_LANES": "2", "BODGE_AMD_SWEEP_SEGMENTS": "2"}),
                                       (5, 5, {"BODGE_AMD_SWEEP_LANES": "2", "BODGE_AMD_SWEEP_STEPS": "2"}),  # 28-position windows
                                       (6, 7, {"BODGE_AMD_SWEEP_LANES": "4"}),  # (K8: 14-position windows, 8 real vectors per launch)
@@ -310,7 +310,7 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
                 knobs.unset(key)
             stencil = is_stencil and block_storage == "dictionary"  # (the stencil forms read the block dictionary)
             swept, rolled = stencil and not three_d, stencil and three_d
-            lanes = int(extra.get("BODGE_AMD_SWEEP_LANES", 4)) if swept else 4  # (default below 4.5e5 sites: 4 lanes per site)
+            lanes = int(extra.get("BODGE_AMD_SWEEP_LANES", 4)) if swept else 4  # (default below 1.5e5 sites, and below 2.5e5 for calls of more than one lane group: 4 lanes per site)
             if rolled:  # K8: 4 lanes per site, or 2 (30-position windows) for calls of at most 4 real / 2 complex vectors
                 lanes = int(extra["BODGE_AMD_SWEEP_LANES"]) if extra.get("BODGE_AMD_SWEEP_LANES") in ("2", "4") else (2 if vectors <= per_group // 2 else 4)
                 assert perf["lanes_per_row"] in (2, lanes)  # (a ragged last batch of a wide call takes 2)
