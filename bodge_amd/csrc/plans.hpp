@@ -503,6 +503,7 @@ struct SweepPlan {
 // vs 458 k, 500x500 252 k vs 326 k, 700x700 130 k vs 193 k, 1000x1000 57 k vs 104 k.
 // BODGE_AMD_SWEEP=0 never, =1 whenever the matrix qualifies.
 constexpr int64_t kSweepMinSites = 150000;   // 2-D: multi-step sweeps (K7, K7b)
+constexpr int64_t kSweepMinSitesWide = 90000;  // ... for calls of more than one lane group (two streams)
 constexpr int64_t kRollMinSites = 600000;    // 3-D: rolling one-step kernel (K8)
 constexpr int64_t kSweepTwoLaneSites = 250000;  // from here on 2 lanes per site beat 4 (two lane groups side by side)
 
@@ -581,7 +582,11 @@ int ensure_stencil(bdg_system* sys, int* kind) {
 // Should this batch run a stencil form, and which (see ensure_stencil)?  Whole square matrix (or a slab of a
 // same-process group), no per-column scalars; unit start vectors when their band of planes gets wide
 // (unit_run_wants_stencil).
-int sweep_wanted(bdg_system* sys, bool col_scalars, int* kind) {
+// `wide_call`: the call has more vectors than one lane group (run_recurrence): its groups run side by side on two streams,
+// and the multi-step sweeps then beat the one-step kernels from 300 x 300 sites on (16 / 64 vectors: 852 / 880 against
+// 690 / 729 k vector-steps/s; 250 x 250: 919 against 994 k; a single group of 8 vectors wins from ~390^2 only - 350^2:
+// 427 against 466 k, 400^2: 470 against 379 k; profiles/r03_sweep_threshold.log).
+int sweep_wanted(bdg_system* sys, bool col_scalars, int* kind, bool wide_call = false) {
     *kind = 0;
     const char* env = knob::raw("BODGE_AMD_SWEEP");
     if ((env && env[0] == '0') || col_scalars) return BDG_OK;
@@ -592,12 +597,13 @@ int sweep_wanted(bdg_system* sys, bool col_scalars, int* kind) {
     if (slab && (sys->slab_comm || sys->group_rows == 0)) return BDG_OK;
     const bool forced = env && env[0] == '1';
     const int64_t lattice_rows = std::max(sys->nb, sys->group_rows);  // (the size of the lattice, not of the slab, decides)
-    if (!forced && lattice_rows < std::min(kSweepMinSites, kRollMinSites)) return BDG_OK;
+    const int64_t min_2d = wide_call ? kSweepMinSitesWide : kSweepMinSites;
+    if (!forced && lattice_rows < std::min(min_2d, kRollMinSites)) return BDG_OK;
     const char* dict_env = knob::raw("BODGE_AMD_DICT");
     if (dict_env && dict_env[0] == '0') return BDG_OK;
     if (int rc = ensure_stencil(sys, kind)) return rc;
     if (slab && *kind != 2) *kind = 0;  // (2-D multi-step sweeps would need three-plane halos: not built)
-    if (!forced && lattice_rows < (*kind == 2 ? kRollMinSites : kSweepMinSites)) *kind = 0;
+    if (!forced && lattice_rows < (*kind == 2 ? kRollMinSites : min_2d)) *kind = 0;
     return BDG_OK;
 }
 
@@ -845,6 +851,7 @@ struct StartSpec {
     int vec_kind = 0;
     const int64_t* rows = nullptr;  // host
     int stencil = -1;  // unit starts: 1 / 0 = the call has decided for / against the stencil kernels, -1 = each batch decides
+    bool wide_call = false;  // the call has more vectors than one lane group (its batches run side by side)
 };
 
 void dots_to_moments(const double* d, const double* e, int n_steps, int n_vectors, double* mu) {

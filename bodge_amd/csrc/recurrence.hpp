@@ -95,7 +95,7 @@ struct Batch {
         sweep = roll = false;
         int stencil_kind = 0;
         if (sys->lanes_override == 0 && rl == 4)
-            if (int rc = sweep_wanted(sys, col_scalars, &stencil_kind)) return rc;
+            if (int rc = sweep_wanted(sys, col_scalars, &stencil_kind, start.wide_call)) return rc;
         // (the stencil kernels keep the whole block table in LDS; a matrix with many distinct blocks in a
         // wide arithmetic mode can exceed that: it takes the one-step kernels, which then stream its blocks)
         if ((size_t)sys->n_unique * mode.stride * sizeof(double2) > table_limit(sys)) stencil_kind = 0;
@@ -703,7 +703,7 @@ int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors, int n_st
                       !(real_env && real_env[0] == '0');
     int stencil_kind = 0;
     const bool unit = start.kind == StartKind::Unit;
-    if (sys->lanes_override == 0 && sweep_wanted(sys, false, &stencil_kind) == BDG_OK && stencil_kind != 0 &&
+    if (sys->lanes_override == 0 && sweep_wanted(sys, false, &stencil_kind, start.wide_call) == BDG_OK && stencil_kind != 0 &&
         !(unit && !(start.stencil >= 0 ? start.stencil != 0 : unit_run_wants_stencil(sys, start.rows, n_vectors, n_steps)))) {
         const int per_lane = real ? 2 : 1;
         const int lanes = stencil_kind == 1 ? sweep_lanes_for(sys, n_vectors, per_lane, unit, true) : roll_lanes_for(sys, n_vectors, per_lane);
@@ -730,6 +730,7 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
     auto ms = [](auto a, auto b) { return std::chrono::duration<double, std::milli>(b - a).count(); };
     if (start.kind == StartKind::Unit)  // one decision for all the batches of the call (their widths follow from it)
         start.stencil = unit_run_wants_stencil(sys, start.rows, n_vectors, n_steps) ? 1 : 0;
+    start.wide_call = n_vectors > 8;
     const int width = batch_width(sys, start, n_vectors, n_steps);
     // Batches are enqueued back to back and waited for once (whole matrices; a slab's batches are
     // paced by its halo exchange anyway): the GPU does not idle while the host turns a batch around.
