@@ -213,9 +213,9 @@ def cpu_baseline(system, scale, r_local, kind, seconds):
     # interpreter's own thread counts against it)
     # (counts up to the CPUs this process may keep busy; two below the quota as well: a quota is CPU time, and the
     # interpreter's own thread counts against it.  Each count with the threads bound one per physical core, spread
-    # over the host, and unbound: a GPU box is shared with other tenants' host work, and on it the same configuration
-    # has measured anything between 130 and 1100 steps/s within a minute (profiles/r03_cpu_probe.log) - the
-    # baseline is the best of the lot.)
+    # over the cores of ONE memory node (cheb_c.spread_cpus: 16 threads over both sockets of a GPU box run at 178
+    # steps/s, over one node at 1070-1080, profiles/r03_numa_probe.log), and unbound (where the scheduler put them:
+    # anything between 130 and 1100 steps/s, profiles/r03_cpu_probe.log) - the baseline is the best of the lot.)
     def thread_sweep(tag):
         nonlocal best
         for threads in sorted({max(1, min(t, usable)) for t in (16, 64, 128, usable, usable - 2)}):
@@ -254,7 +254,7 @@ def cpu_baseline(system, scale, r_local, kind, seconds):
         "kind": "port",
         "sample": f"{best[1]} timed block-steps of the same {r_local} vectors on the same H: C + OpenMP "
                   f"restatement (oracle/cheb_c.c), {'float64' if real else 'complex128'} arithmetic, best of "
-                  f"{list(sweep)} thread configurations = {best[2]} threads{', bound one per physical core spread over the host' if best[3] else ', unbound'} "
+                  f"{list(sweep)} thread configurations = {best[2]} threads{', bound one per physical core, spread over the cores of one memory node' if best[3] else ', unbound'} "
                   f"(host: {logical} logical cores, {usable} usable by this process - affinity mask and cgroup quota; pages of "
                   f"matrix and vectors placed by first touch from the compute threads; {gbps:.0f} GB/s of algorithmic traffic)",
         "other_cpu_variants": extra,

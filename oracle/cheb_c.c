@@ -50,7 +50,8 @@ int cheb_c_threads(void) { return omp_get_max_threads(); }
  * one or two core complexes of a 256-thread host (measured on the GPU box: 93 to 984 steps/s for 8 to 14 threads
  * depending on where they landed, scratch/r3_cpu_probe.py) - a memory-bound loop then runs at the bandwidth of those
  * complexes.  cheb_c_pin_threads binds thread t of the pool to cpus[t] (the caller passes CPUs spread evenly over
- * the physical cores) and remembers every thread's previous mask; cheb_c_unpin_threads puts the masks back - the
+ * the physical cores of one memory node: spread over both sockets 16 threads are six times slower, cheb_c.py) and
+ * remembers every thread's previous mask; cheb_c_unpin_threads puts the masks back - the
  * calling Python thread is thread 0 of the pool, and a mask left on it would be inherited by every BLAS thread and
  * forked worker of the process (why OMP_PROC_BIND is not used).  Returns the number of threads bound.
  */
