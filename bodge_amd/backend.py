@@ -49,6 +49,9 @@ class Perf(C.Structure):
         ("streams", C.c_int32),
         ("bytes_moved", C.c_double),
         ("window_ms", C.c_double),
+        ("sweeps", C.c_int64),
+        ("persistent", C.c_int32),
+        ("groups_per_launch", C.c_int32),
     ]
 
 

@@ -515,6 +515,9 @@ int bdg_destroy(bdg_system* sys) {
     sys->stencil.release();
     if (sys->host_dots) (void)hipHostFree(sys->host_dots);
     sys->host_dots = nullptr;
+    if (sys->march_seen) (void)hipHostFree(sys->march_seen);
+    sys->march_seen = nullptr;
+    sys->march_gave_up.release();
     sys->tile_order.release();
     sys->send_rows.release();
     sys->tiles_interior.release();

@@ -84,7 +84,9 @@ struct StreamSet {
     DeviceBuffer<double2> vec_c, vec_d;  // multi-step sweeps: the new levels are written out of place
     DeviceBuffer<double> partial, dots;
     DeviceBuffer<int64_t> rows;
+    DeviceBuffer<unsigned> march_sync;  // cheb_march3: abort word, ticket counters, unit flags (zeroed before every launch)
     void release_set() {
+        march_sync.release();
         vec_a.release();
         vec_b.release();
         vec_c.release();
@@ -104,6 +106,12 @@ struct bdg_system : StreamSet {
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     std::vector<std::unique_ptr<StreamSet>> side_sets;
     hipEvent_t ev_side = nullptr;  // recorded on `stream` once a call's shared tables exist: the side streams wait for it
+    // cheb_march3 (one launch per reduction chunk): `march_gave_up` is a device word the launches of a call OR their abort
+    // words into, read back (pinned `march_seen`) with the dot products; once a launch has given up waiting the handle
+    // keeps to one launch per sweep (`march_off`).
+    DeviceBuffer<unsigned> march_gave_up;
+    unsigned* march_seen = nullptr;
+    bool march_off = false;
     int64_t nb = 0, nnzb = 0;
     int64_t ncols = 0;       // block rows of the vector buffers: nb owned + halo
     int64_t row_offset = 0;  // global block row of local row 0 (slab mode)

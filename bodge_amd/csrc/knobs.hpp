@@ -16,6 +16,12 @@
 //     BODGE_AMD_SWEEP_STEPS=2|3              steps per sweep (cheb_sweep / cheb_sweep3)
 //     BODGE_AMD_SWEEP_LANES=1|2|4            lanes per site of the sweep kernels
 //     BODGE_AMD_SWEEP_GEN=0                  write the random start block with the fill kernel instead of making it in the first sweep
+//     BODGE_AMD_MARCH=1|2|3                  cheb_march3 for the three-step sweeps of random-start runs (default 0: one cheb_sweep3 launch per
+//                                            sweep and lane group).  1 = all sweeps of a 63-step chunk in one launch, tasks claimed by ticket,
+//                                            flags between neighbouring units; 3 = the same with a fixed unit per wave (needs the grid
+//                                            resident: gives up after the timeout otherwise); 2 = one launch per sweep for all lane groups
+//     BODGE_AMD_MARCH_TIMEOUT_MS=ms          how long a wave polls its neighbours' flags before the launch is given up (default 2000)
+//     BODGE_AMD_MARCH_SLEEP=4|16|64          s_sleep between two polls;  BODGE_AMD_MARCH_DEBUG=bits  measurements / tests (sweep.hpp: MarchArgs.debug)
 //     BODGE_AMD_EIGH=jacobi|tridiagonal|rocsolver|evd|evj|ev   dense solver route (default: Jacobi up to 512 rows, own
 //                                            tridiagonalisation route above);  BODGE_AMD_EIGH_REAL=0  complex arithmetic for a real matrix
 //     BODGE_AMD_EIGH_DEFER=1..4              reflector pairs kept pending in the tridiagonalisation (default 4 from 5000 rows, else 1)

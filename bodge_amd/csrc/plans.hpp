@@ -478,11 +478,37 @@ SweepKernel sweep3_kernel(const ModeInfo& mode, int lanes, bool reverse) {
     return sweep3_kernel_for<ComplexMode>(lanes, reverse);
 }
 
+// cheb_march3: the sweeps of a whole reduction chunk in one launch (sweep.hpp K7c)
+using MarchKernel = void (*)(bdg::MarchArgs);
+template <typename Mode>
+MarchKernel march3_kernel_for(int lanes) {
+    switch (lanes) {
+        case 2: return bdg::cheb_march3<Mode, 2, 0>;
+        case 4: return bdg::cheb_march3<Mode, 4, 0>;
+    }
+    return nullptr;
+}
+MarchKernel march3_kernel(const ModeInfo& mode, int lanes, bool streamed, bool bonds) {
+    if (streamed) {
+        if (!mode.ph || lanes != 4) return nullptr;
+        if (bonds) return mode.real ? bdg::cheb_march3<RealPHMode, 4, 2> : nullptr;
+        return mode.real ? bdg::cheb_march3<RealPHMode, 4, 1> : bdg::cheb_march3<ComplexPHMode, 4, 1>;
+    }
+    switch (mode.id) {
+        case 1: return march3_kernel_for<RealMode>(lanes);
+        case 2: return march3_kernel_for<ComplexPHMode>(lanes);
+        case 3: return march3_kernel_for<RealPHMode>(lanes);
+    }
+    return march3_kernel_for<ComplexMode>(lanes);
+}
+
 struct SweepPlan {
     int lanes = bdg::kSweepLanes;
     int depth = 2;  // recurrence steps per sweep: 2 (cheb_sweep) or 3 (cheb_sweep3)
     SweepKernel kernel = nullptr, kernel_reverse = nullptr;
     SweepKernel kernel_gen = nullptr;  // depth 3: first sweep of a random-start run, t_0 made in registers
+    MarchKernel march = nullptr;       // depth 3: all sweeps of a reduction chunk in one launch (nullptr = not available)
+    int march_grid = 0;                // workgroups of such a launch
     int grid = 0;
     size_t lds_bytes = 0;
     bdg::SweepArgs args{};
@@ -636,6 +662,12 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
         for (SweepKernel k : {plan->kernel, plan->kernel_reverse, plan->kernel_gen})
             if (k) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)plan->lds_bytes));
+    // one launch per chunk: the write-through stores address a buffer through a 32-bit byte offset
+    plan->march = depth == 3 && (size_t)sys->ncols * lanes * 4 * sizeof(double2) < ((size_t)1 << 31) && sys->ncols == sys->nb
+                      ? march3_kernel(mode, lanes, streamed, bonds) : nullptr;
+    if (plan->march && plan->lds_bytes > 64 * 1024)
+        HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan->march), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                    (int)plan->lds_bytes));
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(plan->kernel),
                                                          bdg::kSweepThreads, plan->lds_bytes));
@@ -677,6 +709,10 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     const int64_t units = (int64_t)a.n_cols * a.n_segs;
     const int grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus, (units + bdg::kSweepWaves - 1) / bdg::kSweepWaves);
     plan->grid = std::max(8, (grid + 7) / 8 * 8);
+    // (a chunk in one launch: `share` lane groups are tasks of the same launch - every wave slot of the device)
+    const int march_grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus,
+                                                  (units * std::max(1, share) + bdg::kSweepWaves - 1) / bdg::kSweepWaves);
+    plan->march_grid = std::max(8, (march_grid + 7) / 8 * 8);
     return BDG_OK;
 }
 

@@ -11,6 +11,8 @@ namespace {
 //   begin()  choose kernel + mode, allocate, write t_0 (own rows) and zero t_{-1}
 //   step(n)  one launch of K1 (after the caller has refreshed the halo of t_n)
 //   finish() reduce partials (done per chunk inside step), copy dots to the host
+constexpr int kMarchAborted = -77;  // (internal: a persistent launch gave up waiting - run_recurrence repeats the call sweep by sweep)
+
 struct Batch {
     bdg_system* sys = nullptr;
     StreamSet* ss = nullptr;  // stream + vector buffers + dot partials of this batch: the handle itself, or one of its side sets
@@ -54,6 +56,14 @@ struct Batch {
     // and nothing reads t_{n_steps} (BODGE_AMD_KEEP_LAST=1 stores them all the same, for A/B runs).
     bool discard_last = true;
     double bytes_moved = 0.0;  // algorithmic bytes of the launches made so far (perf.bytes_moved)
+    // cheb_march3: all the sweeps of a reduction chunk in one launch (march_run below).  Up to kMarchGroups batches of a
+    // call are lane groups of the same launches: the first ("leader") owns the stream, the events and the launch count.
+    bool march = false, march_follower = false;
+    int march_levels = 0;           // sweeps per launch: 0 = a whole reduction chunk (persistent, flags between the sweeps), 1 = one
+    bool march_fixed = false;       // persistent launches with a fixed unit per wave instead of tickets
+    int n_sweeps = 0;               // sweeps made so far (the marching direction alternates with them)
+    int64_t sweeps_counted = 0;     // ... for perf.sweeps
+    hipStream_t work_stream = nullptr;  // where this batch's reductions and result copy are enqueued (default: its own stream)
     // one buffer of the batch: what a launch reads for t_n (or t_{n-1}) or writes for one new level
     double vector_bytes() const { return 4.0 * rl * sizeof(double2) * (double)sys->nb; }
     int n_launches = 0;
@@ -149,7 +159,28 @@ struct Batch {
         }
         launch_grid = sweep ? splan.grid : roll ? rplan.grid : plan.grid;
         n_launches = 0;
+        n_sweeps = 0;
+        sweeps_counted = 0;
         bytes_moved = 0.0;
+        work_stream = ss->stream;
+        march_follower = false;
+        // One launch per reduction chunk (cheb_march3) for random start vectors; unit start vectors, which run inside a
+        // band of planes for most of their steps, keep one launch per sweep (their segments change from sweep to sweep).
+        march = sweep && splan.depth == 3 && splan.march != nullptr && !sys->march_off && n_steps >= 4 &&
+                start.kind == StartKind::Random;
+        // BODGE_AMD_MARCH (default 0: measured no faster than one launch per sweep): 1 = a whole chunk per
+        // launch, units claimed by ticket; 3 = the same with a fixed unit per wave (needs the grid resident; falls back after
+        // the timeout otherwise); 2 = one launch per sweep that advances all the lane groups of a pair (no flags)
+        march_levels = 0;
+        march_fixed = false;
+        {
+            const char* env = knob::raw("BODGE_AMD_MARCH");
+            const int kind = env ? atoi(env) : 0;
+            march = march && kind >= 1 && kind <= 3;
+            march_levels = kind == 2 ? 1 : 0;
+            march_fixed = kind == 3;
+        }
+        if (march) launch_grid = splan.args.n_cols * splan.args.n_segs;  // dot partials per (step, unit)
 
         vec_count = (size_t)4 * sys->ncols * rl;  // 16-byte lane payloads
         // t_n and t_{n-1} together beyond the 256 MB Infinity Cache: the write of t_{n+1} and the
@@ -609,6 +640,13 @@ struct Batch {
         ++next;
         return BDG_OK;
     }
+    // A batch prepared for the persistent kernel that runs one launch per sweep after all: partials per workgroup again.
+    void cancel_march() {
+        if (!march) return;
+        march = false;
+        launch_grid = splan.grid;
+        per_step = (size_t)launch_grid * width;
+    }
     // first start / last stop event of the batch (after finish_enqueue): the ends of its launches on its stream
     hipEvent_t first_event() const { return ss->ev_pool[2 * (size_t)ev_base]; }
     hipEvent_t last_event() const { return ss->ev_pool[2 * (size_t)(ev_base + n_chunks - 1) + 1]; }
@@ -617,7 +655,7 @@ struct Batch {
     // accumulate = true adds to what is there (summing the slabs of a group).
     int finish(double* d_out, double* e_out, int ld, int col0, bool accumulate, bool first_batch) {
         if (int rc = finish_enqueue()) return rc;
-        HIP_TRY(hipStreamSynchronize(ss->stream));
+        HIP_TRY(hipStreamSynchronize(work_stream ? work_stream : ss->stream));
         return finish_collect(d_out, e_out, ld, col0, accumulate, first_batch);
     }
     // copy of the batch's dot products to the host, enqueued behind its last reduction
@@ -625,13 +663,23 @@ struct Batch {
         HIP_TRY(hipSetDevice(sys->device));
         // pinned: a pageable target costs ~8 ms on its first use
         HIP_TRY(hipMemcpyAsync(sys->host_dots + (size_t)slot * host_stride, ss->dots.ptr,
-                               (size_t)n_steps * width * sizeof(double), hipMemcpyDeviceToHost, ss->stream));
+                               (size_t)n_steps * width * sizeof(double), hipMemcpyDeviceToHost, work_stream ? work_stream : ss->stream));
         return BDG_OK;
     }
     // after the stream has been waited for
     int finish_collect(double* d_out, double* e_out, int ld, int col0, bool accumulate, bool first_batch) {
         HIP_TRY(hipSetDevice(sys->device));
+        if (march && sys->march_seen && sys->march_seen[0] != 0) {
+            // a wave of a persistent launch gave up waiting for its neighbours (a foreign kernel holding the GPU?):
+            // the vectors are incomplete.  The handle goes back to one launch per sweep and the caller repeats the call.
+            sys->march_seen[0] = 0;
+            (void)hipMemsetAsync(sys->march_gave_up.ptr, 0, sizeof(unsigned), sys->stream);
+            (void)hipStreamSynchronize(sys->stream);
+            sys->march_off = true;
+            return kMarchAborted;
+        }
         const double* host = sys->host_dots + (size_t)slot * host_stride;
+        if (march_follower) n_chunks = 0;  // (the leader of the lane groups holds the events of their launches)
         for (int c = 0; c < n_chunks; ++c) {
             float ms = 0.f;
             HIP_TRY(hipEventElapsedTime(&ms, ss->ev_pool[2 * (ev_base + c)], ss->ev_pool[2 * (ev_base + c) + 1]));
@@ -657,6 +705,8 @@ struct Batch {
                              : roll ? roll_bytes(sys, mode, rl)
                                     : algorithmic_bytes(sys, rv, mode, plan.dictionary);
         p.steps_per_launch = sweep ? splan.depth : 1;
+        p.persistent = march ? 1 : 0;
+        p.sweeps += march ? sweeps_counted : sweep ? n_launches : 0;
         p.rolling = roll ? 1 : 0;
         p.dict_skipped = sys->dict_skipped;
         p.onsite_streamed = sweep && sys->onsite_streamed ? (sys->bonds_streamed ? 2 : 1) : 0;
@@ -666,12 +716,152 @@ struct Batch {
         p.ph_packed = mode.ph ? 1 : 0;
         p.dict_blocks = plan.dictionary ? sys->n_unique : 0;
         p.strip_rows = strip_rows;
-        p.grid = launch_grid;
+        p.grid = march ? splan.march_grid : launch_grid;
         p.lds_bytes = (int32_t)(sweep ? splan.lds_bytes : roll ? rplan.lds_bytes : plan.lds_footprint);
         p.pipelined = plan.pipelined ? 1 : 0;
         return BDG_OK;
     }
 };
+
+// The remaining sweeps of up to kMarchGroups batches of one call (same matrix, same plan, same step count, all at the
+// same step), one cheb_march3 launch per reduction chunk on the first batch's stream.  The batches are lane groups of
+// the same launches; every one keeps its own vector buffers, partials and dot products.
+int march_run(Batch* const* list, int count) {
+    Batch& lead = *list[0];
+    bdg_system* sys = lead.sys;
+    HIP_TRY(hipSetDevice(sys->device));
+    hipStream_t st = lead.ss->stream;
+    const bdg::SweepArgs& geo = lead.splan.args;
+    const int units = geo.n_cols * geo.n_segs;
+    for (int g = 0; g < count; ++g) {
+        Batch& b = *list[g];
+        if (!b.march || b.next != lead.next || b.n_steps != lead.n_steps || b.rl != lead.rl || b.mode.id != lead.mode.id ||
+            b.splan.args.n_segs != geo.n_segs || b.chunk != lead.chunk)
+            return fail(BDG_EINVAL, "lane groups of one persistent launch must share plan and progress");
+        b.march_follower = g > 0;
+        b.work_stream = st;
+        if (g > 0) {  // whatever the group's begin() enqueued on its own stream comes first
+            HIP_TRY(hipEventRecord(sys->ev_side, b.ss->stream));
+            HIP_TRY(hipStreamWaitEvent(st, sys->ev_side, 0));
+        }
+    }
+    const size_t sync_words = (bdg::march_sync_words(units, count) + 3) / 4 * 4;
+    if (int rc = lead.ss->march_sync.reserve(sync_words)) return rc;
+    if (sys->march_gave_up.count == 0) {
+        if (int rc = sys->march_gave_up.reserve(4)) return rc;
+        HIP_TRY(hipMemsetAsync(sys->march_gave_up.ptr, 0, 4 * sizeof(unsigned), st));
+        HIP_TRY(hipHostMalloc(reinterpret_cast<void**>(&sys->march_seen), 4 * sizeof(unsigned), 0));
+        sys->march_seen[0] = 0;
+    }
+    double timeout_ms = 2000.0;
+    if (const char* env = knob::raw("BODGE_AMD_MARCH_TIMEOUT_MS")) timeout_ms = std::max(1.0, atof(env));
+
+    // sweeps per launch: a whole reduction chunk (persistent, flags between the sweeps) or one (no flags, plain stores)
+    const int max_levels = lead.march_levels > 0 ? std::min(lead.march_levels, bdg::kMarchMaxLevels) : bdg::kMarchMaxLevels;
+    while (lead.next < lead.n_steps) {
+        const int n = lead.next;
+        const int chunk_id = n / lead.chunk, in_chunk = n % lead.chunk;
+        const int chunk_end = std::min(lead.n_steps, (chunk_id + 1) * lead.chunk);
+        const int n_end = std::min(chunk_end, n + 3 * max_levels);
+        const int levels = (n_end - n + 2) / 3;
+        if (in_chunk % 3 != 0 || levels > bdg::kMarchMaxLevels) return fail(BDG_EINVAL, "a persistent launch starts at a sweep boundary of its chunk");
+        bdg::MarchArgs m{};
+        m.base = geo;
+        m.base.coef2 = 2.0 / lead.scale;
+        m.base.coef1 = m.base.coef2;
+        m.base.x_lo = 0;
+        m.base.x_hi = geo.lx;
+        if (levels == 1) m.base.stream |= 16;  // (nothing in the launch reads what it writes: plain stores)
+        m.n_groups = count;
+        m.n_levels = levels;
+        m.last_steps = n_end - n - 3 * (levels - 1);
+        m.discard_last = lead.discard_last && n_end == lead.n_steps;
+        m.first_is_start = n == 0;
+        m.gen = n == 0 && lead.gen_start;
+        m.rev0 = lead.alternate ? (lead.n_sweeps & 1) : 0;
+        m.units = units;
+        m.per_step = lead.per_step;
+        m.sync = lead.ss->march_sync.ptr;
+        m.flags_at = (unsigned)(bdg::kMarchCounterWords * (1 + 8 * bdg::kMarchMaxLevels));
+        m.timeout_ticks = (unsigned)std::min(4.0e9, timeout_ms * 1.0e5);
+        m.gave_up = sys->march_gave_up.ptr;
+        m.fixed = lead.march_fixed ? 1 : 0;
+        m.poll_sleep = 64;
+        if (const char* env = knob::raw("BODGE_AMD_MARCH_SLEEP")) m.poll_sleep = atoi(env);
+        if (const char* env = knob::raw("BODGE_AMD_MARCH_DEBUG")) {
+            m.debug = atoi(env);
+            if (m.debug & 4) m.base.stream |= 16;
+        }
+        for (int g = 0; g < count; ++g) {
+            Batch& b = *list[g];
+            bdg::MarchGroup& grp = m.group[g];
+            grp.buf[0] = b.cur;
+            grp.buf[1] = b.prev;
+            grp.buf[2] = b.spare1;
+            grp.buf[3] = b.spare2;
+            grp.partial = b.ss->partial.ptr + (size_t)in_chunk * b.per_step;
+            grp.gen_first_id = b.splan.args.gen_first_id;
+            grp.gen_active = b.splan.args.gen_active;
+            if (b.gen_start != lead.gen_start || b.per_step != lead.per_step)
+                return fail(BDG_EINVAL, "lane groups of one persistent launch must start the same way");
+        }
+        while ((int)lead.ss->ev_pool.size() < 2 * (lead.ev_base + chunk_id + 1)) {
+            hipEvent_t ev = nullptr;
+            HIP_TRY(hipEventCreate(&ev));
+            lead.ss->ev_pool.push_back(ev);
+        }
+        if (in_chunk == 0) HIP_TRY(hipEventRecord(lead.ss->ev_pool[2 * (lead.ev_base + chunk_id)], st));
+        if (levels > 1) HIP_TRY(hipMemsetAsync(m.sync, 0, sync_words * sizeof(unsigned), st));
+        lead.splan.march<<<lead.splan.march_grid, bdg::kBlockThreads, lead.splan.lds_bytes, st>>>(m);
+        HIP_TRY(hipGetLastError());
+        ++lead.n_launches;
+        for (int g = 0; g < count; ++g) {
+            Batch& b = *list[g];
+            for (int level = 0; level < levels; ++level) {  // what step_sweep does per launch
+                const int at = n + 3 * level, now = std::min(3, n_end - at);
+                const bool discard = b.discard_last && at + now == b.n_steps;
+                b.bytes_moved += sweep_bytes(sys, b.mode, b.rl) -
+                                 b.vector_bytes() * ((at == 0 ? 1 : 0) + (at == 0 && b.gen_start ? 1 : 0) + (discard ? 2 : now == 1 ? 1 : 0));
+                double2* old_cur = b.cur;
+                double2* old_prev = b.prev;
+                if (now == 1) {
+                    b.cur = b.spare2;
+                    b.prev = old_cur;
+                    b.spare2 = old_prev;
+                } else {
+                    b.cur = b.spare2;
+                    b.prev = b.spare1;
+                    b.spare1 = old_prev;
+                    b.spare2 = old_cur;
+                }
+            }
+            b.n_sweeps += levels;
+            b.sweeps_counted += levels;
+            b.next = n_end;
+        }
+        if (n_end == chunk_end) {
+            HIP_TRY(hipEventRecord(lead.ss->ev_pool[2 * (lead.ev_base + chunk_id) + 1], st));
+            lead.n_chunks = chunk_id + 1;
+            const int s0 = chunk_id * lead.chunk;
+            for (int g = 0; g < count; ++g) {
+                Batch& b = *list[g];
+                bdg::reduce_partials<<<chunk_end - s0, 256, 0, st>>>(b.ss->partial.ptr, b.ss->dots.ptr + (size_t)s0 * b.width, units,
+                                                                    (int)b.width);
+                HIP_TRY(hipGetLastError());
+            }
+        }
+    }
+    HIP_TRY(hipMemcpyAsync(sys->march_seen, sys->march_gave_up.ptr, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+    if (const char* env = knob::raw("BODGE_AMD_MARCH_DEBUG"); env && (atoi(env) & 8)) {
+        unsigned stats[4] = {0, 0, 0, 0};
+        HIP_TRY(hipMemcpyAsync(stats, sys->march_gave_up.ptr, sizeof stats, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        fprintf(stderr, "[bdg] march: %u tasks, waiting %.2f us and claiming %.2f us per task\n", stats[3],
+                stats[3] ? 0.16 * stats[1] / stats[3] : 0.0, stats[3] ? 0.16 * stats[2] / stats[3] : 0.0);
+        HIP_TRY(hipMemsetAsync(sys->march_gave_up.ptr, 0, sizeof stats, st));
+    }
+    return BDG_OK;
+}
 
 int check_recurrence_args(const void* sys, double scale, int n_steps, int n_vectors, const double* d_out,
                           const double* e_out) {
@@ -721,8 +911,8 @@ int batch_width(bdg_system* sys, const StartSpec& start, int n_vectors, int n_st
 constexpr double kSideBySideOneStepLimit = 1.6e6;  // site-vectors per launch up to which one-step batches run side by side
 
 // Single handle (whole matrix, or one slab of a multi-process run with RCCL halos).
-int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, StartSpec start,
-                   double* d_out, double* e_out) {
+int run_recurrence_once(bdg_system* sys, double scale, int n_steps, int n_vectors, StartSpec start,
+                        double* d_out, double* e_out) {
     if (int rc = check_recurrence_args(sys, scale, n_steps, n_vectors, d_out, e_out)) return rc;
     lanczos_free(sys);
     const bool trace = knob::raw("BODGE_AMD_TRACE") != nullptr;
@@ -763,6 +953,10 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
             if (int rc = batch.begin(sys, scale, n_steps, std::min(width, n_vectors - col), batch_start(start, col), -1))
                 return rc;
             const auto t1 = now();
+            if (batch.march) {
+                Batch* one = &batch;
+                if (int rc = march_run(&one, 1)) return rc;
+            }
             while (batch.next < n_steps)
                 if (int rc = batch.advance()) return rc;
             const auto t2 = now();
@@ -792,6 +986,7 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
     if (!sys->ev_side) HIP_TRY(hipEventCreateWithFlags(&sys->ev_side, hipEventDisableTiming));
     std::vector<Batch> queued((size_t)n_batches);
     size_t stride0 = 0;
+    bool marched = false;
     // (an error leaves nothing in flight: later calls reuse the streams' buffers)
     auto drained = [&](int rc) {
         (void)hipStreamSynchronize(sys->stream);
@@ -822,6 +1017,17 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
             batch.host_stride = stride0;
         }
         const auto t1 = now();
+        // lane groups that take the persistent kernel are tasks of the same launches, on the handle's stream
+        bool all_march = last - first <= bdg::kMarchGroups;
+        for (int index = first; index < last; ++index) all_march = all_march && queued[(size_t)index].march;
+        if (all_march) {
+            Batch* group[bdg::kMarchGroups];
+            for (int index = first; index < last; ++index) group[index - first] = &queued[(size_t)index];
+            if (int rc = march_run(group, last - first)) return drained(rc);
+            marched = true;
+        } else {
+            for (int index = first; index < last; ++index) queued[(size_t)index].cancel_march();
+        }
         for (bool more = true; more;) {
             more = false;
             for (int index = first; index < last; ++index) {
@@ -844,12 +1050,28 @@ int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, St
     float window = 0.f;
     for (int index = 0; index < n_batches; ++index) {
         float t = 0.f;
+        if (queued[(size_t)index].n_chunks == 0) continue;  // (a follower of a persistent launch: its leader has the events)
         HIP_TRY(hipEventElapsedTime(&t, queued[0].first_event(), queued[(size_t)index].last_event()));
         window = std::max(window, t);
     }
     sys->perf.window_ms = window;
-    sys->perf.streams = n_streams;
+    sys->perf.streams = marched ? 1 : n_streams;
+    sys->perf.groups_per_launch = marched ? std::min(n_streams, n_batches) : 1;
     return BDG_OK;
+}
+
+int run_recurrence(bdg_system* sys, double scale, int n_steps, int n_vectors, StartSpec start,
+                   double* d_out, double* e_out) {
+    int rc = run_recurrence_once(sys, scale, n_steps, n_vectors, start, d_out, e_out);
+    if (rc == kMarchAborted) {
+        // a persistent launch gave up waiting (finish_collect has switched the handle to one launch per sweep)
+        (void)hipStreamSynchronize(sys->stream);
+        for (auto& side : sys->side_sets) (void)hipStreamSynchronize(side->stream);
+        if (knob::raw("BODGE_AMD_TRACE")) fprintf(stderr, "[bdg] persistent sweep gave up waiting: the call is repeated one launch per sweep\n");
+        rc = run_recurrence_once(sys, scale, n_steps, n_vectors, start, d_out, e_out);
+    }
+    if (rc == kMarchAborted) return fail(BDG_EDEVICE, "persistent sweep gave up waiting twice");
+    return rc;
 }
 
 // Same-process group of slabs (one handle per slab, on one or several devices of this

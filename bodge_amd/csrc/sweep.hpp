@@ -481,37 +481,398 @@ constexpr int sweep3_onsite_pieces() {
     return sweep3_record_slots<Mode, OS>();
 }
 
-template <typename Mode, int RL, bool REV, bool GEN = false, int OS = 0>
-__global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
-    extern __shared__ double2 lds[];
+// What the wave of a sweep keeps in LDS: the block table, the compact block diagonals behind it, the three hand-over
+// rows of the wave (level 0 plane k, level 1 plane k-1, level 2 plane k-2) and (OS) its ring of on-site records.
+struct Sweep3Lds {
+    double2* table;
+    double2* diag;
+    double2* row_0;
+    double2* row_1;
+    double2* row_2;
+    double2* os_ring;
+};
+
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+constexpr int kRawBufferFlags = 0x00020000;  // raw buffer resource of gfx9 / CDNA: 32-bit data format, no swizzle
+constexpr int kAuxSc1 = 16;                  // cache-policy bits of the raw buffer builtins: sc1 = write-through
+
+// Lane state of the generated start block (GEN): the lane's vector(s) - real modes carry vectors 2r, 2r+1 in
+// (x, y), complex modes vector r.
+struct Sweep3Gen {
+    uint64_t key0 = 0, key1 = 0;
+    bool on0 = false, on1 = false;
+};
+template <typename Mode>
+__device__ inline Sweep3Gen sweep3_gen_keys(uint64_t seed, uint64_t first_id, int active, int r) {
+    Sweep3Gen g;
+    const int v0 = Mode::kVec == 2 ? 2 * r : r;
+    g.on0 = v0 < active;
+    g.on1 = Mode::kVec == 2 && v0 + 1 < active;
+    g.key0 = vector_key(seed, first_id + v0);
+    g.key1 = vector_key(seed, first_id + v0 + 1);
+    return g;
+}
+
+// One unit of a three-step sweep: the wave marches its window `col` through the planes of segment `seg`
+// (`rev`: from the far end back) and adds its dot products to dot1..dot3.  WT: the new planes are stored
+// write-through (cheb_march3, where other workgroups read them later in the same launch).
+// What changes from one sweep to the next (a kernel argument for cheb_sweep3, made per task by cheb_march3): everything
+// else a unit needs stays where the kernel's arguments are - a per-task copy of all of SweepArgs costs registers.
+struct Sweep3Task {
+    const double2* cur;
+    const double2* prev;
+    double2* out1;
+    double2* out2;
+    double coef1;
+    int steps;
+    int discard;
+};
+
+template <typename Mode, int RL, bool GEN, int OS, bool WT>
+__device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task& t, const Sweep3Lds& w, const Sweep3Gen& gen, int lane,
+                                            int seg, int col, bool rev, double (&dot1)[4], double (&dot2)[4], double (&dot3)[4]) {
     constexpr int SLOTS = kWave / RL;
     constexpr int OWNED3 = SLOTS - 6;
-    constexpr int SPB = Mode::kSlotsPerBlock;
     constexpr int STRIDE = Mode::kBlockStride;
     constexpr int RING = sweep3_ring_slots<Mode, OS>(SLOTS);  // LDS slots of the on-site ring (0 without OS)
     constexpr int RSTRIDE = sweep3_record_stride<Mode, OS>();
-    const int lane = threadIdx.x & (kWave - 1);
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    constexpr int DSL = Mode::kDiagSlots;
     const int s = lane / RL;
     const int r = lane % RL;
+    double2* const lds = w.table;
+    double2* const diag = w.diag;
+    double2* const row_0 = w.row_0;
+    double2* const row_1 = w.row_1;
+    double2* const row_2 = w.row_2;
+    [[maybe_unused]] double2* const os_ring = w.os_ring;
+    const double2 zero = make_double2(0.0, 0.0);
+    const size_t nb = (size_t)a.nb;
+    const int steps = t.steps;  // uniform
+    const bool nt_prev = a.stream & 1, nt_cur = a.stream & 4;
+    [[maybe_unused]] const bool nt_store = a.stream & 2;
+    [[maybe_unused]] const uint64_t gen_key0 = gen.key0, gen_key1 = gen.key1;
+    [[maybe_unused]] const bool gen_on0 = gen.on0, gen_on1 = gen.on1;
 
-    // LDS: [table][per wave: three rows of 64 lanes x 4 entries: level 0 plane k, level 1 plane k-1, level 2 plane k-2;
-    //               OS: + ring of three planes of on-site blocks]
+    const int x0 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * seg) / a.n_segs);
+    const int x1 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * (seg + 1)) / a.n_segs);
+    const int p = col * OWNED3 - 3 + s;
+    const bool inside = p >= 0 && p < a.plane;
+    const bool valid = inside || a.wrap_p;  // a ring has no edge: halo slots beyond it hold the far side
+    const int pw = inside ? p : ((p % a.plane) + a.plane) % a.plane;
+    const bool ok1 = valid && s >= 1 && s <= SLOTS - 2;
+    const bool ok2 = valid && s >= 2 && s <= SLOTS - 3;
+    const bool owned = inside && s >= 3 && s <= SLOTS - 4;
+
+    auto act = [&](int k) { return rev ? x0 + x1 - 1 - k : k; };
+    auto ring = [&](int k) { return a.wrap_x ? (k < 0 ? k + a.lx : (k >= a.lx ? k - a.lx : k)) : k; };
+    auto in_lattice = [&](int k) { return a.wrap_x || (act(k) >= 0 && act(k) < a.lx); };
+    auto load_plane = [&](const double2* buf, bool nt, int k, bool wanted, double2 out[4]) {
+        k = ring(act(k));
+        if (wanted && k >= 0 && k < a.lx) {
+            const size_t site = (size_t)k * a.plane + pw;
+#pragma unroll
+            for (int al = 0; al < 4; ++al)
+                out[al] = nt ? load_stream(buf + vslot(al, site, r, nb, RL)) : buf[vslot(al, site, r, nb, RL)];
+        } else {
+#pragma unroll
+            for (int al = 0; al < 4; ++al) out[al] = zero;
+        }
+    };
+    auto store_plane = [&](double2* buf, int k, const double2 v[4]) {
+        if (t.discard) return;  // (uniform: the last sweep of a run)
+        const size_t site = (size_t)act(k) * a.plane + p;
+        if (WT && !(a.stream & 16)) {  // (bit 4: plain stores all the same - measurements only)
+            // write-through (sc1) stores: other workgroups of the same launch read these planes at the next level
+            // (cheb_march3), so they must not linger in this XCD's L2
+            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(buf, 0, (int)(4 * nb * RL * sizeof(double2)), kRawBufferFlags);
+#pragma unroll
+            for (int al = 0; al < 4; ++al)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[al]), rsrc,
+                                                       (int)(vslot(al, site, r, nb, RL) * sizeof(double2)), 0, kAuxSc1);
+        } else {
+#pragma unroll
+            for (int al = 0; al < 4; ++al) {
+                if (nt_store) store_stream(buf + vslot(al, site, r, nb, RL), v[al]);
+                else buf[vslot(al, site, r, nb, RL)] = v[al];
+            }
+        }
+    };
+    // plane k of t_n: read, or (GEN) made from the generator
+    auto cur_plane = [&](int k, bool wanted, double2 out[4]) {
+        if constexpr (GEN) {
+            k = ring(act(k));
+            if (wanted && k >= 0 && k < a.lx) {
+                const uint64_t element = 4 * ((uint64_t)k * a.plane + pw);
+#pragma unroll
+                for (int al = 0; al < 4; ++al) {
+                    if constexpr (Mode::kVec == 2) {
+                        out[al].x = gen_on0 ? start_entry(gen_key0, element + al, 0).x : 0.0;
+                        out[al].y = gen_on1 ? start_entry(gen_key1, element + al, 0).x : 0.0;
+                    } else {
+                        out[al] = gen_on0 ? start_entry(gen_key0, element + al, a.gen_kind) : zero;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int al = 0; al < 4; ++al) out[al] = zero;
+            }
+        } else {
+            load_plane(t.cur, nt_cur, k, wanted, out);
+        }
+    };
+    auto load_ids = [&](int k) {
+        uint2 w = make_uint2(0xFFFFFFFFu, 0xFFu);
+        k = ring(act(k));
+        if (ok1 && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + pw];
+        return w;
+    };
+    auto id_of = [](uint2 w, int slot) { return slot < 4 ? (w.x >> (8 * slot)) & 0xFFu : w.y & 0xFFu; };
+    auto mac = [&](uint2 w, int slot, const double2 x[4], double2 acc[4]) {
+        const unsigned id = id_of(w, slot);
+        if (id == kNoBlock) return;
+#if BDG_COMPACT_DIAG
+        if ((w.y >> (8 + slot)) & 1u) Mode::mac_diag_compact(acc, diag + id * DSL, x);
+#else
+        if ((w.y >> (8 + slot)) & 1u) Mode::mac_diag(acc, lds + id * STRIDE, x);
+#endif
+        else Mode::mac_row(acc, lds + id * STRIDE, x);
+    };
+    auto own_of = [&](const double2* row, double2 out[4]) {
+#pragma unroll
+        for (int be = 0; be < 4; ++be) out[be] = row[SHARE_SLOT(lane, be)];
+    };
+    auto put_own = [&](double2* row, const double2 v[4]) {
+#pragma unroll
+        for (int be = 0; be < 4; ++be) row[SHARE_SLOT(lane, be)] = v[be];
+    };
+    auto wave_sync = [&]() {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    // acc = Σ_offsets block * x in CSR order (-P, -1, 0, +1, +P); `before` / `after` are the planes
+    // behind / ahead of the march, `mid` the lane's own entries, `row` the hand-over row of the level
+    // step j (1-based) runs on plane k-j+1 and is needed on planes [x0-(steps-j), x1+(steps-j))
+    const int k_first = x0 - (steps - 1), k_last = x1 + steps - 2;
+    [[maybe_unused]] auto ring_entry = [&](int kk) { return os_ring + ((kk - k_first) % 3) * (RING / 3); };
+
+    // (`kk` = marching index of the plane the step works on: selects the ring entry of its on-site blocks)
+    auto apply = [&](uint2 w, const double2 before[4], const double2* row, const double2 mid[4],
+                     const double2 after[4], double2 acc[4], [[maybe_unused]] int kk) {
+        double2 x[4];
+        [[maybe_unused]] const double2* rec = nullptr;
+        if constexpr (OS != 0) rec = ring_entry(kk) + s * RSTRIDE;
+        // one bond block times the neighbour's entries: from the table, or (OS = 2) from the site's record
+        auto bond = [&](int slot, const double2 v[4]) {
+            if constexpr (OS == 2) {
+                if (id_of(w, slot) != kNoBlock) Mode::mac_bond(acc, rec[4 + (slot < 2 ? slot : slot - 1)], v);
+            } else {
+                mac(w, slot, v, acc);
+            }
+        };
+        if (rev) bond(0, after);
+        else bond(0, before);
+        if (id_of(w, 1) != kNoBlock) {
+#pragma unroll
+            for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane - RL, be)];
+            bond(1, x);
+        }
+        if constexpr (OS != 0) {
+            if (id_of(w, 2) != kNoBlock) Mode::mac_onsite(acc, rec, mid);
+        } else {
+            mac(w, 2, mid, acc);
+        }
+        if (id_of(w, 3) != kNoBlock) {
+#pragma unroll
+            for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane + RL, be)];
+            bond(3, x);
+        }
+        if (rev) bond(4, before);
+        else bond(4, after);
+    };
+
+    // OS: the wave's window of on-site records of one plane is contiguous in memory (SLOTS x
+    // kOnsiteSlots 16-byte pieces; with periodic planes the halo slots wrap, so the address is
+    // taken per piece): piece e of the window belongs to slot e / kOnsiteSlots.
+    constexpr int OSL = OS != 0 ? (SLOTS * sweep3_onsite_pieces<Mode, OS>() + kWave - 1) / kWave : 1;  // pieces per lane
+    [[maybe_unused]] auto load_onsite = [&](int k, bool wanted, double2 out[OSL]) {
+        if constexpr (OS != 0) {
+            constexpr int PIECES = sweep3_record_slots<Mode, OS>();
+            k = ring(act(k));
+#pragma unroll
+            for (int j = 0; j < OSL; ++j) {
+                const int e = lane + j * kWave, slot = e / PIECES, part = e - slot * PIECES;
+                const int pe = col * OWNED3 - 3 + slot;
+                const bool in_e = pe >= 0 && pe < a.plane;
+                const int pwe = in_e ? pe : ((pe % a.plane) + a.plane) % a.plane;
+                out[j] = zero;
+                // (plain loads: the halo slots of the neighbouring windows read the same records - 16 slots
+                // per 10 owned - and should find them in L2; a.stream bit 3 = non-temporal, for A/B runs)
+                if (wanted && slot < SLOTS && (in_e || a.wrap_p) && k >= 0 && k < a.lx) {
+                    const double2* src = a.onsite + ((size_t)k * a.plane + pwe) * PIECES + part;
+                    out[j] = (a.stream & 8) ? load_stream(src) : *src;
+                }
+            }
+        }
+    };
+    [[maybe_unused]] auto put_onsite = [&](int kk, const double2 v[OSL]) {
+        if constexpr (OS != 0) {
+            constexpr int PIECES = sweep3_record_slots<Mode, OS>();
+            double2* dst = ring_entry(kk);
+#pragma unroll
+            for (int j = 0; j < OSL; ++j) {
+                const int e = lane + j * kWave, slot = e / PIECES, part = e - slot * PIECES;
+                if (slot < SLOTS) dst[slot * RSTRIDE + part] = v[j];
+            }
+        }
+    };
+
+    // ---- prologue
+    // Rolling state.  t_n: `cn_m` = plane k-1; two buffers hold planes k and k+1 and swap roles
+    // every iteration (the loop is unrolled by two): the centre plane goes to its LDS row at the
+    // top of the iteration, which frees its registers for the load of plane k+2 - issued there and
+    // first used a whole iteration later, with no register-to-register hand-over in between.
+    // t_{n-1} of plane k+1 is loaded into `pv` as soon as step 1 has consumed plane k's.
+    double2 cn_m[4], buf_a[4], buf_b[4], pv[4], c1_m[4], c2_m[4];
+    cur_plane(k_first - 1, valid, cn_m);
+    cur_plane(k_first, valid, buf_a);
+    cur_plane(k_first + 1, valid, buf_b);
+    load_plane(t.prev, nt_prev, k_first, !GEN && ok1 && t.prev != nullptr, pv);  // (GEN: t_{-1} = 0)
+    uint2 ids_0 = load_ids(k_first), ids_1 = make_uint2(0xFFFFFFFFu, 0xFFu), ids_2 = ids_1;
+#pragma unroll
+    for (int al = 0; al < 4; ++al) c1_m[al] = c2_m[al] = zero;
+    put_own(row_1, c1_m);  // the rows still hold the previous unit's planes
+    put_own(row_2, c1_m);
+    if constexpr (OS != 0) {  // on-site blocks of the first plane (the later ones arrive one iteration ahead)
+        double2 first_os[OSL];
+        load_onsite(k_first, true, first_os);
+        put_onsite(k_first, first_os);
+    }
+
+    // one iteration: `centre` holds plane k on entry and plane k+2 (in flight) on exit, `after` plane k+1
+    auto iterate = [&](int k, double2 (&centre)[4], const double2 (&after)[4]) {
+        const bool more = k < k_last;
+        const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFu);
+        put_own(row_0, centre);
+        wave_sync();
+        cur_plane(k + 2, valid && more, centre);
+
+        // ---- step 1 on plane k: level 1 = c1 H t_n - t_{n-1}
+        double2 new1[4], new2[4];
+#pragma unroll
+        for (int al = 0; al < 4; ++al) new1[al] = new2[al] = zero;
+        if (ok1 && in_lattice(k)) {
+            double2 acc[4], mid[4];
+#pragma unroll
+            for (int al = 0; al < 4; ++al) acc[al] = zero;
+            own_of(row_0, mid);
+            apply(ids_0, cn_m, row_0, mid, after, acc, k);
+#pragma unroll
+            for (int al = 0; al < 4; ++al) {
+                new1[al].x = fma(t.coef1, acc[al].x, -pv[al].x);
+                new1[al].y = fma(t.coef1, acc[al].y, -pv[al].y);
+            }
+            if (owned && k >= x0 && k < x1) {
+#pragma unroll
+                for (int al = 0; al < 4; ++al) Mode::dots(dot1, mid[al], new1[al]);
+                if (steps == 1) store_plane(t.out2, k, new1);
+                if (steps == 2) store_plane(t.out1, k, new1);
+            }
+        }
+        load_plane(t.prev, nt_prev, k + 1, !GEN && ok1 && more && t.prev != nullptr, pv);
+
+        // ---- step 2 on plane k-1: level 2 = c2 H level1 - t_n        (row_1 = level 1, plane k-1)
+        if (steps >= 2 && ok2 && in_lattice(k - 1) && k - 1 >= x0 - (steps - 2) && k - 1 < x1 + (steps - 2)) {
+            double2 acc[4], mid[4];
+#pragma unroll
+            for (int al = 0; al < 4; ++al) acc[al] = zero;
+            own_of(row_1, mid);
+            apply(ids_1, c1_m, row_1, mid, new1, acc, k - 1);
+#pragma unroll
+            for (int al = 0; al < 4; ++al) {
+                new2[al].x = fma(a.coef2, acc[al].x, -cn_m[al].x);
+                new2[al].y = fma(a.coef2, acc[al].y, -cn_m[al].y);
+            }
+            if (owned && k - 1 >= x0 && k - 1 < x1) {
+#pragma unroll
+                for (int al = 0; al < 4; ++al) Mode::dots(dot2, mid[al], new2[al]);
+                if (steps == 2) store_plane(t.out2, k - 1, new2);
+                if (steps == 3) store_plane(t.out1, k - 1, new2);
+            }
+        }
+
+        // (OS) on-site records of plane k+1: asked for here rather than at the top of the iteration - they are
+        // not needed before its end, and 4-8 registers held across steps 1 and 2 are 4-8 registers spilled
+        [[maybe_unused]] double2 nx_os[OSL];
+        load_onsite(k + 1, more, nx_os);
+
+        // ---- step 3 on plane k-2: level 3 = c2 H level2 - level1       (row_2 = level 2, plane k-2)
+        if (steps >= 3 && owned && k - 2 >= x0 && k - 2 < x1) {
+            double2 acc[4], mid[4], new3[4];
+#pragma unroll
+            for (int al = 0; al < 4; ++al) acc[al] = zero;
+            own_of(row_2, mid);
+            apply(ids_2, c2_m, row_2, mid, new2, acc, k - 2);
+#pragma unroll
+            for (int al = 0; al < 4; ++al) {
+                new3[al].x = fma(a.coef2, acc[al].x, -c1_m[al].x);
+                new3[al].y = fma(a.coef2, acc[al].y, -c1_m[al].y);
+                Mode::dots(dot3, mid[al], new3[al]);
+            }
+            store_plane(t.out2, k - 2, new3);
+        }
+
+        // ---- roll: every level moves one plane on
+        wave_sync();
+        own_of(row_0, cn_m);   // level 0, plane k
+        own_of(row_1, c1_m);   // level 1, plane k-1
+        own_of(row_2, c2_m);   // level 2, plane k-2
+        wave_sync();
+        put_own(row_1, new1);  // level 1, plane k
+        put_own(row_2, new2);  // level 2, plane k-1
+        put_onsite(k + 1, nx_os);  // (OS) takes the ring entry of plane k-2, which step 3 has just finished with
+        ids_2 = ids_1;
+        ids_1 = ids_0;
+        ids_0 = nx_ids;
+    };
+    for (int k = k_first; k <= k_last; k += 2) {
+        iterate(k, buf_a, buf_b);
+        if (k + 1 <= k_last) iterate(k + 1, buf_b, buf_a);
+    }
+}
+
+template <typename Mode, int OS>
+__device__ inline Sweep3Lds sweep3_stage_lds(double2* lds, const SweepArgs& a, int slots, int wave) {
+    constexpr int SPB = Mode::kSlotsPerBlock;
+    constexpr int STRIDE = Mode::kBlockStride;
+    constexpr int DSL = Mode::kDiagSlots;
+    const int ring = sweep3_ring_slots<Mode, OS>(slots);
+    // LDS: [table][compact diagonals][per wave: three rows of 64 lanes x 4 entries; OS: + ring of three planes of on-site blocks]
     const double2* table = static_cast<const double2*>(a.dict_table);
     for (int e = threadIdx.x; e < a.n_unique * SPB; e += kBlockThreads)
         lds[(e / SPB) * STRIDE + (e % SPB)] = table[e];
     // compact copies of the block diagonals behind the table: a block flagged diagonal (plain hopping: four of the
     // five blocks of a row in the s-wave models) then costs Mode::kDiagSlots 16-byte LDS reads instead of mac_diag's
     // (1 instead of 2 in real particle-hole arithmetic: a tenth of the kernel's LDS operations)
-    constexpr int DSL = Mode::kDiagSlots;
-    double2* diag = lds + a.n_unique * STRIDE;
-    double2* row_0 = diag + a.n_unique * DSL + wave * (3 * kWave * 4 + RING);
-    double2* row_1 = row_0 + kWave * 4;
-    double2* row_2 = row_1 + kWave * 4;
-    [[maybe_unused]] double2* os_ring = row_2 + kWave * 4;
+    Sweep3Lds w;
+    w.table = lds;
+    w.diag = lds + a.n_unique * STRIDE;
+    w.row_0 = w.diag + a.n_unique * DSL + wave * (3 * kWave * 4 + ring);
+    w.row_1 = w.row_0 + kWave * 4;
+    w.row_2 = w.row_1 + kWave * 4;
+    w.os_ring = w.row_2 + kWave * 4;
     __syncthreads();
-    for (int id = threadIdx.x; id < a.n_unique; id += kBlockThreads) Mode::pack_diag(diag + id * DSL, lds + id * STRIDE);
+    for (int id = threadIdx.x; id < a.n_unique; id += kBlockThreads) Mode::pack_diag(w.diag + id * DSL, lds + id * STRIDE);
     __syncthreads();
+    return w;
+}
+
+template <typename Mode, int RL, bool REV, bool GEN = false, int OS = 0>
+__global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
+    extern __shared__ double2 lds[];
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const Sweep3Lds w = sweep3_stage_lds<Mode, OS>(lds, a, kWave / RL, wave);
 
     const int n_units = a.n_cols * a.n_segs;
     const int xcd = blockIdx.x & 7;
@@ -520,302 +881,17 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
     const int waves_per_xcd = (gridDim.x >> 3) * kWavesPerBlock;
 
     double dot1[4] = {0.0, 0.0, 0.0, 0.0}, dot2[4] = {0.0, 0.0, 0.0, 0.0}, dot3[4] = {0.0, 0.0, 0.0, 0.0};
-    const double2 zero = make_double2(0.0, 0.0);
-    const size_t nb = (size_t)a.nb;
-    const int steps = a.steps;  // uniform
-    const bool nt_prev = a.stream & 1, nt_store = a.stream & 2, nt_cur = a.stream & 4;
-    // GEN: the lane's vector(s) - real modes carry vectors 2r, 2r+1 in (x, y), complex modes vector r
-    uint64_t gen_key0 = 0, gen_key1 = 0;
-    bool gen_on0 = false, gen_on1 = false;
-    if constexpr (GEN) {
-        const int v0 = Mode::kVec == 2 ? 2 * r : r;
-        gen_on0 = v0 < a.gen_active;
-        gen_on1 = Mode::kVec == 2 && v0 + 1 < a.gen_active;
-        gen_key0 = vector_key(a.gen_seed, a.gen_first_id + v0);
-        gen_key1 = vector_key(a.gen_seed, a.gen_first_id + v0 + 1);
-    }
+    Sweep3Gen gen;
+    if constexpr (GEN) gen = sweep3_gen_keys<Mode>(a.gen_seed, a.gen_first_id, a.gen_active, lane % RL);
 
+    const Sweep3Task task{a.cur, a.prev, a.out1, a.out2, a.coef1, a.steps, a.discard};
     for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
         const int seg = u / a.n_cols, col = u - seg * a.n_cols;
-        const int x0 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * seg) / a.n_segs);
-        const int x1 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * (seg + 1)) / a.n_segs);
-        const int p = col * OWNED3 - 3 + s;
-        const bool inside = p >= 0 && p < a.plane;
-        const bool valid = inside || a.wrap_p;  // a ring has no edge: halo slots beyond it hold the far side
-        const int pw = inside ? p : ((p % a.plane) + a.plane) % a.plane;
-        const bool ok1 = valid && s >= 1 && s <= SLOTS - 2;
-        const bool ok2 = valid && s >= 2 && s <= SLOTS - 3;
-        const bool owned = inside && s >= 3 && s <= SLOTS - 4;
-
         const bool rev = REV != (bool)(a.zigzag & seg & 1);  // wave-uniform
-        auto act = [&](int k) { return rev ? x0 + x1 - 1 - k : k; };
-        auto ring = [&](int k) { return a.wrap_x ? (k < 0 ? k + a.lx : (k >= a.lx ? k - a.lx : k)) : k; };
-        auto in_lattice = [&](int k) { return a.wrap_x || (act(k) >= 0 && act(k) < a.lx); };
-        auto load_plane = [&](const double2* buf, bool nt, int k, bool wanted, double2 out[4]) {
-            k = ring(act(k));
-            if (wanted && k >= 0 && k < a.lx) {
-                const size_t site = (size_t)k * a.plane + pw;
-#pragma unroll
-                for (int al = 0; al < 4; ++al)
-                    out[al] = nt ? load_stream(buf + vslot(al, site, r, nb, RL)) : buf[vslot(al, site, r, nb, RL)];
-            } else {
-#pragma unroll
-                for (int al = 0; al < 4; ++al) out[al] = zero;
-            }
-        };
-        auto store_plane = [&](double2* buf, int k, const double2 v[4]) {
-            if (a.discard) return;  // (uniform: the last sweep of a run)
-            const size_t site = (size_t)act(k) * a.plane + p;
-#pragma unroll
-            for (int al = 0; al < 4; ++al) {
-                if (nt_store) store_stream(buf + vslot(al, site, r, nb, RL), v[al]);
-                else buf[vslot(al, site, r, nb, RL)] = v[al];
-            }
-        };
-        // plane k of t_n: read, or (GEN) made from the generator
-        auto cur_plane = [&](int k, bool wanted, double2 out[4]) {
-            if constexpr (GEN) {
-                k = ring(act(k));
-                if (wanted && k >= 0 && k < a.lx) {
-                    const uint64_t element = 4 * ((uint64_t)k * a.plane + pw);
-#pragma unroll
-                    for (int al = 0; al < 4; ++al) {
-                        if constexpr (Mode::kVec == 2) {
-                            out[al].x = gen_on0 ? start_entry(gen_key0, element + al, 0).x : 0.0;
-                            out[al].y = gen_on1 ? start_entry(gen_key1, element + al, 0).x : 0.0;
-                        } else {
-                            out[al] = gen_on0 ? start_entry(gen_key0, element + al, a.gen_kind) : zero;
-                        }
-                    }
-                } else {
-#pragma unroll
-                    for (int al = 0; al < 4; ++al) out[al] = zero;
-                }
-            } else {
-                load_plane(a.cur, nt_cur, k, wanted, out);
-            }
-        };
-        auto load_ids = [&](int k) {
-            uint2 w = make_uint2(0xFFFFFFFFu, 0xFFu);
-            k = ring(act(k));
-            if (ok1 && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + pw];
-            return w;
-        };
-        auto id_of = [](uint2 w, int slot) { return slot < 4 ? (w.x >> (8 * slot)) & 0xFFu : w.y & 0xFFu; };
-        auto mac = [&](uint2 w, int slot, const double2 x[4], double2 acc[4]) {
-            const unsigned id = id_of(w, slot);
-            if (id == kNoBlock) return;
-#if BDG_COMPACT_DIAG
-            if ((w.y >> (8 + slot)) & 1u) Mode::mac_diag_compact(acc, diag + id * DSL, x);
-#else
-            if ((w.y >> (8 + slot)) & 1u) Mode::mac_diag(acc, lds + id * STRIDE, x);
-#endif
-            else Mode::mac_row(acc, lds + id * STRIDE, x);
-        };
-        auto own_of = [&](const double2* row, double2 out[4]) {
-#pragma unroll
-            for (int be = 0; be < 4; ++be) out[be] = row[SHARE_SLOT(lane, be)];
-        };
-        auto put_own = [&](double2* row, const double2 v[4]) {
-#pragma unroll
-            for (int be = 0; be < 4; ++be) row[SHARE_SLOT(lane, be)] = v[be];
-        };
-        auto wave_sync = [&]() {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-        };
-        // acc = Σ_offsets block * x in CSR order (-P, -1, 0, +1, +P); `before` / `after` are the planes
-        // behind / ahead of the march, `mid` the lane's own entries, `row` the hand-over row of the level
-        // step j (1-based) runs on plane k-j+1 and is needed on planes [x0-(steps-j), x1+(steps-j))
-        const int k_first = x0 - (steps - 1), k_last = x1 + steps - 2;
-        [[maybe_unused]] auto ring_entry = [&](int kk) { return os_ring + ((kk - k_first) % 3) * (RING / 3); };
-
-        // (`kk` = marching index of the plane the step works on: selects the ring entry of its on-site blocks)
-        auto apply = [&](uint2 w, const double2 before[4], const double2* row, const double2 mid[4],
-                         const double2 after[4], double2 acc[4], [[maybe_unused]] int kk) {
-            double2 x[4];
-            [[maybe_unused]] const double2* rec = nullptr;
-            if constexpr (OS != 0) rec = ring_entry(kk) + s * RSTRIDE;
-            // one bond block times the neighbour's entries: from the table, or (OS = 2) from the site's record
-            auto bond = [&](int slot, const double2 v[4]) {
-                if constexpr (OS == 2) {
-                    if (id_of(w, slot) != kNoBlock) Mode::mac_bond(acc, rec[4 + (slot < 2 ? slot : slot - 1)], v);
-                } else {
-                    mac(w, slot, v, acc);
-                }
-            };
-            if (rev) bond(0, after);
-            else bond(0, before);
-            if (id_of(w, 1) != kNoBlock) {
-#pragma unroll
-                for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane - RL, be)];
-                bond(1, x);
-            }
-            if constexpr (OS != 0) {
-                if (id_of(w, 2) != kNoBlock) Mode::mac_onsite(acc, rec, mid);
-            } else {
-                mac(w, 2, mid, acc);
-            }
-            if (id_of(w, 3) != kNoBlock) {
-#pragma unroll
-                for (int be = 0; be < 4; ++be) x[be] = row[SHARE_SLOT(lane + RL, be)];
-                bond(3, x);
-            }
-            if (rev) bond(4, before);
-            else bond(4, after);
-        };
-
-        // OS: the wave's window of on-site records of one plane is contiguous in memory (SLOTS x
-        // kOnsiteSlots 16-byte pieces; with periodic planes the halo slots wrap, so the address is
-        // taken per piece): piece e of the window belongs to slot e / kOnsiteSlots.
-        constexpr int OSL = OS != 0 ? (SLOTS * sweep3_onsite_pieces<Mode, OS>() + kWave - 1) / kWave : 1;  // pieces per lane
-        [[maybe_unused]] auto load_onsite = [&](int k, bool wanted, double2 out[OSL]) {
-            if constexpr (OS != 0) {
-                constexpr int PIECES = sweep3_record_slots<Mode, OS>();
-                k = ring(act(k));
-#pragma unroll
-                for (int j = 0; j < OSL; ++j) {
-                    const int e = lane + j * kWave, slot = e / PIECES, part = e - slot * PIECES;
-                    const int pe = col * OWNED3 - 3 + slot;
-                    const bool in_e = pe >= 0 && pe < a.plane;
-                    const int pwe = in_e ? pe : ((pe % a.plane) + a.plane) % a.plane;
-                    out[j] = zero;
-                    // (plain loads: the halo slots of the neighbouring windows read the same records - 16 slots
-                    // per 10 owned - and should find them in L2; a.stream bit 3 = non-temporal, for A/B runs)
-                    if (wanted && slot < SLOTS && (in_e || a.wrap_p) && k >= 0 && k < a.lx) {
-                        const double2* src = a.onsite + ((size_t)k * a.plane + pwe) * PIECES + part;
-                        out[j] = (a.stream & 8) ? load_stream(src) : *src;
-                    }
-                }
-            }
-        };
-        [[maybe_unused]] auto put_onsite = [&](int kk, const double2 v[OSL]) {
-            if constexpr (OS != 0) {
-                constexpr int PIECES = sweep3_record_slots<Mode, OS>();
-                double2* dst = ring_entry(kk);
-#pragma unroll
-                for (int j = 0; j < OSL; ++j) {
-                    const int e = lane + j * kWave, slot = e / PIECES, part = e - slot * PIECES;
-                    if (slot < SLOTS) dst[slot * RSTRIDE + part] = v[j];
-                }
-            }
-        };
-
-        // ---- prologue
-        // Rolling state.  t_n: `cn_m` = plane k-1; two buffers hold planes k and k+1 and swap roles
-        // every iteration (the loop is unrolled by two): the centre plane goes to its LDS row at the
-        // top of the iteration, which frees its registers for the load of plane k+2 - issued there and
-        // first used a whole iteration later, with no register-to-register hand-over in between.
-        // t_{n-1} of plane k+1 is loaded into `pv` as soon as step 1 has consumed plane k's.
-        double2 cn_m[4], buf_a[4], buf_b[4], pv[4], c1_m[4], c2_m[4];
-        cur_plane(k_first - 1, valid, cn_m);
-        cur_plane(k_first, valid, buf_a);
-        cur_plane(k_first + 1, valid, buf_b);
-        load_plane(a.prev, nt_prev, k_first, !GEN && ok1 && a.prev != nullptr, pv);  // (GEN: t_{-1} = 0)
-        uint2 ids_0 = load_ids(k_first), ids_1 = make_uint2(0xFFFFFFFFu, 0xFFu), ids_2 = ids_1;
-#pragma unroll
-        for (int al = 0; al < 4; ++al) c1_m[al] = c2_m[al] = zero;
-        put_own(row_1, c1_m);  // the rows still hold the previous unit's planes
-        put_own(row_2, c1_m);
-        if constexpr (OS != 0) {  // on-site blocks of the first plane (the later ones arrive one iteration ahead)
-            double2 first_os[OSL];
-            load_onsite(k_first, true, first_os);
-            put_onsite(k_first, first_os);
-        }
-
-        // one iteration: `centre` holds plane k on entry and plane k+2 (in flight) on exit, `after` plane k+1
-        auto iterate = [&](int k, double2 (&centre)[4], const double2 (&after)[4]) {
-            const bool more = k < k_last;
-            const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFu);
-            put_own(row_0, centre);
-            wave_sync();
-            cur_plane(k + 2, valid && more, centre);
-
-            // ---- step 1 on plane k: level 1 = c1 H t_n - t_{n-1}
-            double2 new1[4], new2[4];
-#pragma unroll
-            for (int al = 0; al < 4; ++al) new1[al] = new2[al] = zero;
-            if (ok1 && in_lattice(k)) {
-                double2 acc[4], mid[4];
-#pragma unroll
-                for (int al = 0; al < 4; ++al) acc[al] = zero;
-                own_of(row_0, mid);
-                apply(ids_0, cn_m, row_0, mid, after, acc, k);
-#pragma unroll
-                for (int al = 0; al < 4; ++al) {
-                    new1[al].x = fma(a.coef1, acc[al].x, -pv[al].x);
-                    new1[al].y = fma(a.coef1, acc[al].y, -pv[al].y);
-                }
-                if (owned && k >= x0 && k < x1) {
-#pragma unroll
-                    for (int al = 0; al < 4; ++al) Mode::dots(dot1, mid[al], new1[al]);
-                    if (steps == 1) store_plane(a.out2, k, new1);
-                    if (steps == 2) store_plane(a.out1, k, new1);
-                }
-            }
-            load_plane(a.prev, nt_prev, k + 1, !GEN && ok1 && more && a.prev != nullptr, pv);
-
-            // ---- step 2 on plane k-1: level 2 = c2 H level1 - t_n        (row_1 = level 1, plane k-1)
-            if (steps >= 2 && ok2 && in_lattice(k - 1) && k - 1 >= x0 - (steps - 2) && k - 1 < x1 + (steps - 2)) {
-                double2 acc[4], mid[4];
-#pragma unroll
-                for (int al = 0; al < 4; ++al) acc[al] = zero;
-                own_of(row_1, mid);
-                apply(ids_1, c1_m, row_1, mid, new1, acc, k - 1);
-#pragma unroll
-                for (int al = 0; al < 4; ++al) {
-                    new2[al].x = fma(a.coef2, acc[al].x, -cn_m[al].x);
-                    new2[al].y = fma(a.coef2, acc[al].y, -cn_m[al].y);
-                }
-                if (owned && k - 1 >= x0 && k - 1 < x1) {
-#pragma unroll
-                    for (int al = 0; al < 4; ++al) Mode::dots(dot2, mid[al], new2[al]);
-                    if (steps == 2) store_plane(a.out2, k - 1, new2);
-                    if (steps == 3) store_plane(a.out1, k - 1, new2);
-                }
-            }
-
-            // (OS) on-site records of plane k+1: asked for here rather than at the top of the iteration - they are
-            // not needed before its end, and 4-8 registers held across steps 1 and 2 are 4-8 registers spilled
-            [[maybe_unused]] double2 nx_os[OSL];
-            load_onsite(k + 1, more, nx_os);
-
-            // ---- step 3 on plane k-2: level 3 = c2 H level2 - level1       (row_2 = level 2, plane k-2)
-            if (steps >= 3 && owned && k - 2 >= x0 && k - 2 < x1) {
-                double2 acc[4], mid[4], new3[4];
-#pragma unroll
-                for (int al = 0; al < 4; ++al) acc[al] = zero;
-                own_of(row_2, mid);
-                apply(ids_2, c2_m, row_2, mid, new2, acc, k - 2);
-#pragma unroll
-                for (int al = 0; al < 4; ++al) {
-                    new3[al].x = fma(a.coef2, acc[al].x, -c1_m[al].x);
-                    new3[al].y = fma(a.coef2, acc[al].y, -c1_m[al].y);
-                    Mode::dots(dot3, mid[al], new3[al]);
-                }
-                store_plane(a.out2, k - 2, new3);
-            }
-
-            // ---- roll: every level moves one plane on
-            wave_sync();
-            own_of(row_0, cn_m);   // level 0, plane k
-            own_of(row_1, c1_m);   // level 1, plane k-1
-            own_of(row_2, c2_m);   // level 2, plane k-2
-            wave_sync();
-            put_own(row_1, new1);  // level 1, plane k
-            put_own(row_2, new2);  // level 2, plane k-1
-            put_onsite(k + 1, nx_os);  // (OS) takes the ring entry of plane k-2, which step 3 has just finished with
-            ids_2 = ids_1;
-            ids_1 = ids_0;
-            ids_0 = nx_ids;
-        };
-        for (int k = k_first; k <= k_last; k += 2) {
-            iterate(k, buf_a, buf_b);
-            if (k + 1 <= k_last) iterate(k + 1, buf_b, buf_a);
-        }
+        sweep3_unit<Mode, RL, GEN, OS, false>(a, task, w, gen, lane, seg, col, rev, dot1, dot2, dot3);
     }
 
+    const int steps = a.steps;
     __syncthreads();
     sweep_reduce_dots<Mode, RL, kWavesPerBlock>(dot1, reinterpret_cast<double*>(lds), a.partial1, lane, wave);
     if (steps >= 2) {
@@ -825,6 +901,224 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
     if (steps >= 3) {
         __syncthreads();
         sweep_reduce_dots<Mode, RL, kWavesPerBlock>(dot3, reinterpret_cast<double*>(lds), a.partial3, lane, wave);
+    }
+}
+
+// =====================================================================================
+// K7c  cheb_march3 - the three-step sweeps of a whole reduction chunk (up to 21 of them = 63 steps) in ONE launch.
+//
+// A launch of cheb_sweep3 is one round: every wave starts at the same moment, loads its first planes while nothing
+// is written, marches, and drains while nothing is read; the next sweep cannot start before the slowest wave of the
+// last one has finished and the launch has been turned around.  But sweep l+1 of a unit (segment s, window c) needs
+// only the planes the nine units (s-1..s+1, c-1..c+1) wrote in sweep l (three recomputed planes / positions per
+// side), and overwrites only what those nine read in sweep l.  So here the sweeps ("levels") of a chunk are tasks
+// (level, lane group, unit) that the waves of one launch claim from ticket counters and run as soon as the nine
+// units of the level before have published theirs:
+//   * tickets (default; MarchArgs.fixed = the static assignment of cheb_sweep3 instead): per level and XCD one counter; workgroups b, b+8, ... (one XCD under round-robin placement - speed
+//     only) claim units of their eighth of a level first, then whatever another eighth has left, and move on to the
+//     next level only when all eight counters of the level are exhausted.  A task of level l is therefore claimed
+//     only after EVERY task of level l-1 has been claimed - by a wave that is running - so whatever a task waits
+//     for is finished or being worked on: no co-residency of the grid is assumed, and nothing can deadlock.
+//   * hand-over (guide: G16 R1): the new planes are stored write-through (sc1 buffer stores); after its march the
+//     wave waits for its stores (s_waitcnt vmcnt(0)) and lane 0 stores the unit's flag = levels done (relaxed,
+//     agent scope).  A consumer polls the nine flags with ONE wave instruction (lane i loads flag i, sc1) and
+//     s_sleep between polls, then makes one agent-scope acquire (buffer_inv sc1: this CU's L1) and only then loads.
+//   * a bounded wait: a wave that has polled one task's flags for `timeout_ticks` of the 100 MHz clock raises the abort word, every
+//     wave leaves at its next poll or claim, and the host falls back to one launch per sweep.
+// Two lane groups of a call are tasks of the same launch (their units interleaved in ticket order): what two
+// streams did for cheb_sweep3 - one group's waves filling the other's idle ends - now happens between any two
+// tasks.  The arithmetic is sweep3_unit's: t's are the bits cheb_sweep3 makes; dot partials are kept per unit
+// ([step][unit]) and summed in unit order by reduce_partials - independent of which wave ran which task.
+constexpr int kMarchGroups = 4;       // lane groups one launch advances side by side
+constexpr int kMarchMaxLevels = 24;   // sweeps per launch (a 63-step reduction chunk: 21)
+constexpr int kMarchCounterWords = 32;  // every polled word on a 128-byte line of its own
+
+struct MarchGroup {
+    double2* buf[4];       // even levels read buf[0] (t_n), buf[1] (t_{n-1}) and write buf[2], buf[3]; odd levels the other way round
+    double* partial;       // [steps of the launch][units][RL * kVec][2]
+    unsigned long long gen_first_id;
+    int gen_active;
+    int pad;
+};
+
+struct MarchArgs {
+    SweepArgs base;        // geometry, tables, coef2, generator seed / kind, zigzag, rings; buffers and partials come from the groups
+    MarchGroup group[kMarchGroups];
+    int n_groups;
+    int n_levels;
+    int last_steps;        // steps of the last level (1..3); every other level makes 3
+    int discard_last;      // the last level stores nothing (end of a run)
+    int first_is_start;    // level 0 is the first sweep of a run: t_{-1} = 0 is not read and coef1 = coef2 / 2
+    int gen;               // ... and makes the random t_0 itself (GEN)
+    int rev0;              // marching direction of level 0 (levels alternate)
+    int units;             // n_cols * n_segs
+    unsigned long long per_step;   // doubles between the partials of consecutive steps
+    unsigned* sync;        // word 0: abort; counters at kMarchCounterWords * (1 + 8 * level + xcd); flags from flags_at on, [group][unit]
+    unsigned flags_at;
+    unsigned timeout_ticks;
+    unsigned* gave_up;     // set (never cleared by a launch) when a wave gives up waiting: the host reads it with the results
+    // 1 = no tickets: wave i of an XCD's workgroups takes units i, i + waves, ... of its eighth at every level, as
+    // cheb_sweep3's waves do (neighbouring windows on the waves of one workgroup: shared halo lines in one L1).  Needs the
+    // whole grid resident - a wave that waits for a unit whose wave never started gives up after the timeout and the
+    // host falls back.  Launches of a single level always run this way (nothing is waited for).
+    int fixed;
+    // measurements and tests only (BODGE_AMD_MARCH_DEBUG): bit 0 = no acquire after a wait, bit 1 = no wait at all (WRONG
+    // results: what the hand-over costs), bit 2 = plain instead of write-through stores, bit 3 = add every wave's waiting
+    // and claiming time (100 MHz ticks) and task count to gave_up[1..3], bit 5 = the first wave that has to wait gives up
+    // at once (the fallback path under test)
+    int debug;
+    int poll_sleep;        // s_sleep argument between two polls (units of 64 clocks)
+};
+
+__host__ __device__ inline size_t march_sync_words(int units, int groups) {
+    return (size_t)kMarchCounterWords * (1 + 8 * kMarchMaxLevels) + (size_t)groups * units;
+}
+
+template <typename Mode, int RL, int OS>
+__global__ __launch_bounds__(kBlockThreads, 2) void cheb_march3(MarchArgs m) {
+    extern __shared__ double2 lds[];
+    constexpr int W = 2 * Mode::kVec;  // doubles per lane of one step's dot products
+    const int lane = threadIdx.x & (kWave - 1);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
+    const Sweep3Lds w = sweep3_stage_lds<Mode, OS>(lds, m.base, kWave / RL, wave);
+
+    const int n_units = m.units, n_cols = m.base.n_cols, n_segs = m.base.n_segs;
+    const int home = blockIdx.x & 7;
+    auto first_of = [&](int x) { return (int)(((int64_t)n_units * x) >> 3); };
+    auto share_of = [&](int x) { return (unsigned)((first_of(x + 1) - first_of(x)) * m.n_groups); };
+    auto counter = [&](int level, int x) { return m.sync + (size_t)kMarchCounterWords * (1 + 8 * level + x); };
+    unsigned* const flags = m.sync + m.flags_at;
+    unsigned long long t_waiting = 0, t_claiming = 0;
+    unsigned n_tasks = 0;
+    // A launch of ONE level has nothing to wait for: its waves take the units of their eighth in turn, as cheb_sweep3's do
+    // (no tickets); m.fixed asks for the same at every level.
+    const bool fixed = m.n_levels == 1 || m.fixed;
+    const unsigned my_first = (unsigned)((blockIdx.x >> 3) * kWavesPerBlock + wave), my_stride = (unsigned)((gridDim.x >> 3) * kWavesPerBlock);
+    unsigned my_next = my_first;
+    for (int level = 0; level < m.n_levels;) {
+        const unsigned long long t_claim = (m.debug & 8) ? wall_clock64() : 0;
+        int queue = home;
+        unsigned idx = 0;
+        if (fixed) {
+            if (my_next >= share_of(home)) {
+                ++level;
+                my_next = my_first;
+                continue;
+            }
+            idx = my_next;
+            my_next += my_stride;
+        } else {
+            // ---- claim: own eighth of the level first, then what another eighth has left, then the next level
+            if (lane == 0) idx = __hip_atomic_fetch_add(counter(level, home), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            idx = __builtin_amdgcn_readfirstlane(idx);
+            if (idx >= share_of(home)) {
+                unsigned seen = 0xFFFFFFFFu;
+                if (lane < 8) seen = __hip_atomic_load(counter(level, lane), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const unsigned stop = __hip_atomic_load(m.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (__builtin_amdgcn_readfirstlane(stop) != 0) break;
+                const unsigned long long left = __ballot(lane < 8 && seen < share_of(lane < 8 ? lane : 0));
+                if (left == 0) {
+                    ++level;
+                    continue;
+                }
+                // the nearest eighth after the own one that still has tasks
+                const unsigned rot = (unsigned)(((left | (left << 8)) >> home) & 0xFFu);
+                queue = (home + __builtin_ctz(rot)) & 7;
+                if (lane == 0) idx = __hip_atomic_fetch_add(counter(level, queue), 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                idx = __builtin_amdgcn_readfirstlane(idx);
+                if (idx >= share_of(queue)) continue;  // (taken meanwhile: look again)
+            }
+        }
+        const int g = (int)(idx % (unsigned)m.n_groups);
+        const int u = first_of(queue) + (int)(idx / (unsigned)m.n_groups);
+        const int seg = u / n_cols, col = u - seg * n_cols;
+
+        if (m.debug & 8) t_claiming += wall_clock64() - t_claim;
+        ++n_tasks;
+        // ---- wait until the nine units around this one have published the level before
+        if (level > 0 && !(m.debug & 2)) {
+            const int ds = lane / 3 - 1, dc = lane % 3 - 1;
+            int ns = seg + ds, nc = col + dc;
+            if (m.base.wrap_x) ns = ns < 0 ? ns + n_segs : (ns >= n_segs ? ns - n_segs : ns);
+            if (m.base.wrap_p) nc = nc < 0 ? nc + n_cols : (nc >= n_cols ? nc - n_cols : nc);
+            const bool watch = lane < 9 && ns >= 0 && ns < n_segs && nc >= 0 && nc < n_cols;
+            const unsigned* mine = watch ? flags + (size_t)g * n_units + (size_t)ns * n_cols + nc : m.sync;
+            bool stop = false;
+            const unsigned long long t_wait = wall_clock64();
+            for (;;) {
+                const unsigned v = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                // (lanes that watch no unit read the abort word: zero unless the launch is being given up)
+                if (__any(!watch && v != 0)) {
+                    stop = true;
+                    break;
+                }
+                if (__all(!watch || v >= (unsigned)level)) break;
+                if (wall_clock64() - t_wait > (unsigned long long)m.timeout_ticks || (m.debug & 32)) {
+                    if (lane == 0) {
+                        __hip_atomic_store(m.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        __hip_atomic_store(m.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                    stop = true;
+                    break;
+                }
+                if (m.poll_sleep <= 4) __builtin_amdgcn_s_sleep(4);
+                else if (m.poll_sleep <= 16) __builtin_amdgcn_s_sleep(16);
+                else __builtin_amdgcn_s_sleep(64);
+            }
+            if (stop) break;
+            if (m.debug & 8) t_waiting += wall_clock64() - t_wait;
+            if (!(m.debug & 1)) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+        }
+
+        // ---- the sweep of this unit
+        const MarchGroup& grp = m.group[g];
+        const bool odd = level & 1;
+        const bool start = m.first_is_start && level == 0;
+        const bool last = level == m.n_levels - 1;
+        Sweep3Task task;
+        task.cur = grp.buf[odd ? 3 : 0];
+        task.prev = start ? nullptr : grp.buf[odd ? 2 : 1];
+        task.out1 = grp.buf[odd ? 1 : 2];
+        task.out2 = grp.buf[odd ? 0 : 3];
+        task.coef1 = start ? 0.5 * m.base.coef2 : m.base.coef2;
+        task.steps = last ? m.last_steps : 3;
+        task.discard = last ? m.discard_last : 0;
+        const bool rev = (bool)((m.rev0 + level) & 1) != (bool)(m.base.zigzag & seg & 1);
+        double dot1[4] = {0.0, 0.0, 0.0, 0.0}, dot2[4] = {0.0, 0.0, 0.0, 0.0}, dot3[4] = {0.0, 0.0, 0.0, 0.0};
+        if (start && m.gen) {
+            const Sweep3Gen gen = sweep3_gen_keys<Mode>(m.base.gen_seed, grp.gen_first_id, grp.gen_active, lane % RL);
+            sweep3_unit<Mode, RL, true, OS, true>(m.base, task, w, gen, lane, seg, col, rev, dot1, dot2, dot3);
+        } else {
+            sweep3_unit<Mode, RL, false, OS, true>(m.base, task, w, Sweep3Gen{}, lane, seg, col, rev, dot1, dot2, dot3);
+        }
+
+        // ---- publish: stores drained, then the flag
+        if (m.n_levels > 1) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (lane == 0)
+                __hip_atomic_store(flags + (size_t)g * n_units + u, (unsigned)(level + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+
+        // ---- dot products of the unit: over the site lanes, one partial per (step, unit)
+        auto put_dots = [&](double (&dot)[4], int step) {
+#pragma unroll
+            for (int off = kWave / 2; off >= RL; off >>= 1)
+#pragma unroll
+                for (int c = 0; c < W; ++c) dot[c] += __shfl_xor(dot[c], off);
+            if (lane < RL) {
+                double* out = grp.partial + (size_t)(3 * level + step) * m.per_step + ((size_t)u * RL + lane) * W;
+#pragma unroll
+                for (int c = 0; c < W; ++c) out[c] = dot[c];
+            }
+        };
+        put_dots(dot1, 0);
+        if (task.steps >= 2) put_dots(dot2, 1);
+        if (task.steps >= 3) put_dots(dot3, 2);
+    }
+    if ((m.debug & 8) && lane == 0) {
+        atomicAdd(m.gave_up + 1, (unsigned)(t_waiting >> 4));
+        atomicAdd(m.gave_up + 2, (unsigned)(t_claiming >> 4));
+        atomicAdd(m.gave_up + 3, n_tasks);
     }
 }
 

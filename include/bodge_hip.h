@@ -80,6 +80,11 @@ typedef struct bdg_perf {
                               sums the streams' own times (kernel_ms / launches = duration of one launch, what a
                               profiler reports) and window_ms is the elapsed time they share.  One stream:
                               window_ms = kernel_ms. */
+    int64_t sweeps;        /* multi-step sweeps made, summed over the lane groups (= launches with one launch per sweep) */
+    int32_t persistent;    /* 1 = cheb_march3: every launch makes all the sweeps of a reduction chunk (up to 21 = 63
+                              steps) of `groups_per_launch` lane groups; its waves claim (sweep, group, unit) tasks and
+                              start one as soon as the neighbouring units have published the sweep before */
+    int32_t groups_per_launch; /* lane groups (batches of the call) advanced by one persistent launch, else 1 */
 } bdg_perf;
 
 const char* bdg_last_error(void);

@@ -319,7 +319,9 @@ def test_multi_step_sweep_kernels_match_oracle_and_one_step_kernels(api, solver_
             batches = -(-vectors // (per_group * lanes // 4))
             assert not swept or perf["lanes_per_row"] == lanes
             if swept:
-                assert perf["launches"] == batches * -(-steps // depth)
+                assert perf["sweeps"] == batches * -(-steps // depth)
+                if not perf["persistent"]:
+                    assert perf["launches"] == perf["sweeps"]
             if rolled:
                 assert perf["launches"] == batches * steps
             assert np.array_equal(got[0], again[0]) and np.array_equal(got[1], again[1])  # bit reproducible
@@ -431,6 +433,91 @@ def test_three_step_sweep_with_streamed_onsite_blocks(api, solver_cls, knobs, bl
                 first = got
             for other in (ref, one):
                 assert np.abs(got[0] - other[0]).max() <= 1e-12 * n and np.abs(got[1] - other[1]).max() <= 1e-12 * n
+
+
+@pytest.mark.parametrize("shape,kind,vec_kind", [
+    ((64, 48, 1), "swave", cheb_ref.VEC_RADEMACHER),
+    ((40, 100, 1), "peierls", cheb_ref.VEC_Z4),           # complex blocks and vectors, ragged last window
+    ((30, 30, 1), "periodic", cheb_ref.VEC_RADEMACHER),   # torus: the units' neighbours wrap around in both directions
+    ((37, 30, 1), "periodic_x", cheb_ref.VEC_Z4),         # ring of planes only
+    ((48, 50, 1), "potential", cheb_ref.VEC_RADEMACHER),  # streamed on-site blocks (OS = 1), real
+    ((33, 61, 1), "texture", cheb_ref.VEC_Z4),            # ... complex
+    ((40, 36, 1), "ssd", cheb_ref.VEC_RADEMACHER),        # bond blocks streamed too (OS = 2)
+])
+def test_sweeps_of_a_chunk_in_one_launch_match_one_launch_per_sweep(api, solver_cls, knobs, block_storage, shape, kind, vec_kind):
+    """cheb_march3 (sweep.hpp K7c; opt-in through BODGE_AMD_MARCH): all the sweeps of a 63-step reduction chunk in one
+    launch, the waves claiming (sweep, lane group, unit) tasks and waiting on their neighbours' flags - by ticket (1),
+    with a fixed unit per wave (3), or one sweep per launch for all lane groups (2).  The vectors are the bits
+    cheb_sweep3 makes, so every d_n, e_n agrees with one launch per sweep to the rounding of the partial sums, and with
+    the CPU oracle; runs that cross a chunk boundary, end on 1, 2 or 3 steps, one and two lane groups, several pairs."""
+    if block_storage != "dictionary":
+        pytest.skip("the stencil kernels read the block dictionary")
+    if kind in ("potential", "texture"):
+        system = _position_dependent_system(api, shape, kind)
+    elif kind == "ssd":
+        system = _ssd_system(api, shape, "ssd")
+    else:
+        system = _sweep_system(api, shape, kind)
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    n = bsr.shape[0]
+    complex_run = vec_kind == cheb_ref.VEC_Z4 or kind in ("peierls", "texture")
+    per_group = 4 if complex_run else 8
+    knobs.set("BODGE_AMD_SWEEP", "1")
+    with solver_cls.from_hamiltonian(system) as dev:
+        for steps, vectors, extra in [(9, per_group, {}), (70, 2 * per_group, {}), (8, 3, {}), (64, per_group + 1, {"BODGE_AMD_SWEEP_SEGMENTS": "3"}),
+                                      (13, 5 * per_group, {}), (7, 2 * per_group, {"BODGE_AMD_SWEEP_GEN": "0"}),
+                                      (10, 2 * per_group, {"BODGE_AMD_SWEEP_LANES": "2"})]:
+            if kind in ("potential", "texture", "ssd") and "BODGE_AMD_SWEEP_LANES" in extra:
+                continue  # (streamed blocks: 4 lanes per site only)
+            knobs.update(extra)
+            knobs.set("BODGE_AMD_MARCH", "0")
+            classic = dev.dots_random(scale, steps, vectors, seed=11, kind=vec_kind)
+            base = dev.perf()
+            assert base["steps_per_launch"] == 3 and base["persistent"] == 0 and base["sweeps"] == base["launches"], base
+            ref = None
+            if steps <= 13:
+                ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 11, range(vectors), vec_kind))
+            for mode in ("1", "3", "2"):
+                knobs.set("BODGE_AMD_MARCH", mode)
+                got = dev.dots_random(scale, steps, vectors, seed=11, kind=vec_kind)
+                perf = dev.perf()
+                again = dev.dots_random(scale, steps, vectors, seed=11, kind=vec_kind)
+                assert perf["persistent"] == 1 and perf["steps_per_launch"] == 3 and perf["sweeps"] == base["sweeps"], (mode, perf)
+                assert perf["lanes_per_row"] == base["lanes_per_row"] and perf["onsite_streamed"] == base["onsite_streamed"]
+                if mode != "2" and steps >= 6:
+                    assert perf["launches"] < perf["sweeps"], (mode, perf)
+                assert abs(perf["bytes_moved"] - base["bytes_moved"]) <= 1e-9 * base["bytes_moved"]
+                assert np.array_equal(got[0], again[0]) and np.array_equal(got[1], again[1])  # whichever wave ran which task
+                assert np.abs(got[0] - classic[0]).max() <= 1e-13 * n and np.abs(got[1] - classic[1]).max() <= 1e-13 * n, mode
+                if ref is not None:
+                    assert np.abs(got[0] - ref[0]).max() <= 1e-12 * n and np.abs(got[1] - ref[1]).max() <= 1e-12 * n, mode
+            for key in extra:
+                knobs.unset(key)
+
+
+def test_a_persistent_launch_that_gives_up_waiting_is_repeated_sweep_by_sweep(api, solver_cls, knobs, block_storage):
+    """A wave of cheb_march3 that cannot get its neighbours' flags within the timeout (a foreign kernel holding the GPU, a
+    grid that is not resident with the fixed assignment) raises the abort word; every wave leaves, the handle goes back to
+    one launch per sweep and the call is repeated.  Forced here by a debug bit: the result is the classic one, bit for bit."""
+    if block_storage != "dictionary":
+        pytest.skip("the stencil kernels read the block dictionary")
+    system = _sweep_system(api, (64, 48, 1), "swave")
+    bsr = system.matrix("bsr")
+    scale = cheb_ref.spectral_bound(bsr)
+    knobs.set("BODGE_AMD_SWEEP", "1")
+    with solver_cls.from_hamiltonian(system) as dev:
+        knobs.set("BODGE_AMD_MARCH", "0")
+        classic = dev.dots_random(scale, 20, 16, seed=3)
+        knobs.set("BODGE_AMD_MARCH", "1")
+        knobs.set("BODGE_AMD_MARCH_DEBUG", "32")
+        got = dev.dots_random(scale, 20, 16, seed=3)
+        perf = dev.perf()
+        assert perf["persistent"] == 0 and perf["sweeps"] == perf["launches"], perf
+        assert np.array_equal(got[0], classic[0]) and np.array_equal(got[1], classic[1])
+        knobs.unset("BODGE_AMD_MARCH_DEBUG")
+        later = dev.dots_random(scale, 20, 16, seed=3)  # the handle keeps to one launch per sweep
+        assert dev.perf()["persistent"] == 0 and np.array_equal(later[0], classic[0])
 
 
 def _ssd_system(api, shape, kind, seed=0):
