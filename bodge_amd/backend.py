@@ -176,26 +176,40 @@ def as_u8p(array: np.ndarray):
     return array.ctypes.data_as(_u8p)
 
 
+_overrides: dict[str, str] = {}  # what set_option has set in this process (the library keeps no getter)
+
+
 def set_option(name: str, value) -> None:
     """Override one BODGE_AMD_* switch of the library for this process (`None` removes the override).
 
     The library looks here before the environment variable of the same name; unlike changing
     `os.environ` this is safe while other host threads are inside library calls."""
     check(load().bdg_set_option(name.encode(), None if value is None else str(value).encode()))
+    if value is None:
+        _overrides.pop(name, None)
+    else:
+        _overrides[name] = str(value)
+
+
+def get_option(name: str):
+    """The override set for `name` in this process, or None (the environment variable, if any, then shows)."""
+    return _overrides.get(name)
 
 
 class options:
-    """`with backend.options(BODGE_AMD_SWEEP="0", ...):` - switches set for the block, removed after it."""
+    """`with backend.options(BODGE_AMD_SWEEP="0", ...):` - switches set for the block; on leaving it every one goes back
+    to what it was before (an enclosing block's value, a process-wide `set_option`, or no override)."""
 
     def __init__(self, **values):
         self._values = values
+        self._before = {}
 
     def __enter__(self):
+        self._before = {name: _overrides.get(name) for name in self._values}
         for name, value in self._values.items():
             set_option(name, value)
         return self
 
     def __exit__(self, *exc):
-        for name in self._values:
-            set_option(name, None)
-        return False
+        for name, value in self._before.items():
+            set_option(name, value)

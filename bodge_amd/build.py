@@ -19,7 +19,7 @@ INCLUDE = os.path.join(os.path.dirname(ROOT), "include")
 LIBRARY = os.path.join(CSRC, "libbodge_hip.so")
 SOURCES = [os.path.join(CSRC, "bodge_hip.hip")]
 HEADERS = [os.path.join(CSRC, name) for name in (
-    "kernels.hpp", "sweep.hpp", "host_assembly.hpp", "core.hpp", "plans.hpp", "libraries.hpp", "recurrence.hpp",
+    "kernels.hpp", "sweep.hpp", "twostage.hpp", "host_assembly.hpp", "core.hpp", "plans.hpp", "libraries.hpp", "recurrence.hpp",
     "lanczos.hpp", "dense.hpp", "tridiag.hpp", "knobs.hpp")] + [os.path.join(INCLUDE, "bodge_hip.h")]
 ARCH = "gfx950"
 

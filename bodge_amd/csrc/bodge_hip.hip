@@ -43,6 +43,7 @@
 #include <string_view>
 #include <thread>
 #include <tuple>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -50,6 +51,7 @@
 #include "host_assembly.hpp"
 #include "kernels.hpp"
 #include "sweep.hpp"
+#include "twostage.hpp"
 
 #include "core.hpp"
 #include "plans.hpp"
@@ -518,7 +520,8 @@ int bdg_destroy(bdg_system* sys) {
     if (sys->march_seen) (void)hipHostFree(sys->march_seen);
     sys->march_seen = nullptr;
     sys->march_gave_up.release();
-    sys->tile_order.release();
+    for (auto& cached : sys->tile_orders) cached->ids.release();
+    sys->tile_orders.clear();
     sys->send_rows.release();
     sys->tiles_interior.release();
     sys->tiles_boundary.release();
@@ -543,7 +546,14 @@ int bdg_set_lattice_shape(bdg_system* sys, int32_t lx, int32_t ly, int32_t lz) {
     sys->shape[0] = lx;
     sys->shape[1] = ly;
     sys->shape[2] = lz;
-    sys->order_rows_per_tile = 0;
+    // (cached tile orders belong to the old shape; launches that still read them must finish first)
+    if (!sys->tile_orders.empty()) {
+        HIP_TRY(hipSetDevice(sys->device));
+        HIP_TRY(hipStreamSynchronize(sys->stream));
+        for (auto& side : sys->side_sets) HIP_TRY(hipStreamSynchronize(side->stream));
+        for (auto& cached : sys->tile_orders) cached->ids.release();
+        sys->tile_orders.clear();
+    }
     sys->stencil_state = 0;
     return BDG_OK;
 }
@@ -688,6 +698,7 @@ int bdg_eigh_dense(bdg_system* sys, double* w_out, double* z_out) {
     if (sys->ncols != sys->nb) return fail(BDG_EINVAL, "bdg_eigh_dense needs a whole (square) matrix, not a slab");
     lanczos_free(sys);
     HIP_TRY(hipSetDevice(sys->device));
+    release_side_sets(sys);  // (the dense arrays want the memory)
     const int64_t n = 4 * sys->nb;
     {
         const char* forced = knob::raw("BODGE_AMD_EIGH");
@@ -848,6 +859,7 @@ int bdg_eigh_dense_above(bdg_system* sys, double lower_bound, int64_t capacity, 
     if (own) {
         lanczos_free(sys);
         HIP_TRY(hipSetDevice(sys->device));
+        release_side_sets(sys);
         return eig_tridiagonal_above(sys, w_out, lower_bound, capacity, n_vectors, z_out);
     }
     // the full solve of another driver, cut to the eigenvalues above the bound
@@ -961,6 +973,8 @@ int bdg_lanczos_begin(bdg_system* sys, int32_t n_vectors, uint64_t seed, uint64_
     start.seed = seed;
     start.first_id = first_vec_id;
     start.vec_kind = vec_kind;
+    (void)hipSetDevice(sys->device);
+    release_side_sets(sys);  // (a Lanczos run keeps up to k + 4 vector buffers of its own)
     return lanczos_begin(sys, n_vectors, start, max_iter);
 }
 

@@ -184,10 +184,27 @@ struct bdg_system : StreamSet {
     size_t host_dots_count = 0;
     // lattice geometry hint (rows = z + lz*(y + ly*x)) and the cached strip-major tile order
     int shape[3] = {0, 0, 0};
-    DeviceBuffer<int> tile_order;
-    int order_rows_per_tile = 0, order_strip_rows = 0;
+    // One cached permutation per (rows per tile, strip width): the batches of a call may differ in both (a narrower last
+    // batch), and an order is never rewritten while launches that read it can still be in flight.
+    struct TileOrder {
+        int rows_per_tile = 0, strip_rows = 0;
+        DeviceBuffer<int> ids;
+    };
+    std::vector<std::unique_ptr<TileOrder>> tile_orders;
     bdg_perf perf{};
 };
+
+namespace {
+// The side sets of a handle (vector buffers, partials, streams of the batches that ran beside the first) are kept from call
+// to call; whoever needs the memory for something else - a Lanczos run, a dense solve - gives them back first.
+inline void release_side_sets(bdg_system* sys) {
+    for (auto& side : sys->side_sets) {
+        if (side->stream) (void)hipStreamSynchronize(side->stream);
+        side->release_set();
+    }
+    sys->side_sets.clear();
+}
+}  // namespace
 
 struct bdg_comm {
     int device = 0;

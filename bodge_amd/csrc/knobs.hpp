@@ -79,6 +79,11 @@ inline void set(const char* name, const char* value) {
         t.entries.erase(name);
         return;
     }
+    for (const std::string& kept : t.pool)  // (the pool holds every distinct value once: it does not grow with the number of calls)
+        if (kept == value) {
+            t.entries[name] = kept.c_str();
+            return;
+        }
     t.pool.emplace_back(value);
     t.entries[name] = t.pool.back().c_str();
 }

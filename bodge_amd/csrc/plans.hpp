@@ -358,10 +358,11 @@ int prepare_tile_order(bdg_system* sys, int rows_per_tile, int n_tiles, double r
     strip = std::max<int64_t>(rows_per_tile, strip / rows_per_tile * rows_per_tile);
     if (strip >= plane || budget <= 0) return BDG_OK;
     *strip_out = (int)strip;
-    if (sys->order_rows_per_tile == rows_per_tile && sys->order_strip_rows == strip) {
-        *order_out = sys->tile_order.ptr;
-        return BDG_OK;
-    }
+    for (const auto& cached : sys->tile_orders)
+        if (cached->rows_per_tile == rows_per_tile && cached->strip_rows == strip && cached->ids.count >= (size_t)n_tiles) {
+            *order_out = cached->ids.ptr;
+            return BDG_OK;
+        }
     // Tile t (first row r0 = t * rows_per_tile) belongs to plane x = r0 / plane and strip
     // (r0 % plane) / strip; emit strip by strip, plane by plane, ascending inside.  O(n_tiles).
     std::vector<int> order;
@@ -377,11 +378,20 @@ int prepare_tile_order(bdg_system* sys, int rows_per_tile, int n_tiles, double r
     }
     if ((int)order.size() != n_tiles)
         return fail(BDG_EDEVICE, "internal error: tile order has %zu of %d tiles", order.size(), n_tiles);
-    if (int rc = sys->tile_order.reserve((size_t)n_tiles)) return rc;
-    HIP_TRY(hipMemcpy(sys->tile_order.ptr, order.data(), sizeof(int) * n_tiles, hipMemcpyHostToDevice));
-    sys->order_rows_per_tile = rows_per_tile;
-    sys->order_strip_rows = (int)strip;
-    *order_out = sys->tile_order.ptr;
+    if (sys->tile_orders.size() >= 16) {  // (a handle driven through very many shapes: start over, once nothing reads the old ones)
+        HIP_TRY(hipStreamSynchronize(sys->stream));
+        for (auto& side : sys->side_sets) HIP_TRY(hipStreamSynchronize(side->stream));
+        for (auto& cached : sys->tile_orders) cached->ids.release();
+        sys->tile_orders.clear();
+    }
+    auto fresh = std::make_unique<bdg_system::TileOrder>();
+    if (int rc = fresh->ids.reserve((size_t)n_tiles)) return rc;
+    // (a new buffer: the blocking copy cannot disturb launches of earlier batches, which read other buffers)
+    HIP_TRY(hipMemcpy(fresh->ids.ptr, order.data(), sizeof(int) * n_tiles, hipMemcpyHostToDevice));
+    fresh->rows_per_tile = rows_per_tile;
+    fresh->strip_rows = (int)strip;
+    *order_out = fresh->ids.ptr;
+    sys->tile_orders.push_back(std::move(fresh));
     return BDG_OK;
 }
 

@@ -1003,8 +1003,16 @@ int run_recurrence_once(bdg_system* sys, double scale, int n_steps, int n_vector
             batch.stream_share = std::min(n_streams, n_batches - first);  // (a last batch on its own has the GPU to itself)
             const int col = index * width;
             if (int rc = batch.begin(sys, scale, n_steps, std::min(width, n_vectors - col), batch_start(start, col), -1, false,
-                                     index - first))
+                                     index - first)) {
+                if (rc == BDG_ENOMEM && index > first) {
+                    // no room for a side set's buffers after all: give them back and run the rest of the call on one stream
+                    (void)drained(0);
+                    release_side_sets(sys);
+                    n_streams = 1;
+                    break;  // (`last` = index: this batch begins again in the next round, on the handle's own set)
+                }
                 return drained(rc);
+            }
             if (index == 0) {  // one spacing of the result pieces for the whole call: the first batch is the widest
                 stride0 = batch.host_stride;
                 // one-step kernels: two streams only while one launch leaves the GPU part empty (sites x vectors of a batch)
@@ -1042,7 +1050,7 @@ int run_recurrence_once(bdg_system* sys, double scale, int n_steps, int n_vector
         if (trace) fprintf(stderr, "[bdg] batches %d..%d: begin %.3f ms, enqueue %.3f ms\n", first, last - 1, ms(t0, t1), ms(t1, now()));
     }
     HIP_TRY(hipStreamSynchronize(sys->stream));
-    for (int side = 0; side < n_streams - 1; ++side) HIP_TRY(hipStreamSynchronize(sys->side_sets[(size_t)side]->stream));
+    for (auto& side : sys->side_sets) HIP_TRY(hipStreamSynchronize(side->stream));
     for (int index = 0; index < n_batches; ++index)
         if (int rc = queued[(size_t)index].finish_collect(d_out, e_out, n_vectors, index * width, false, index == 0))
             return rc;

@@ -750,6 +750,97 @@ inline void scatter_for_tridiagonal(bdg_system* sys, double* a, hipStream_t st) 
 // else double2.  *n_vectors receives the number of such eigenvalues; if it exceeds `capacity` nothing is
 // written to z_out and BDG_EINVAL is returned.  z_out: eigenvector m (m-th eigenvalue above the bound,
 // ascending) in the 4*nb complex entries from z_out + 8*nb*m.
+// K10 (twostage.hpp): a (n x n real symmetric, row-major, both triangles; overwritten) -> diagonal d and sub-diagonal e of
+// an orthogonally similar tridiagonal matrix, through a band of half-width kTsBand.  Everything is enqueued on `st`.
+int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStream_t st) {
+    constexpr int B = bdg::kTsBand;
+    DeviceBuffer<double> work, band;
+    DeviceBuffer<unsigned> sync;
+    const int64_t n_panels = n > B + 1 ? (n - B - 1 + B - 1) / B : 0;
+    constexpr int kSlices = 8;                       // k slices of X = A22 V at most
+    const int64_t max_parts = (n + 255) / 256;       // parts of Z = V^T X
+    // work: V, X, W (n x B each), T, M (B x B), Z parts, QR partials [2][256][2B], row broadcast [2][B], the k slices of X
+    const size_t work_count = (size_t)3 * n * B + 2 * B * B + (size_t)max_parts * B * B + (size_t)2 * 256 * 2 * B + 2 * B +
+                              (size_t)kSlices * n * B;
+    auto body = [&]() -> int {
+        if (int rc = work.reserve(work_count)) return rc;
+        if (int rc = band.reserve((size_t)(n + 4 * B) * bdg::kTsBandLd)) return rc;
+        const size_t sync_count = ((size_t)n_panels + (size_t)n + 8 + 3) / 4 * 4;
+        if (int rc = sync.reserve(sync_count)) return rc;
+        HIP_TRY(hipMemsetAsync(sync.ptr, 0, sync_count * sizeof(unsigned), st));
+        HIP_TRY(hipMemsetAsync(work.ptr, 0, work_count * sizeof(double), st));
+        double* v = work.ptr;
+        double* x = v + (size_t)n * B;
+        double* w = x + (size_t)n * B;
+        double* t = w + (size_t)n * B;
+        double* mm = t + B * B;
+        double* zpart = mm + B * B;
+        double* partial = zpart + (size_t)max_parts * B * B;
+        double* rowi = partial + (size_t)2 * 256 * 2 * B;
+        double* xpart = rowi + 2 * B;
+        unsigned* panel_counter = sync.ptr;                 // one barrier counter per panel
+        unsigned* progress = sync.ptr + n_panels;           // [n]
+        unsigned* ticket = progress + n;
+        unsigned* gave_up = ticket + 1;
+        int64_t panel = 0;
+        for (int64_t j0 = 0; j0 + B + 1 < n; j0 += B, ++panel) {
+            const int64_t r0 = j0 + B, m = n - r0;
+            bdg::TsPanelArgs q{};
+            q.a = a;
+            q.n = (int)n;
+            q.j0 = (int)j0;
+            q.r0 = (int)r0;
+            q.m = (int)m;
+            q.reflectors = (int)std::min<int64_t>(B, m - 1);
+            q.v = v;
+            q.t = t;
+            q.partial = partial;
+            q.rowi = rowi;
+            q.counter = panel_counter + panel;
+            const unsigned qr_grid = (unsigned)((m + 16 + 255) / 256);  // (sixteen zero rows of V behind the last one)
+            if (qr_grid > 256) return fail(BDG_EINVAL, "two-stage route limited to 65000 rows");
+            bdg::ts_panel_qr<<<qr_grid, 256, 0, st>>>(q);
+            // X = A22 V in k slices: enough waves (16 rows each) for every SIMD of the device
+            const int64_t row_waves = (m + 15) / 16;
+            const int slices = (int)std::clamp<int64_t>((2048 + row_waves - 1) / row_waves, 1, kSlices);
+            const int k_slice = (int)(((m + slices - 1) / slices + 15) / 16 * 16);
+            const int used = (int)((m + k_slice - 1) / k_slice);
+            bdg::ts_symm<<<dim3((unsigned)((m + 63) / 64), (unsigned)used), 256, 0, st>>>(a, (int)n, (int)r0, (int)m, v, xpart, k_slice);
+            const unsigned parts = (unsigned)((m + 255) / 256);
+            bdg::ts_xz<<<parts, 64, 0, st>>>(xpart, used, v, (int)m, x, zpart);
+            bdg::ts_small<<<1, 256, 0, st>>>(zpart, (int)parts, t, mm);
+            bdg::ts_w<<<(unsigned)((m + 16 + 255) / 256), 256, 0, st>>>(x, v, t, mm, (int)m, w);
+            const unsigned tiles = (unsigned)((m + 63) / 64);
+            bdg::ts_rank2k<<<dim3(tiles, tiles), 256, 0, st>>>(a, (int)n, (int)r0, (int)m, v, w);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemsetAsync(band.ptr, 0, (size_t)(n + 4 * B) * bdg::kTsBandLd * sizeof(double), st));
+        bdg::ts_extract_band<<<2048, 256, 0, st>>>(a, (int)n, band.ptr);
+        if (const char* env = knob::raw("BODGE_AMD_EIGH_STAGE2"); !(env && env[0] == '0')) {
+            bdg::TsChaseArgs c{};
+            c.ab = band.ptr;
+            c.n = (int)n;
+            c.progress = progress;
+            c.ticket = ticket;
+            c.gave_up = gave_up;
+            c.timeout_ticks = 400000000u;  // 4 s of the 100 MHz clock
+            bdg::ts_chase<<<512, 64, 0, st>>>(c);
+        }
+        bdg::ts_band_to_tridiagonal<<<256, 256, 0, st>>>(band.ptr, (int)n, d, e);
+        HIP_TRY(hipGetLastError());
+        unsigned failed = 0;
+        HIP_TRY(hipMemcpyAsync(&failed, gave_up, sizeof(unsigned), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        if (failed) return fail(BDG_EDEVICE, "band reduction gave up waiting for a sweep (is another kernel holding the GPU?)");
+        return BDG_OK;
+    };
+    const int rc = body();
+    work.release();
+    band.release();
+    sync.release();
+    return rc;
+}
+
 template <typename T>
 int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, int64_t capacity, int64_t* n_vectors,
                           double* z_out) {
@@ -763,7 +854,7 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
     DeviceBuffer<double2> emitted;
     DeviceBuffer<bdg::TdScalars<T>> scal;
     auto body = [&]() -> int {
-        if (int rc = a.reserve((size_t)n * n)) return rc;
+        if (int rc = a.reserve((size_t)n * n + 64)) return rc;  // (+64: ts_symm reads up to 15 entries past a row's end)
         constexpr int kVectors = 4 + 2 * bdg::kTdDefer;  // (the last one holds the 2 K dot products handed from step to step)
         if (int rc = vectors.reserve((size_t)kVectors * n)) return rc;
         if (int rc = taus.reserve((size_t)n)) return rc;
@@ -791,7 +882,15 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
         if (const char* env = knob::raw("BODGE_AMD_EIGH_DEFER")) defer = std::clamp(atoi(env), 1, bdg::kTdDefer);
         double* d = diag.ptr;
         double* e = diag.ptr + n;
-        for (int64_t j = 0; j < n; ++j) {
+        // eigenvalues only, real matrices: through the band (K10, BLAS-3); BODGE_AMD_EIGH_STAGES=1|2 overrides
+        bool two_stage = false;
+        if constexpr (std::is_same_v<T, double>) {
+            two_stage = !z_out && !n_vectors && n >= 1024;
+            if (const char* env = knob::raw("BODGE_AMD_EIGH_STAGES")) two_stage = atoi(env) == 2 && n > 2 * bdg::kTsBand + 2;
+            if (two_stage)
+                if (int rc = tridiagonalise_two_stage(a.ptr, n, d, e, st)) return rc;
+        }
+        for (int64_t j = 0; j < n && !two_stage; ++j) {
             T* v_unf = v[(j + 1) & 1];  // made at step j-1; its w is finished by this step's vector kernel
             T* v_new = v[j & 1];
             bdg::td_vector_step<T><<<1, 1024, 0, st>>>(a.ptr, (int)n, (int)j, v_unf, q, pend, v_new, d, e, scal.ptr, taus.ptr, pend_dots);

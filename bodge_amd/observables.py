@@ -198,7 +198,10 @@ def free_energy(
         if system.has_symmetric_spectrum(1e-12):
             # ±-symmetric spectrum: the reference's "ε > 0" (ref :305) keeps one member of every pair, and of a
             # pair of zero modes whichever round-off made positive - the upper half of the sorted spectrum is the
-            # same set without depending on the sign of 1e-17 (each zero mode then contributes T ln 2, as there)
+            # same set without depending on the sign of 1e-17 (each such pair then contributes T ln 2, as there).
+            # Deliberate deviation: a pair of EXACT zeros (a decoupled site, a zero block) counts once
+            # here as well - this is Tr f(H), what the Chebyshev route gives - where the reference's strict "> 0"
+            # drops both members; F then differs by T ln 2 per exact pair (test_exact_zero_modes_count_once_per_pair)
             eps = np.maximum(eps[len(eps) // 2:], 0.0)
         else:
             eps = eps[eps > 0]

@@ -70,23 +70,24 @@ class Knobs:
         from bodge_amd import backend
 
         self._backend = backend
-        self._names = set()
+        self._before = {}  # name -> the override in force before this test touched it (None = none)
 
     def set(self, name, value):
+        self._before.setdefault(name, self._backend.get_option(name))
         self._backend.set_option(name, value)
-        self._names.add(name)
 
     def unset(self, name):
+        self._before.setdefault(name, self._backend.get_option(name))
         self._backend.set_option(name, None)
-        self._names.discard(name)
 
     def update(self, values):
         for name, value in values.items():
             self.set(name, value)
 
     def clear(self):
-        for name in list(self._names):
-            self.unset(name)
+        for name, value in self._before.items():  # back to what was there (a process-wide set_option survives a test)
+            self._backend.set_option(name, value)
+        self._before.clear()
 
 
 @pytest.fixture

@@ -1406,6 +1406,32 @@ def test_default_call_warns_when_it_is_not_the_reference_computation(api, monkey
     assert abs(zero / system.free_energy(0.0, method="dense") - 1) < 1e-10
 
 
+def test_exact_zero_modes_count_once_per_pair(api):
+    """ADVICE r3 / DESIGN §6: a site with no terms at all has four eigenvalues that are exactly zero.  The reference's
+    `ε > 0` (ref hamiltonian.py:305) drops all four; the dense route here evaluates Tr f(H) - every ± pair once, so each
+    of the two exact pairs adds T ln 2, the number the Chebyshev route gives as well."""
+    lattice = api.CubicLattice((5, 4, 1))
+    system = api.Hamiltonian(lattice)
+    lonely = (0, 0, 0)
+    with system as (H, Δ):
+        for i in lattice.sites():
+            if i != lonely:
+                H[i, i] = 3.0 * api.σ0 - 0.05 * api.σ3
+                Δ[i, i] = -0.1 * api.jσ2
+        for i, j in lattice.bonds():
+            if lonely not in (i, j):
+                H[i, j] = -1.0 * api.σ0
+    dense = np.asarray(system.matrix("dense"))
+    eps = np.linalg.eigvalsh(dense)
+    assert np.sum(np.abs(eps) < 1e-12) == 4
+    kept = eps[eps > 1e-9]
+    for T in (0.1, 0.5):
+        strict = -0.5 * kept.sum() - T * np.log1p(np.exp(-kept / T)).sum()  # the reference's sum without the zero modes
+        for method in ("dense", "chebyshev"):
+            value = system.free_energy(T, method=method, **({"moments": 2048, "trace": "exact"} if method == "chebyshev" else {}))
+            assert abs(value - (strict - 2 * T * np.log(2.0))) <= 1e-9 * abs(strict), (T, method, value, strict)
+
+
 @pytest.mark.parametrize("name", ["swave20", "complex235", "random357", "snf", "chain128", "dwave8", "swave30_zeeman",
                                   "peierls30", "chain300", "swave50_zeeman"])
 def test_eigenvalues_by_tridiagonalisation_match_the_reference(api, golden, knobs, name):
