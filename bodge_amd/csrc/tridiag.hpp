@@ -328,27 +328,40 @@ __global__ __launch_bounds__(256) void td_fused_pass(T* __restrict__ a, int n, i
     }
 }
 
-// k-th smallest eigenvalue of the symmetric tridiagonal matrix (d, e) by bisection on the Sturm count
-// (number of negative pivots of T - x I): one thread per eigenvalue, ascending output.
-__global__ void td_bisect(const double* __restrict__ d, const double* __restrict__ e2, int n, double lo, double hi,
-                          double pivmin, double* __restrict__ out) {
-    const int k = blockIdx.x * blockDim.x + threadIdx.x;
-    if (k >= n) return;
+// k-th smallest eigenvalue of the symmetric tridiagonal matrix (d, e) by multisection on the Sturm count
+// (number of negative pivots of T - x I), ascending output.  The Sturm recurrence is one dependent division per row:
+// a lone thread per eigenvalue is a chain of 53 x n of them, with most SIMDs of the device idle at n = 10^4.  So
+// kBisectPoints = 16 adjacent lanes share an eigenvalue: each evaluates the count at its own point of the current
+// interval, which then shrinks to one of seventeen parts - 13 rounds instead of 53 (58 -> 15 ms at n = 10^4).
+constexpr int kBisectPoints = 16;
+__global__ __launch_bounds__(64) void td_bisect(const double* __restrict__ d, const double* __restrict__ e2, int n, double lo, double hi,
+                                                double pivmin, double* __restrict__ out) {
+    const int lane = threadIdx.x & 63, point = lane % kBisectPoints, group = lane / kBisectPoints;
+    const int k = blockIdx.x * (64 / kBisectPoints) + group;  // (k >= n: the lanes work on the last eigenvalue again and store nothing)
+    const int kk = min(k, n - 1);
     double a = lo, b = hi;
-    for (int it = 0; it < 200; ++it) {
-        const double mid = 0.5 * (a + b);
-        if (!(mid > a && mid < b)) break;  // the interval is one ulp wide
-        double piv = d[0] - mid;
+    for (int it = 0; it < 64; ++it) {
+        const double width = b - a;
+        const double x = a + width * ((point + 1) * (1.0 / (kBisectPoints + 1)));
+        // (an interval of a few ulps: some points coincide with its ends, which is harmless)
+        double piv = d[0] - x;
         int count = piv < 0.0 ? 1 : 0;
         for (int i = 1; i < n; ++i) {
             if (fabs(piv) < pivmin) piv = -pivmin;
-            piv = d[i] - mid - e2[i - 1] / piv;
+            piv = d[i] - x - e2[i - 1] / piv;
             count += piv < 0.0 ? 1 : 0;
         }
-        if (count > k) b = mid;
-        else a = mid;
+        // the part between the last point with count <= k and the first with count > k
+        const bool above = count > kk;
+        const unsigned long long votes = __ballot(above) >> (group * kBisectPoints) & ((1ull << kBisectPoints) - 1);
+        const int first_above = votes ? __builtin_ctzll(votes) : kBisectPoints;  // points are ascending, counts monotone
+        const double new_a = first_above == 0 ? a : __shfl(x, group * kBisectPoints + first_above - 1);
+        const double new_b = first_above == kBisectPoints ? b : __shfl(x, group * kBisectPoints + first_above);
+        if (!(new_b - new_a < width)) break;  // nothing gained any more: the interval is down to rounding
+        a = new_a;
+        b = new_b;
     }
-    out[k] = 0.5 * (a + b);
+    if (point == 0 && k < n) out[k] = 0.5 * (a + b);
 }
 
 // ---- eigenvectors of the tridiagonal matrix by inverse iteration (the scheme of LAPACK's dstein).
@@ -756,16 +769,18 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
     constexpr int B = bdg::kTsBand;
     DeviceBuffer<double> work, band;
     DeviceBuffer<unsigned> sync;
+    hipStream_t side = nullptr;
+    hipEvent_t ev_strip = nullptr, ev_qr = nullptr;
     const int64_t n_panels = n > B + 1 ? (n - B - 1 + B - 1) / B : 0;
     constexpr int kSlices = 8;                       // k slices of X = A22 V at most
     const int64_t max_parts = (n + 255) / 256;       // parts of Z = V^T X
     // work: V, X, W (n x B each), T, M (B x B), Z parts, QR partials [2][256][2B], row broadcast [2][B], the k slices of X
     const size_t work_count = (size_t)3 * n * B + 2 * B * B + (size_t)max_parts * B * B + (size_t)2 * 256 * 2 * B + 2 * B +
-                              (size_t)kSlices * n * B;
+                              (size_t)kSlices * n * B + (size_t)((n + 127) / 128 + 1) * B * B + 2 * B + B * B + (size_t)n * B;
     auto body = [&]() -> int {
         if (int rc = work.reserve(work_count)) return rc;
         if (int rc = band.reserve((size_t)(n + 4 * B) * bdg::kTsBandLd)) return rc;
-        const size_t sync_count = ((size_t)n_panels + (size_t)n + 8 + 3) / 4 * 4;
+        const size_t sync_count = ((size_t)2 * n_panels + (size_t)n + 8 + 3) / 4 * 4;
         if (int rc = sync.reserve(sync_count)) return rc;
         HIP_TRY(hipMemsetAsync(sync.ptr, 0, sync_count * sizeof(unsigned), st));
         HIP_TRY(hipMemsetAsync(work.ptr, 0, work_count * sizeof(double), st));
@@ -778,12 +793,23 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
         double* partial = zpart + (size_t)max_parts * B * B;
         double* rowi = partial + (size_t)2 * 256 * 2 * B;
         double* xpart = rowi + 2 * B;
+        double* gpart = xpart + (size_t)kSlices * n * B;
+        double* qr_scale = gpart + (size_t)((n + 127) / 128 + 1) * B * B;
+        double* qr_beta = qr_scale + B;
+        double* qr_w = qr_beta + B;
+        double* v2 = qr_w + B * B;  // V of every other panel
+        bool gram_qr = true;
+        if (const char* env = knob::raw("BODGE_AMD_EIGH_GRAM_QR")) gram_qr = atoi(env) != 0;
         unsigned* panel_counter = sync.ptr;                 // one barrier counter per panel
+        unsigned* unsafe = sync.ptr + n_panels + n + 8;     // [n_panels]: panels the Gram route gave up
         unsigned* progress = sync.ptr + n_panels;           // [n]
         unsigned* ticket = progress + n;
         unsigned* gave_up = ticket + 1;
-        int64_t panel = 0;
-        for (int64_t j0 = 0; j0 + B + 1 < n; j0 += B, ++panel) {
+        // The factorisation of panel p + 1 (a chain of small kernels, one of them a single workgroup) runs on a second
+        // stream beside the bulk of panel p's rank-2B update: first the strip of the update that panel p + 1 lives in,
+        // then both at once.  V alternates between two buffers (the update still reads panel p's).
+        double* vbuf[2] = {v, v2};
+        auto factorise = [&](int64_t panel, int64_t j0, hipStream_t on) -> int {
             const int64_t r0 = j0 + B, m = n - r0;
             bdg::TsPanelArgs q{};
             q.a = a;
@@ -792,26 +818,81 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
             q.r0 = (int)r0;
             q.m = (int)m;
             q.reflectors = (int)std::min<int64_t>(B, m - 1);
-            q.v = v;
+            q.v = vbuf[panel & 1];
             q.t = t;
             q.partial = partial;
             q.rowi = rowi;
             q.counter = panel_counter + panel;
             const unsigned qr_grid = (unsigned)((m + 16 + 255) / 256);  // (sixteen zero rows of V behind the last one)
             if (qr_grid > 256) return fail(BDG_EINVAL, "two-stage route limited to 65000 rows");
-            bdg::ts_panel_qr<<<qr_grid, 256, 0, st>>>(q);
+            if (gram_qr) {
+                // reflectors from the Gram matrix of the panel (no grid barrier); panels that lose too much of a column
+                // to cancellation are factorised by ts_panel_qr instead (`unsafe` decides on the device)
+                const unsigned gparts = (unsigned)std::max<int64_t>(1, (m - B + 127) / 128);
+                bdg::ts_gram<<<gparts, 64, 0, on>>>(a, (int)n, (int)j0, (int)r0, (int)m, gpart);
+                bdg::TsRecurArgs rc{};
+                rc.a = a;
+                rc.n = (int)n;
+                rc.j0 = (int)j0;
+                rc.r0 = (int)r0;
+                rc.m = (int)m;
+                rc.reflectors = q.reflectors;
+                rc.gpart = gpart;
+                rc.parts = (int)gparts;
+                rc.scale = qr_scale;
+                rc.beta = qr_beta;
+                rc.wrows = qr_w;
+                rc.t = t;
+                rc.unsafe = unsafe + panel;
+                bdg::ts_qr_recur<<<1, 256, 0, on>>>(rc);
+                bdg::ts_qr_apply<<<qr_grid, 256, 0, on>>>(a, (int)n, (int)j0, (int)r0, (int)m, q.reflectors, qr_scale, qr_beta, qr_w,
+                                                         unsafe + panel, q.v);
+                q.only_if = unsafe + panel;
+            }
+            bdg::ts_panel_qr<<<qr_grid, 256, 0, on>>>(q);
+            return BDG_OK;
+        };
+        // (pays while the bulk of an update outlasts the chain: two events per panel cost more than they hide on small blocks)
+        bool lookahead = n >= 6000;
+        if (const char* env = knob::raw("BODGE_AMD_EIGH_LOOKAHEAD")) lookahead = atoi(env) != 0;
+        if (lookahead && !side) {
+            HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            HIP_TRY(hipEventCreateWithFlags(&ev_strip, hipEventDisableTiming));
+            HIP_TRY(hipEventCreateWithFlags(&ev_qr, hipEventDisableTiming));
+        }
+        int64_t panel = 0;
+        if (n_panels > 0)
+            if (int rc = factorise(0, 0, st)) return rc;
+        for (int64_t j0 = 0; j0 + B + 1 < n; j0 += B, ++panel) {
+            const int64_t r0 = j0 + B, m = n - r0;
+            const double* vp = vbuf[panel & 1];
             // X = A22 V in k slices: enough waves (16 rows each) for every SIMD of the device
             const int64_t row_waves = (m + 15) / 16;
             const int slices = (int)std::clamp<int64_t>((2048 + row_waves - 1) / row_waves, 1, kSlices);
             const int k_slice = (int)(((m + slices - 1) / slices + 15) / 16 * 16);
             const int used = (int)((m + k_slice - 1) / k_slice);
-            bdg::ts_symm<<<dim3((unsigned)((m + 63) / 64), (unsigned)used), 256, 0, st>>>(a, (int)n, (int)r0, (int)m, v, xpart, k_slice);
+            bdg::ts_symm<<<dim3((unsigned)((m + 63) / 64), (unsigned)used), 256, 0, st>>>(a, (int)n, (int)r0, (int)m, vp, xpart, k_slice);
             const unsigned parts = (unsigned)((m + 255) / 256);
-            bdg::ts_xz<<<parts, 64, 0, st>>>(xpart, used, v, (int)m, x, zpart);
+            bdg::ts_xz<<<parts, 256, 0, st>>>(xpart, used, vp, (int)m, x, zpart);
             bdg::ts_small<<<1, 256, 0, st>>>(zpart, (int)parts, t, mm);
-            bdg::ts_w<<<(unsigned)((m + 16 + 255) / 256), 256, 0, st>>>(x, v, t, mm, (int)m, w);
-            const unsigned tiles = (unsigned)((m + 63) / 64);
-            bdg::ts_rank2k<<<dim3(tiles, tiles), 256, 0, st>>>(a, (int)n, (int)r0, (int)m, v, w);
+            bdg::ts_w<<<(unsigned)((m + 16 + 255) / 256), 256, 0, st>>>(x, vp, t, mm, (int)m, w);
+            const bool more = j0 + B + B + 1 < n;  // another panel follows
+            const unsigned tile_rows = (unsigned)((m + 63) / 64);
+            bdg::ts_rank2k<<<dim3(1, tile_rows), 256, 0, st>>>(a, (int)n, (int)r0, (int)m, vp, w, 1);
+            const bool beside = more && lookahead && m >= 3072;
+            if (beside) {
+                HIP_TRY(hipEventRecord(ev_strip, st));
+                HIP_TRY(hipStreamWaitEvent(side, ev_strip, 0));
+                if (int rc = factorise(panel + 1, j0 + B, side)) return rc;
+                HIP_TRY(hipEventRecord(ev_qr, side));
+            }
+            if (m > B) {
+                const unsigned tile_cols = (unsigned)((m - B + 63) / 64);
+                bdg::ts_rank2k<<<dim3(tile_cols, tile_rows), 256, 0, st>>>(a, (int)n, (int)r0, (int)m, vp, w, 0);
+            }
+            if (beside) HIP_TRY(hipStreamWaitEvent(st, ev_qr, 0));
+            if (more && !beside)
+                if (int rc = factorise(panel + 1, j0 + B, st)) return rc;
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(band.ptr, 0, (size_t)(n + 4 * B) * bdg::kTsBandLd * sizeof(double), st));
@@ -824,17 +905,50 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
             c.ticket = ticket;
             c.gave_up = gave_up;
             c.timeout_ticks = 400000000u;  // 4 s of the 100 MHz clock
-            bdg::ts_chase<<<512, 64, 0, st>>>(c);
+            c.xcd = gave_up + 1;
+            HIP_TRY(hipMemsetAsync(c.xcd, 0xFF, sizeof(unsigned), st));
+            int chase_grid = 2048;  // (an eighth of them find themselves on the XCD the sweeps run on)
+            if (const char* env = knob::raw("BODGE_AMD_EIGH_CHASE_GRID")) chase_grid = std::max(1, atoi(env));
+            DeviceBuffer<unsigned long long> phases;
+            if (knob::raw("BODGE_AMD_EIGH_CHASE_PROFILE")) {
+                if (int rc = phases.reserve(8)) return rc;
+                HIP_TRY(hipMemsetAsync(phases.ptr, 0, 8 * sizeof(unsigned long long), st));
+                c.profile = phases.ptr;
+            }
+            bdg::ts_chase<<<chase_grid, 64, 0, st>>>(c);
+            if (c.profile) {
+                unsigned long long ticks[8];
+                HIP_TRY(hipMemcpyAsync(ticks, phases.ptr, sizeof ticks, hipMemcpyDeviceToHost, st));
+                HIP_TRY(hipStreamSynchronize(st));
+                const double steps = (double)n * n / (2.0 * B);
+                fprintf(stderr, "[bdg] ts_chase, us per step: to LDS %.2f, poll + prefetch %.2f, reflector %.2f, G %.2f, S %.2f, G2 %.2f, stores %.2f, drain %.2f\n",
+                        ticks[0] * 0.01 / steps, ticks[1] * 0.01 / steps, ticks[2] * 0.01 / steps, ticks[3] * 0.01 / steps,
+                        ticks[4] * 0.01 / steps, ticks[5] * 0.01 / steps, ticks[6] * 0.01 / steps, ticks[7] * 0.01 / steps);
+                phases.release();
+            }
         }
         bdg::ts_band_to_tridiagonal<<<256, 256, 0, st>>>(band.ptr, (int)n, d, e);
         HIP_TRY(hipGetLastError());
         unsigned failed = 0;
         HIP_TRY(hipMemcpyAsync(&failed, gave_up, sizeof(unsigned), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
+        if (knob::raw("BODGE_AMD_TRACE") && n_panels > 0) {
+            std::vector<unsigned> flags((size_t)n_panels);
+            HIP_TRY(hipMemcpy(flags.data(), unsafe, sizeof(unsigned) * n_panels, hipMemcpyDeviceToHost));
+            int64_t fell_back = 0;
+            for (unsigned f : flags) fell_back += f != 0;
+            fprintf(stderr, "[bdg] two-stage: %lld panels, %lld of them factorised with a barrier per column\n", (long long)n_panels, (long long)fell_back);
+        }
         if (failed) return fail(BDG_EDEVICE, "band reduction gave up waiting for a sweep (is another kernel holding the GPU?)");
         return BDG_OK;
     };
     const int rc = body();
+    if (side) {
+        (void)hipStreamSynchronize(side);
+        (void)hipStreamDestroy(side);
+        (void)hipEventDestroy(ev_strip);
+        (void)hipEventDestroy(ev_qr);
+    }
     work.release();
     band.release();
     sync.release();
@@ -885,8 +999,10 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
         // eigenvalues only, real matrices: through the band (K10, BLAS-3); BODGE_AMD_EIGH_STAGES=1|2 overrides
         bool two_stage = false;
         if constexpr (std::is_same_v<T, double>) {
-            two_stage = !z_out && !n_vectors && n >= 1024;
+            // (measured, scratch/r4_twostage_check.py: 92 against 92 ms at n = 3600, 0.36 against 1.1 s at 10^4, 7.8 against 50 s at 4e4)
+            two_stage = n >= 6000;
             if (const char* env = knob::raw("BODGE_AMD_EIGH_STAGES")) two_stage = atoi(env) == 2 && n > 2 * bdg::kTsBand + 2;
+            two_stage = two_stage && !z_out && !n_vectors;  // (eigenvectors: the one-stage route, whose reflectors the back-transformation knows)
             if (two_stage)
                 if (int rc = tridiagonalise_two_stage(a.ptr, n, d, e, st)) return rc;
         }
@@ -934,7 +1050,8 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
         double* e2_dev = diag.ptr + 2 * n;
         double* eig_dev = diag.ptr + 3 * n;
         HIP_TRY(hipMemcpyAsync(e2_dev, e2.data(), sizeof(double) * n, hipMemcpyHostToDevice, st));
-        bdg::td_bisect<<<(unsigned)((n + 63) / 64), 64, 0, st>>>(d, e2_dev, (int)n, lo, hi, pivmin, eig_dev);
+        constexpr int kPerWave = 64 / bdg::kBisectPoints;
+        bdg::td_bisect<<<(unsigned)((n + kPerWave - 1) / kPerWave), 64, 0, st>>>(d, e2_dev, (int)n, lo, hi, pivmin, eig_dev);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(w_out, eig_dev, sizeof(double) * n, hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));

@@ -57,6 +57,25 @@ struct TsBuffer {
     __device__ inline void store(size_t index, double v) const {
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, (int)(index * sizeof(double)), 0, 16);
     }
+    // Between workgroups of ONE XCD the L2 is the meeting point: stores that stay in it (plain) and loads that skip the
+    // L1 (nt: served by the L2) - no write-through to memory, a third of the round trip (guide: visibility table).
+    __device__ inline double load_l2(size_t index) const {
+        return __builtin_bit_cast(double, __builtin_amdgcn_raw_buffer_load_b64(rsrc, (int)(index * sizeof(double)), 0, 2));
+    }
+    __device__ inline void store_l2(size_t index, double v) const {
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, v), rsrc, (int)(index * sizeof(double)), 0, 0);
+    }
+};
+struct TsWords {  // the same for 32-bit words (progress counters)
+    __amdgpu_buffer_rsrc_t rsrc;
+    __device__ inline TsWords(const unsigned* base, size_t count)
+        : rsrc(__builtin_amdgcn_make_buffer_rsrc(const_cast<unsigned*>(base), 0, (int)(count * sizeof(unsigned)), 0x00020000)) {}
+    __device__ inline unsigned load_l2(size_t index) const {
+        return __builtin_amdgcn_raw_buffer_load_b32(rsrc, (int)(index * sizeof(unsigned)), 0, 2);
+    }
+    __device__ inline void store_l2(size_t index, unsigned v) const {
+        __builtin_amdgcn_raw_buffer_store_b32(v, rsrc, (int)(index * sizeof(unsigned)), 0, 0);
+    }
 };
 __device__ inline void ts_compiler_fence() { asm volatile("" ::: "memory"); }
 
@@ -76,10 +95,12 @@ struct TsPanelArgs {
     double* partial; // [2][grid][B + 1 + B]: S_c, then the row-i broadcast is separate
     double* rowi;    // [2][B]
     unsigned* counter;
+    const unsigned* only_if;  // nullptr, or: run only if this word is non-zero (the Gram route gave the panel up)
 };
 
 __global__ __launch_bounds__(256) void ts_panel_qr(TsPanelArgs q) {
     constexpr int B = kTsBand;
+    if (q.only_if && *q.only_if == 0) return;  // (uniform over the grid)
     __shared__ double red[4][2 * B];
     __shared__ double tot[2 * B];
     __shared__ double rowv[B];
@@ -176,10 +197,10 @@ __global__ __launch_bounds__(256) void ts_panel_qr(TsPanelArgs q) {
         for (int c = 0; c < B; ++c) {
             const bool in_v = c < q.reflectors;
             q.v[(size_t)g * B + c] = !in_v ? 0.0 : (g > c ? p[c] : (g == c ? 1.0 : 0.0));
-            // R (upper triangle of the first rows), zeros below; the transposed panel likewise
-            const double r = (g <= c || !in_v) ? p[c] : 0.0;
-            q.a[(size_t)(q.r0 + g) * q.n + q.j0 + c] = r;
-            q.a[(size_t)(q.j0 + c) * q.n + q.r0 + g] = r;
+            // R (upper triangle of the first rows), zeros below
+            // (only the panel itself: its mirror image above the diagonal is never read again - the trailing block starts
+            // below and to the right of it, the band is taken from the lower triangle)
+            q.a[(size_t)(q.r0 + g) * q.n + q.j0 + c] = (g <= c || !in_v) ? p[c] : 0.0;
         }
     }
     if (g >= q.m && g < q.m + 16) {  // sixteen zero rows behind the last one: the MFMA kernels read k in blocks of sixteen
@@ -189,6 +210,232 @@ __global__ __launch_bounds__(256) void ts_panel_qr(TsPanelArgs q) {
     __syncthreads();
     if (blockIdx.x == 0)
         for (int e = threadIdx.x; e < B * B; e += 256) q.t[e] = (e / B < q.reflectors && e % B < q.reflectors) ? tmat[e / B][e % B] : 0.0;
+}
+
+// ------------------------------------------------------------------------------------------------ stage 1: panel QR from the Gram matrix
+// ts_panel_qr pays a grid barrier per column (~25 us each, 0.9 ms per panel).  But everything a step needs from the rows
+// below the panel's top block are inner products of its CURRENT columns, and reflections leave the inner products of
+// whole columns unchanged:  sum_{g >= i} P(i)[g][a] P(i)[g][b] = G[a][b] - sum_{k < i} R[k][a] R[k][b]  with G = P^T P of the
+// untouched panel and R the rows already final.  So: ts_gram (G of the rows below the top block, MFMA), ts_qr_recur (ONE
+// workgroup runs all B steps on the top B x B block and G: reflector scales, the rows w(i), T), ts_qr_apply (every row
+// applies the B reflectors to itself) - no barrier at all.  The price is cancellation: the remaining norm of a column
+// comes as a difference, with an error of eps G[i][i]; the reflector built from it is orthogonal to eps G[i][i] / (what
+// remains).  ts_qr_recur therefore raises `unsafe` when less than 1 % of a column's squared norm remains (defect above
+// 1e-13), and the panel is then factorised by ts_panel_qr, which sums the rows themselves.
+constexpr double kTsGramFloor = 1e-2;
+
+__global__ __launch_bounds__(64) void ts_gram(const double* __restrict__ a, int n, int j0, int r0, int m, double* __restrict__ gpart) {
+    constexpr int B = kTsBand;
+    const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
+    const int g0 = B + blockIdx.x * 128, g1 = min(m, g0 + 128);  // rows of the panel below its top block
+    v4f64 acc[3];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) acc[p] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 4
+    for (int k = g0; k < g1; k += 4) {
+        const int row = k + kk;
+        double p0 = 0.0, p1 = 0.0;
+        if (row < g1) {
+            const double* src = a + (size_t)(r0 + row) * n + j0;
+            p0 = src[i];
+            p1 = src[i + 16];
+        }
+        acc[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, p0, acc[0], 0, 0, 0);
+        acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, p1, acc[1], 0, 0, 0);
+        acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, p1, acc[2], 0, 0, 0);
+    }
+    double* out = gpart + (size_t)blockIdx.x * B * B;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = kk + 4 * r;
+        out[(size_t)row * B + i] = acc[0][r];
+        out[(size_t)row * B + 16 + i] = acc[1][r];
+        out[(size_t)(16 + i) * B + row] = acc[1][r];
+        out[(size_t)(16 + row) * B + 16 + i] = acc[2][r];
+    }
+}
+
+struct TsRecurArgs {
+    const double* a;
+    int n, j0, r0, m, reflectors;
+    const double* gpart;
+    int parts;
+    double* scale;   // [B]  1 / (alpha - beta) of every reflector
+    double* beta;    // [B]
+    double* wrows;   // [B][B]  w(i)[c] = tau_i (row i of the current panel + scale_i S_c), c > i
+    double* t;       // [B][B]
+    unsigned* unsafe;  // raised when a column keeps less than kTsGramFloor of its squared norm
+};
+
+__global__ __launch_bounds__(256) void ts_qr_recur(TsRecurArgs q) {
+    constexpr int B = kTsBand, L = B + 1;
+    __shared__ double gt[B * L];    // G of the rows below the top block
+    __shared__ double top[B * L];   // the top block: rows final above the diagonal sweep (R), reflector entries below
+    __shared__ double top0[B * L];  // ... as it came
+    __shared__ double cm[B * L];    // current columns below the top block = original columns x cm
+    __shared__ double cv[B * L];    // reflector entries below the top block = original columns x cv
+    __shared__ double wm[B * L], vtv[B * L], tmat[B * L], m1[B * L];
+    __shared__ double rem[B], sc[B], be[B], ta[B];
+    __shared__ int bad;
+    const int t = threadIdx.x;
+    if (t == 0) bad = 0;
+    for (int e = t; e < B * B; e += 256) {
+        const int r = e / B, c = e % B;
+        double sum = 0.0;
+        for (int w = 0; w < q.parts; ++w) sum += q.gpart[(size_t)w * B * B + e];
+        gt[r * L + c] = sum;
+        const double v = r < q.m ? q.a[(size_t)(q.r0 + r) * q.n + q.j0 + c] : 0.0;
+        top[r * L + c] = v;
+        top0[r * L + c] = v;
+        cm[r * L + c] = r == c ? 1.0 : 0.0;
+        cv[r * L + c] = 0.0;
+        wm[r * L + c] = 0.0;
+        tmat[r * L + c] = 0.0;
+    }
+    __syncthreads();
+    // F = G + top0^T top0: inner products of the whole columns; `left` starts as F and loses R[k][a] R[k][b] with every
+    // finished row k: left[i][c] = inner product of the current columns i and c over the rows i.. (what step i needs)
+    for (int e = t; e < B * B; e += 256) {
+        const int r = e / B, c = e % B;
+        double full = gt[r * L + c];
+        for (int k = 0; k < B; ++k) full += top0[k * L + r] * top0[k * L + c];
+        vtv[r * L + c] = full;  // (F; vtv is free until the end)
+        m1[r * L + c] = full;   // left
+    }
+    __syncthreads();
+    for (int i = 0; i < q.reflectors; ++i) {
+        const double alpha = top[i * L + i];
+        const double rem_i = m1[i * L + i];
+        if (t == 0 && rem_i < kTsGramFloor * vtv[i * L + i]) bad = 1;
+        const double sigma = fmax(rem_i - alpha * alpha, 0.0);
+        double beta = alpha, tau = 0.0, scale = 0.0;
+        if (sigma > 0.0) {
+            beta = -copysign(sqrt(alpha * alpha + sigma), alpha);
+            tau = (beta - alpha) / beta;
+            scale = 1.0 / (alpha - beta);
+        }
+        if (t < B) {
+            const int c = t;
+            // S_c = sum over the rows below row i;  w_c = tau (P[i][c] + scale S_c)
+            wm[i * L + c] = c > i ? tau * (top[i * L + c] + scale * (m1[i * L + c] - alpha * top[i * L + c])) : 0.0;
+        }
+        if (t == 0) {
+            sc[i] = scale;
+            be[i] = beta;
+            ta[i] = tau;
+        }
+        __syncthreads();
+        for (int e = t; e < B * B; e += 256) {
+            const int g = e / B, c = e % B;
+            // the top block: rows i.. take the reflector
+            if (g >= i) {
+                const double vg = g == i ? 1.0 : top[g * L + i] * scale;
+                if (c > i) top[g * L + c] -= vg * wm[i * L + c];
+            }
+            // columns below the top block: column c loses scale w_c times column i
+            if (c > i) cm[g * L + c] -= scale * cm[g * L + i] * wm[i * L + c];
+        }
+        __syncthreads();
+        if (t < B) {
+            const int g = t;
+            cv[g * L + i] = scale * cm[g * L + i];
+            if (g == i) top[g * L + i] = beta;
+            else if (g > i) top[g * L + i] *= scale;
+        }
+        __syncthreads();
+        // row i is final: R[i][i] = beta, R[i][c] = top[i][c]; the columns' remaining inner products lose it
+        for (int e = t; e < B * B; e += 256) {
+            const int a = e / B, c = e % B;
+            if (a > i && c > i) m1[a * L + c] -= top[i * L + a] * top[i * L + c];
+        }
+        __syncthreads();
+    }
+    // V^T V = (top part) + cv^T G cv; then T column by column
+    for (int e = t; e < B * B; e += 256) {
+        const int r = e / B, c = e % B;
+        double sum = 0.0;
+        for (int k = 0; k < B; ++k) sum += gt[r * L + k] * cv[k * L + c];
+        m1[r * L + c] = sum;
+    }
+    __syncthreads();
+    for (int e = t; e < B * B; e += 256) {
+        const int r = e / B, c = e % B;  // columns r < c of V
+        double sum = 0.0;
+        if (r < c && c < q.reflectors) {
+            for (int k = 0; k < B; ++k) sum += cv[k * L + r] * m1[k * L + c];
+            for (int g = c; g < B; ++g) {  // rows of the top block where both reflectors live (v_c starts at row c)
+                const double vr = top[g * L + r];  // (g > r: stored entry)
+                const double vc = g == c ? 1.0 : top[g * L + c];
+                sum += vr * vc;
+            }
+        }
+        vtv[r * L + c] = sum;
+    }
+    __syncthreads();
+    for (int col = 0; col < q.reflectors; ++col) {
+        if (t < B) {
+            const int row = t;
+            if (row < col) {
+                double sum = 0.0;
+                for (int k = row; k < col; ++k) sum += tmat[row * L + k] * vtv[k * L + col];
+                tmat[row * L + col] = -ta[col] * sum;
+            } else if (row == col) {
+                tmat[row * L + col] = ta[col];
+            }
+        }
+        __syncthreads();
+    }
+    for (int e = t; e < B * B; e += 256) {
+        q.wrows[e] = wm[e / B * L + e % B];
+        q.t[e] = tmat[e / B * L + e % B];
+    }
+    if (t < B) {
+        q.scale[t] = t < q.reflectors ? sc[t] : 0.0;
+        q.beta[t] = t < q.reflectors ? be[t] : 0.0;
+    }
+    if (t == 0) *q.unsafe = bad ? 1u : 0u;
+}
+
+// every row applies the reflectors to itself (ts_qr_recur found them), writes its row of V, and R / zeros into A
+__global__ __launch_bounds__(256) void ts_qr_apply(double* __restrict__ a, int n, int j0, int r0, int m, int reflectors,
+                                                   const double* __restrict__ scale, const double* __restrict__ beta,
+                                                   const double* __restrict__ wrows, const unsigned* __restrict__ unsafe,
+                                                   double* __restrict__ v) {
+    constexpr int B = kTsBand;
+    if (*unsafe) return;  // (ts_panel_qr factorises this panel)
+    __shared__ double wm[B][B], sc[B], be[B];
+    for (int e = threadIdx.x; e < B * B; e += 256) wm[e / B][e % B] = wrows[e];
+    if (threadIdx.x < B) {
+        sc[threadIdx.x] = scale[threadIdx.x];
+        be[threadIdx.x] = beta[threadIdx.x];
+    }
+    __syncthreads();
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= m + 16) return;
+    if (g >= m) {
+#pragma unroll
+        for (int c = 0; c < B; ++c) v[(size_t)g * B + c] = 0.0;
+        return;
+    }
+    double p[B];
+#pragma unroll
+    for (int c = 0; c < B; ++c) p[c] = a[(size_t)(r0 + g) * n + j0 + c];
+#pragma unroll
+    for (int i = 0; i < B; ++i) {
+        if (i < reflectors && g >= i) {
+            const double vg = g == i ? 1.0 : p[i] * sc[i];
+#pragma unroll
+            for (int c = 0; c < B; ++c)
+                if (c > i) p[c] -= vg * wm[i][c];
+            p[i] = g == i ? be[i] : vg;
+        }
+    }
+#pragma unroll
+    for (int c = 0; c < B; ++c) {
+        const bool in_v = c < reflectors;
+        v[(size_t)g * B + c] = !in_v ? 0.0 : (g > c ? p[c] : (g == c ? 1.0 : 0.0));
+        a[(size_t)(r0 + g) * n + j0 + c] = (g <= c || !in_v) ? p[c] : 0.0;
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ stage 1: X = A22 V
@@ -233,17 +480,19 @@ __global__ __launch_bounds__(256) void ts_symm(const double* __restrict__ a, int
     }
 }
 
-// X = sum of the k slices (written out), and this wave's share of Z = V^T X (32 x 32, k = the wave's 256 rows), again MFMA:
-// A[i][k] = V[k][i], B[k][j] = X[k][j].
-__global__ __launch_bounds__(64) void ts_xz(const double* __restrict__ xpart, int slices, const double* __restrict__ v, int m,
-                                            double* __restrict__ x, double* __restrict__ zpart) {
+// X = sum of the k slices (written out), and the workgroup's share of Z = V^T X (32 x 32, k = its 256 rows: 64 per
+// wave, summed through LDS), again MFMA: A[i][k] = V[k][i], B[k][j] = X[k][j].
+__global__ __launch_bounds__(256) void ts_xz(const double* __restrict__ xpart, int slices, const double* __restrict__ v, int m,
+                                             double* __restrict__ x, double* __restrict__ zpart) {
     constexpr int B = kTsBand;
-    const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
-    const int g0 = blockIdx.x * 256, g1 = min(m, g0 + 256);
+    __shared__ double zs[4][B * B];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kk = lane >> 4;
+    const int g0 = blockIdx.x * 256 + wave * 64, g1 = min(m, g0 + 64);
     v4f64 acc[2][2];
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[p >> 1][p & 1] = v4f64{0.0, 0.0, 0.0, 0.0};
-    for (int k = g0; k < g1; k += 4) {
+#pragma unroll 4
+    for (int k = g0; k < g0 + 64; k += 4) {
         const int row = k + kk;
         double x0 = 0.0, x1 = 0.0, v0 = 0.0, v1 = 0.0;
         if (row < g1) {
@@ -261,11 +510,13 @@ __global__ __launch_bounds__(64) void ts_xz(const double* __restrict__ xpart, in
         acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, x0, acc[1][0], 0, 0, 0);
         acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, x1, acc[1][1], 0, 0, 0);
     }
-    double* out = zpart + (size_t)blockIdx.x * B * B;
 #pragma unroll
     for (int p = 0; p < 4; ++p)
 #pragma unroll
-        for (int r = 0; r < 4; ++r) out[(size_t)((p >> 1) * 16 + kk + 4 * r) * B + (p & 1) * 16 + i] = acc[p >> 1][p & 1][r];
+        for (int r = 0; r < 4; ++r) zs[wave][((p >> 1) * 16 + kk + 4 * r) * B + (p & 1) * 16 + i] = acc[p >> 1][p & 1][r];
+    __syncthreads();
+    double* out = zpart + (size_t)blockIdx.x * B * B;
+    for (int e = threadIdx.x; e < B * B; e += 256) out[e] = (zs[0][e] + zs[1][e]) + (zs[2][e] + zs[3][e]);
 }
 
 // M = T^T (sum of the Z parts) T / 2, one workgroup
@@ -329,13 +580,17 @@ __global__ __launch_bounds__(256) void ts_w(const double* __restrict__ x, const 
 // ------------------------------------------------------------------------------------------------ stage 1: rank-2B update
 // A22 <- A22 - [V | W] [W | V]^T, a wave per 32 x 32 tile (2 x 2 MFMA tiles: each fragment feeds two products), K = 2B =
 // four blocks of sixteen, operands straight from V and W (L2 resident) in the k order of ts_symm.
+// `first_strip`: 1 = only the first B columns of the block (the next panel and its top block: its factorisation then runs
+// beside the rest of the update), 0 = rows and columns from B on (the block the next panel's products read).  The first B
+// rows to the right of the diagonal block are never read again and stay as they are.
 __global__ __launch_bounds__(256) void ts_rank2k(double* __restrict__ a, int n, int r0, int m, const double* __restrict__ v,
-                                                 const double* __restrict__ w) {
+                                                 const double* __restrict__ w, int first_strip) {
     constexpr int B = kTsBand;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int i = lane & 15, kk = lane >> 4;
-    const int row0 = blockIdx.y * 64 + (wave >> 1) * 32, col0 = blockIdx.x * 64 + (wave & 1) * 32;
+    const int row0 = blockIdx.y * 64 + (wave >> 1) * 32, col0 = first_strip ? 0 : B + blockIdx.x * 64 + (wave & 1) * 32;
     if (row0 >= m || col0 >= m) return;
+    if (first_strip ? (wave & 1) != 0 : row0 < B) return;
     v4f64 acc[2][2];
 #pragma unroll
     for (int p = 0; p < 4; ++p) acc[p >> 1][p & 1] = v4f64{0.0, 0.0, 0.0, 0.0};
@@ -393,165 +648,223 @@ struct TsChaseArgs {
     unsigned* ticket;    // next sweep
     unsigned* gave_up;   // raised by a wave that has polled too long (the host then reports an error)
     unsigned timeout_ticks;
+    // All sweeps run on ONE XCD (the first wave to arrive proposes its own, read from the hardware register; waves that
+    // find themselves elsewhere leave): band entries and progress words then meet in that XCD's L2 - plain stores and
+    // L1-bypassing loads, 1.5 us per hand-over instead of 4.5 through memory.  0xFFFFFFFF = not chosen yet.
+    unsigned* xcd;
+    unsigned long long* profile;  // nullptr, or [8] ticks (100 MHz) the sweeps spent per phase of a step, summed (measurements)
 };
 
 __global__ __launch_bounds__(64) void ts_chase(TsChaseArgs q) {
     constexpr int B = kTsBand, LD = kTsBandLd, LB = kTsLdb;
     constexpr int PER = B * B / 64;  // block entries per lane
-    __shared__ double g[B * LB], s[B * LB], g2[B * LB];
-    __shared__ double vv[B], pw[B], uu[B];
+    // The three blocks of a step live in registers.  Layout A (how the band is read and written: consecutive lanes walk
+    // down a column): lane = (row i = lane & 31, parity hp = lane >> 5), register e = column 2 e + hp - row sums are sums
+    // over a lane's registers.  Column sums (the reflector from the left on G) want layout B: lane = (column c = lane & 31,
+    // half hp), register t = row 16 hp + t; G changes layout through LDS once per step, S is made symmetric through it.
+    __shared__ double buf[B * LB];
+    __shared__ double vec[B], wvec[B];
     const int lane = threadIdx.x;
-    const int c = lane & 31, half = lane >> 5;
+    const int li = lane & 31, hp = lane >> 5;
     const int n = q.n;
     const TsBuffer band(q.ab, (size_t)(n + 4 * B) * LD);
+    const TsWords progress(q.progress, (size_t)n);
+    {
+        const unsigned here = __builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu;  // HW_REG_XCC_ID
+        unsigned chosen = 0;
+        if (lane == 0) {
+            const unsigned before = atomicCAS(q.xcd, 0xFFFFFFFFu, here);
+            chosen = before == 0xFFFFFFFFu ? here : before;
+        }
+        if (__builtin_amdgcn_readfirstlane(chosen) != here) return;
+    }
     auto wave_sync = [] {
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
         __builtin_amdgcn_wave_barrier();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
     };
+    // sum over the 32 rows (lanes of one parity), the same value in every lane of that parity afterwards
+    auto sum_rows = [](double v) {
+#pragma unroll
+        for (int off = 16; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        return v;
+    };
+    unsigned long long spent[8] = {0, 0, 0, 0, 0, 0, 0, 0}, mark = 0;
+    auto lap = [&](int phase) {
+        if (q.profile) {
+            const unsigned long long now = wall_clock64();
+            spent[phase] += now - mark;
+            mark = now;
+        }
+    };
     for (;;) {
         unsigned jt = 0;
         if (lane == 0) jt = __hip_atomic_fetch_add(q.ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         const int j = (int)__builtin_amdgcn_readfirstlane(jt);
-        if (j >= n - 2) return;
-        // has the sweep before finished `need` steps (or left the matrix)?  blocking, or one look
-        auto ready = [&](unsigned need, bool block) -> int {  // 1 yes, 0 not yet, -1 give up
-            if (j == 0) return 1;
+        if (j >= n - 2) break;
+        // blocks until the sweep before has finished `need` steps (or left the matrix); false = give up
+        auto wait_for = [&](unsigned need) -> bool {
+            if (j == 0) return true;
             const unsigned long long t0 = wall_clock64();
             for (;;) {
-                if (__hip_atomic_load(q.progress + j - 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= need) return 1;
-                if (!block) return 0;
+                if (progress.load_l2((size_t)j - 1) >= need) return true;
                 if (wall_clock64() - t0 > (unsigned long long)q.timeout_ticks ||
                     __hip_atomic_load(q.gave_up, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
                     if (lane == 0) __hip_atomic_store(q.gave_up, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    return -1;
+                    return false;
                 }
                 __builtin_amdgcn_s_sleep(1);
             }
         };
-        // entries of S (both triangles from the stored lower one) and of G2 of step k, this lane's share, to registers
-        double sv[PER], gv[PER];
+        // layout A: the lower triangle of S (zeros above) and G2 of step k
+        double s_next[PER], g2_next[PER];
         auto fetch = [&](int k) {
             const int r = j + 1 + k * B, h = min(B, n - r), h2 = min(B, n - r - h);
 #pragma unroll
             for (int e = 0; e < PER; ++e) {
-                const int idx = lane + 64 * e, i = idx % B, cc = idx / B;  // consecutive lanes walk down a column
-                const int lo = min(i, cc), hi = max(i, cc);
-                sv[e] = (i < h && cc < h) ? band.load((size_t)(r + lo) * LD + (hi - lo)) : 0.0;
-                gv[e] = (i < h2 && cc < h) ? band.load((size_t)(r + cc) * LD + (B + i - cc)) : 0.0;
+                const int cc = 2 * e + hp;
+                s_next[e] = (li < h && cc <= li) ? band.load_l2((size_t)(r + cc) * LD + (li - cc)) : 0.0;
+                g2_next[e] = (li < h2 && cc < h) ? band.load_l2((size_t)(r + cc) * LD + (B + li - cc)) : 0.0;
             }
         };
-        if (ready(3, true) < 0) return;
+        if (!wait_for(3)) return;
         ts_compiler_fence();
         fetch(0);
+        double ga[PER];  // G in layout A (from step 1 on: the G2 of the step before)
+#pragma unroll
+        for (int e = 0; e < PER; ++e) ga[e] = 0.0;
+        if (q.profile) mark = wall_clock64();
         for (int k = 0;; ++k) {
             const int r = j + 1 + k * B;
             const int h = min(B, n - r);       // rows of the reflector (>= 2)
             const int h2 = min(B, n - r - h);  // rows of the block below
             const bool last = h2 <= 1;         // the next step would have a reflector of at most one row: the sweep ends
-            double xi = 0.0;  // lanes 0 .. B-1: entry i of the column to annihilate
-            if (k == 0 && lane < h) xi = band.load((size_t)j * LD + 1 + lane);
+            double sa[PER], g2a[PER];
 #pragma unroll
             for (int e = 0; e < PER; ++e) {
-                const int idx = lane + 64 * e, i = idx % B, cc = idx / B;
-                s[i * LB + cc] = sv[e];
-                g2[i * LB + cc] = gv[e];
+                sa[e] = s_next[e];
+                g2a[e] = g2_next[e];
             }
+            // how far is the sweep before?  (asked now, looked at after the next LDS round trip)
+            const unsigned seen = (!last && j > 0) ? progress.load_l2((size_t)j - 1) : kTsSweepDone;
+            double xi = 0.0;  // lanes of parity 0: entry li of the column to annihilate
+            if (k == 0) {
+                if (hp == 0 && li < h) xi = band.load_l2((size_t)j * LD + 1 + li);
+            } else if (hp == 0) {
+                xi = ga[0];
+            }
+            // ---- S symmetric: the stored lower triangle goes through LDS, every lane picks up what lies above its diagonal
+#pragma unroll
+            for (int e = 0; e < PER; ++e) buf[li * LB + 2 * e + hp] = sa[e];
             wave_sync();
-            // the blocks of the next step, if the sweep before is far enough already (else after this step)
+#pragma unroll
+            for (int e = 0; e < PER; ++e) {
+                const int cc = 2 * e + hp;
+                const double mirrored = buf[cc * LB + li];
+                if (cc > li) sa[e] = mirrored;
+            }
+            lap(0);
             bool fetched = false;
-            if (!last && ready((unsigned)(k + 4), false) > 0) {
+            if (!last && seen >= (unsigned)(k + 4)) {
                 ts_compiler_fence();
                 fetch(k + 1);
                 fetched = true;
             }
-            // ---- the reflector
-            if (k > 0 && lane < B) xi = g[lane * LB + 0];
-            double sq = (lane >= 1 && lane < B) ? xi * xi : 0.0;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) sq += __shfl_xor(sq, off);
-            const double alpha = __shfl(xi, 0);
+            lap(1);
+            // ---- the reflector (lanes of parity 0 hold the column, then everybody its own row's entry)
+            const double sq = sum_rows((hp == 0 && li >= 1) ? xi * xi : 0.0);
+            const double sq0 = __shfl(sq, 0), alpha = __shfl(xi, 0);
             double beta = alpha, tau = 0.0, scale = 0.0;
-            if (sq > 0.0) {
-                beta = -copysign(sqrt(alpha * alpha + sq), alpha);
+            if (sq0 > 0.0) {
+                beta = -copysign(sqrt(alpha * alpha + sq0), alpha);
                 tau = (beta - alpha) / beta;
                 scale = 1.0 / (alpha - beta);
             }
-            if (lane < B) vv[lane] = lane == 0 ? 1.0 : (lane < h ? xi * scale : 0.0);
-            wave_sync();
-            // the annihilated column: (beta, 0, ..., 0)
-            if (k == 0) {
-                if (lane < h) band.store((size_t)j * LD + 1 + lane, lane == 0 ? beta : 0.0);
-            } else {
-                if (lane < B) g[lane * LB + 0] = lane == 0 ? beta : 0.0;
-                // ---- from the left on the other columns of G: column c (its half of the rows)
-                if (c >= 1) {
-                    double dot = 0.0;
+            double vi = li == 0 ? 1.0 : (li < h ? xi * scale : 0.0);
+            vi = __shfl(vi, li);  // (parity 1 takes its row's entry from parity 0)
+            wave_sync();          // (buf has been read)
+            if (hp == 0) vec[li] = vi;
+            if (k > 0) {
+                // G to layout B through LDS, its first column already (beta, 0, ..., 0)
+                if (hp == 0) ga[0] = li == 0 ? beta : 0.0;
 #pragma unroll
-                    for (int i = 16 * half; i < 16 * half + 16; ++i) dot += vv[i] * g[i * LB + c];
-                    dot += __shfl_xor(dot, 32);
-                    dot *= tau;
-#pragma unroll
-                    for (int i = 16 * half; i < 16 * half + 16; ++i) g[i * LB + c] -= vv[i] * dot;
-                }
+                for (int e = 0; e < PER; ++e) buf[li * LB + 2 * e + hp] = ga[e];
+            } else if (hp == 0 && li < h) {
+                band.store_l2((size_t)j * LD + 1 + li, li == 0 ? beta : 0.0);
             }
+            wave_sync();
+            double vcol[PER];  // v at this lane's columns (layout A)
+#pragma unroll
+            for (int e = 0; e < PER; ++e) vcol[e] = vec[2 * e + hp];
+            lap(2);
+            if (k > 0) {
+                // ---- from the left on G (layout B: lane = column li, rows 16 hp ..): column sums in the lane
+                double gb[PER], vrow[PER];
+#pragma unroll
+                for (int t = 0; t < PER; ++t) {
+                    gb[t] = buf[(16 * hp + t) * LB + li];
+                    vrow[t] = vec[16 * hp + t];
+                }
+                double dot = 0.0;
+#pragma unroll
+                for (int t = 0; t < PER; ++t) dot += vrow[t] * gb[t];
+                dot += __shfl_xor(dot, 32);
+                dot = li >= 1 ? tau * dot : 0.0;  // (column 0 is the annihilated one)
+                const size_t at = (size_t)(r - B + li) * LD + (B + 16 * hp - li);  // rows 16 hp .. of column li: contiguous
+#pragma unroll
+                for (int t = 0; t < PER; ++t)
+                    if (16 * hp + t < h) band.store_l2(at + t, gb[t] - vrow[t] * dot);
+            }
+            lap(3);
             // ---- two-sided on S:  p = tau S v,  w = p - (tau p.v / 2) v,  S -= v w^T + w v^T
             {
                 double dot = 0.0;
 #pragma unroll
-                for (int i = 16 * half; i < 16 * half + 16; ++i) dot += s[i * LB + c] * vv[i];  // (S symmetric: column c = row c)
+                for (int e = 0; e < PER; ++e) dot += sa[e] * vcol[e];
                 dot += __shfl_xor(dot, 32);
-                const double pc = tau * dot;
-                double pv = half == 0 ? pc * vv[c] : 0.0;
-#pragma unroll
-                for (int off = 32; off >= 1; off >>= 1) pv += __shfl_xor(pv, off);
-                const double wc = pc - 0.5 * tau * pv * vv[c];
-                if (half == 0) pw[c] = wc;
+                const double pi = tau * dot;
+                const double pv = __shfl(sum_rows(hp == 0 ? pi * vi : 0.0), 0);
+                const double wi = pi - 0.5 * tau * pv * vi;
+                if (hp == 0) wvec[li] = wi;
                 wave_sync();
-                const double vc = vv[c];
 #pragma unroll
-                for (int i = 16 * half; i < 16 * half + 16; ++i) s[i * LB + c] -= vv[i] * wc + pw[i] * vc;
+                for (int e = 0; e < PER; ++e) {
+                    const int cc = 2 * e + hp;
+                    sa[e] -= vi * wvec[cc] + wi * vcol[e];
+                    if (li < h && cc <= li) band.store_l2((size_t)(r + cc) * LD + (li - cc), sa[e]);
+                }
             }
-            // ---- from the right on G2:  u = G2 v (row sums: lane = row), G2 -= tau u v^T
+            lap(4);
+            // ---- from the right on G2:  u = tau G2 v (row sums),  G2 -= u v^T;  it is the G of the next step
             if (h2 > 0) {
                 double dot = 0.0;
 #pragma unroll
-                for (int cc = 16 * half; cc < 16 * half + 16; ++cc) dot += g2[c * LB + cc] * vv[cc];  // (lane c = row c)
+                for (int e = 0; e < PER; ++e) dot += g2a[e] * vcol[e];
                 dot += __shfl_xor(dot, 32);
-                if (half == 0) uu[c] = tau * dot;
-                wave_sync();
-                const double vc = vv[c];
-#pragma unroll
-                for (int i = 16 * half; i < 16 * half + 16; ++i) g2[i * LB + c] -= uu[i] * vc;
-            }
-            wave_sync();
-            // ---- store G (done with for this sweep) and the lower triangle of S; G2 becomes the next G (kept in LDS),
-            // or is stored as well when the sweep ends here
-#pragma unroll
-            for (int e = 0; e < PER; ++e) {
-                const int idx = lane + 64 * e, i = idx % B, cc = idx / B;
-                if (k > 0 && i < h) band.store((size_t)(r - B + cc) * LD + (B + i - cc), g[i * LB + cc]);
-                if (i < h && cc <= i) band.store((size_t)(r + cc) * LD + (i - cc), s[i * LB + cc]);
-                if (last && i < h2 && cc < h) band.store((size_t)(r + cc) * LD + (B + i - cc), g2[i * LB + cc]);
-            }
-            if (!last) {
+                const double ui = tau * dot;
 #pragma unroll
                 for (int e = 0; e < PER; ++e) {
-                    const int idx = lane + 64 * e;
-                    g[idx / B * LB + idx % B] = g2[idx / B * LB + idx % B];
+                    g2a[e] -= ui * vcol[e];
+                    if (last && li < h2 && 2 * e + hp < h) band.store_l2((size_t)(r + 2 * e + hp) * LD + (B + li - (2 * e + hp)), g2a[e]);
                 }
             }
+#pragma unroll
+            for (int e = 0; e < PER; ++e) ga[e] = g2a[e];
+            lap(5);
+            lap(6);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (lane == 0)
-                __hip_atomic_store(q.progress + j, last ? kTsSweepDone : (unsigned)(k + 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            lap(7);
+            if (lane == 0) progress.store_l2((size_t)j, last ? kTsSweepDone : (unsigned)(k + 1));
             if (last) break;
             if (!fetched) {
-                if (ready((unsigned)(k + 4), true) < 0) return;
+                if (!wait_for((unsigned)(k + 4))) return;
                 ts_compiler_fence();
                 fetch(k + 1);
             }
         }
     }
+    if (q.profile && lane == 0)
+        for (int phase = 0; phase < 8; ++phase) atomicAdd(q.profile + phase, spent[phase]);
 }
 
 // d[c] = A[c][c], e[c] = A[c + 1][c]

@@ -101,9 +101,9 @@ def _auto_method(system, temperature: float, moments, scale) -> str:
     """Dense or Chebyshev for `free_energy(method="auto")`, by estimated run time.
 
     The dense route needs eigenvalues only: the library's own Householder tridiagonalisation +
-    bisection (csrc/tridiag.hpp; no rocSOLVER), 8 ms at 4N = 512, 0.105 s at 3600, 1.1 s at 10^4,
-    i.e. ≈ 2.3e-12·(4N)³ s (1.1e-12 from 5000 rows on) above a floor of ≈ 18 µs per row (two launches), and the Jacobi kernels
-    below 4N = 512.  T = 0: dense up to 4N = 8192; above, the Chebyshev expansion of the smoothed
+    bisection (csrc/tridiag.hpp; no rocSOLVER), 8 ms at 4N = 512, 0.09 s at 3600, i.e. ≈ 2.0e-12·(4N)³ s above a floor of
+    ≈ 18 µs per row (two launches); from 6000 rows on real matrices go through a band (csrc/twostage.hpp: 0.36 s at 10^4,
+    7.8 s at 4·10^4), complex ones stay one-stage (1.1e-12·(4N)³ s); the Jacobi kernels below 4N = 512.  T = 0: dense up to 4N = 8192; above, the Chebyshev expansion of the smoothed
     density -(ε/4)·erf(5ε/gap) (see `free_energy`) when the spectrum is gapped enough, else dense.
     Matrices without the particle-hole form must go dense.  Otherwise the two routes are priced:
     an exact-trace Chebyshev run costs M/2 launches per batch of 64 unit vectors, each ≥ 7 µs or its
@@ -127,8 +127,16 @@ def _auto_method(system, temperature: float, moments, scale) -> str:
     batches = -(-(dim // 2) // 64) if dim <= EXACT_TRACE_LIMIT else 1  # electron rows only
     launch = max(7e-6, (dim // 4) * 64 * 192 / 5e12)
     chebyshev_seconds = 0.5 * m * batches * launch
-    # (tridiagonalisation + bisection: ~18 us per row, 2.3e-12 dim^3 s below 5000 rows, 1.1e-12 dim^3 above - pending updates)
-    dense_seconds = 6e-11 * dim**3 if dim <= 512 else max(1.8e-5 * dim, (2.3e-12 if dim < 5000 else 1.1e-12) * dim**3)
+    # (tridiagonalisation + bisection: ~18 us per row, 2.0e-12 dim^3 s below 6000 rows; from there on real matrices take the
+    # two-stage route - band by MFMA panels, bulge chasing: 0.36 s at 10^4, 7.8 s at 4e4 - complex ones 1.1e-12 dim^3)
+    if dim <= 512:
+        dense_seconds = 6e-11 * dim**3
+    elif dim < 6000:
+        dense_seconds = max(1.8e-5 * dim, 2.0e-12 * dim**3)
+    elif system._memoized("imag_free", lambda: not bool(system._data.imag.any())):
+        dense_seconds = 1.5e-5 * dim + 1.2e-13 * dim**3 + 1.0e-9 * dim**2
+    else:
+        dense_seconds = 1.1e-12 * dim**3
     return "dense" if dense_seconds <= chebyshev_seconds else "chebyshev"
 
 

@@ -50,7 +50,9 @@ def _system(rng, case):
     return s, f"case {case}: {shape} {kind}"
 
 
-def run(seed: int = 0, n_cases: int = 100) -> int:
+def run(seed: int = 0, n_cases: int = 100, stages: str | None = None) -> int:
+    """`stages="2"`: the eigenvalues through the two-stage route (csrc/twostage.hpp: band by MFMA panels, bulge chasing) for every
+    real matrix large enough for a band (4N > 66) - the eigenvectors keep the one-stage route either way."""
     rng = np.random.default_rng(seed)
     failures, t_start = 0, time.time()
     for case in range(n_cases):
@@ -59,11 +61,13 @@ def run(seed: int = 0, n_cases: int = 100) -> int:
         dense = np.asarray(system.matrix("dense"))
         exact = np.linalg.eigvalsh(dense)
         scale = max(1.0, np.abs(exact).max())
-        with DeviceSolver.from_hamiltonian(system) as dev, backend.options(BODGE_AMD_EIGH="tridiagonal"):
+        extra = {"BODGE_AMD_EIGH_STAGES": stages} if stages else {}
+        with DeviceSolver.from_hamiltonian(system) as dev, backend.options(BODGE_AMD_EIGH="tridiagonal", **extra):
             w, _ = dev.eigh(vectors=False)
             w2, z = dev.eigh_above(0.0)
         problems = []
-        if not (np.abs(w - exact).max() <= 1e-11 * scale and np.array_equal(w, w2)):
+        same = np.array_equal(w, w2) if not stages else np.abs(w - w2).max() <= 1e-11 * scale  # (two routes: rounding apart)
+        if not (np.abs(w - exact).max() <= 1e-11 * scale and same):
             problems.append(f"eigenvalues off by {np.abs(w - exact).max():.1e}")
         vals = w2[w2 > 0]
         if z.shape != (dim, vals.size) or not np.isfinite(z).all():
@@ -83,4 +87,4 @@ def run(seed: int = 0, n_cases: int = 100) -> int:
 
 
 if __name__ == "__main__":
-    sys.exit(1 if run(int(os.environ.get("FUZZ_SEED", "0")), int(os.environ.get("FUZZ_CASES", "100"))) else 0)
+    sys.exit(1 if run(int(os.environ.get("FUZZ_SEED", "0")), int(os.environ.get("FUZZ_CASES", "100")), os.environ.get("FUZZ_STAGES")) else 0)

@@ -35,6 +35,13 @@ def solver_cls(hip_library):
     return DeviceSolver
 
 
+def _dense_once(block_storage, dim, limit=2000):
+    """The dense routes scatter the uploaded BSR triple to a dense array: how the recurrence kernels keep the blocks
+    (dictionary or streamed) plays no part.  Large systems therefore run in one of the two module-wide variants."""
+    if block_storage != "dictionary" and dim > limit:
+        pytest.skip("dense route: independent of the block storage of the recurrence kernels; large systems run once")
+
+
 def _build(api, name):
     spec = systems.CATALOG[name]
     return spec["build"](api, **spec["kwargs"])
@@ -1434,7 +1441,7 @@ def test_exact_zero_modes_count_once_per_pair(api):
 
 @pytest.mark.parametrize("name", ["swave20", "complex235", "random357", "snf", "chain128", "dwave8", "swave30_zeeman",
                                   "peierls30", "chain300", "swave50_zeeman"])
-def test_eigenvalues_by_tridiagonalisation_match_the_reference(api, golden, knobs, name):
+def test_eigenvalues_by_tridiagonalisation_match_the_reference(api, golden, knobs, block_storage, name):
     """The eigenvalues-only dense route (csrc/tridiag.hpp: Householder tridiagonalisation with lazily
     applied rank-2 updates + Sturm bisection, real or complex arithmetic by imag(H)) needs no rocSOLVER:
     all 4N eigenvalues against numpy (4N <= 4000) and the positive half against the reference's
@@ -1443,6 +1450,7 @@ def test_eigenvalues_by_tridiagonalisation_match_the_reference(api, golden, knob
     which takes this route from 4N > 512 on, against the reference's values."""
     system = _build(api, name)
     dim = system.shape[0]
+    _dense_once(block_storage, dim)
     ref = golden.eigenvalues(name)
     knobs.set("BODGE_AMD_EIGH", "tridiagonal")
     w, vectors = system._solver().eigh(vectors=False)
@@ -1471,8 +1479,41 @@ def test_eigenvalues_by_tridiagonalisation_match_the_reference(api, golden, knob
             assert abs(value - expect) <= 1e-10 * abs(value)
 
 
+@pytest.mark.parametrize("name,options", [
+    ("swave30_zeeman", {"BODGE_AMD_EIGH_STAGES": "2"}),                                   # n = 3600: forced (default from 6000 rows)
+    ("swave30_zeeman", {"BODGE_AMD_EIGH_STAGES": "2", "BODGE_AMD_EIGH_GRAM_QR": "0"}),      # every panel with a grid barrier per column
+    ("swave30_zeeman", {"BODGE_AMD_EIGH_STAGES": "2", "BODGE_AMD_EIGH_LOOKAHEAD": "1"}),    # next panel factorised beside the update
+    ("chain300", {"BODGE_AMD_EIGH_STAGES": "2"}),                                         # n = 1200, a chain: panels of few non-zeros
+    ("dwave8", {"BODGE_AMD_EIGH_STAGES": "2"}),                                           # zero modes, 3-D
+    ("swave50_zeeman", {}),                                                               # n = 10^4: the default route
+])
+def test_eigenvalues_by_the_two_stage_route_match_the_reference(api, golden, knobs, block_storage, name, options):
+    """K10 (csrc/twostage.hpp): real symmetric matrix -> band of half-width 32 by block Householder panels (Gram-matrix QR,
+    fp64 MFMA products) -> tridiagonal by pipelined bulge chasing -> bisection.  Eigenvalues against the reference's
+    diagonalize() (1e-10; measured 2e-13), against numpy up to 4000 rows, and against the one-stage route."""
+    system = _build(api, name)
+    dim = system.shape[0]
+    _dense_once(block_storage, dim, limit=0)
+    ref = golden.eigenvalues(name)
+    knobs.set("BODGE_AMD_EIGH", "tridiagonal")
+    knobs.set("BODGE_AMD_EIGH_STAGES", "1")
+    one, _ = system._solver().eigh(vectors=False)
+    knobs.unset("BODGE_AMD_EIGH_STAGES")
+    knobs.update(options)
+    two, _ = system._solver().eigh(vectors=False)
+    assert two.shape == (dim,) and np.all(np.diff(two) >= 0)
+    assert np.abs(two - one).max() <= 1e-11 * max(1.0, np.abs(one).max())
+    assert np.abs(two[dim // 2:] - ref).max() <= 1e-10
+    if dim <= 4000:
+        assert np.abs(two - np.linalg.eigvalsh(np.asarray(system.matrix("dense")))).max() <= 1e-10
+    for temperature in systems.CATALOG[name]["temps"]:
+        if not np.count_nonzero(np.abs(two) < 1e-12):
+            value = system.free_energy(temperature, method="dense")
+            assert abs(value - golden.free_energy(name, temperature)) <= 1e-10 * abs(value)
+
+
 @pytest.mark.parametrize("name", ["swave30_zeeman", "peierls30", "chain300", "swave50_zeeman", "dwave8", "snf"])
-def test_dense_ladder_without_a_library(api, golden, name):
+def test_dense_ladder_without_a_library(api, golden, block_storage, name):
     """BASELINE config 5's feasible ladder through the DEFAULT route of `diagonalize()` - the library's own
     Householder tridiagonalisation, bisection, inverse iteration and back-transformation (csrc/tridiag.hpp),
     no rocSOLVER: n = 3600 real and complex, the literal "300" chain (n = 1200), n = 10^4, and two smaller
@@ -1482,6 +1523,7 @@ def test_dense_ladder_without_a_library(api, golden, name):
     object mapped into the process afterwards."""
     system = _build(api, name)
     dim = system.shape[0]
+    _dense_once(block_storage, dim)
     vals, vecs = system.diagonalize(format="raw")
     ref = golden.eigenvalues(name)
     zero_modes = int(np.count_nonzero(ref < 1e-12))
@@ -1601,10 +1643,11 @@ def test_lowest_eigenpairs_of_a_tiny_matrix(api):
 
 
 @pytest.mark.parametrize("name", ["swave30_zeeman", "peierls30"])
-def test_own_jacobi_kernels_reach_4096_rows(api, golden, knobs, name):
+def test_own_jacobi_kernels_reach_4096_rows(api, golden, knobs, block_storage, name):
     """Between 4N = 2048 and 4096 the own one-sided Jacobi kernels (16 elements per thread) serve
     for as long as the rocSOLVER object has not arrived from cold storage; forced here.  n = 3600,
     real and complex, against the reference's own spectra: eigenvalues 1e-10, residual 1e-9."""
+    _dense_once(block_storage, 3600)
     knobs.set("BODGE_AMD_EIGH", "jacobi")
     system = _build(api, name)
     vals, vecs = system.diagonalize(format="raw")
