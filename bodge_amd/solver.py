@@ -458,9 +458,19 @@ class Communicator:
                 uid = store.get(key, timeout)
             if len(uid) != 128:
                 raise RuntimeError(f"rank {rank}: rendezvous returned {len(uid)} bytes instead of an RCCL id")
-        # one process per GPU; more ranks than GPUs wrap around and RCCL reports the duplicate
+        # one process per GPU; more ranks than GPUs wrap around.  RCCL refuses two ranks on one device ("invalid usage"),
+        # but only after its bootstrap and topology search - tens of seconds per rank: the ranks compare (host, device)
+        # over the rendezvous store first and give the same answer at once
         count = backend.device_count()
-        comm = cls(rank, world, local % count if count > 0 else local, uid)
+        device = local % count if count > 0 else local
+        if world > 1:
+            import socket
+
+            places = [blob.decode() for blob in store.gather(f"{socket.gethostname()}/{device}".encode())]
+            clash = sorted({place for place in places if places.count(place) > 1})
+            if clash:
+                raise RuntimeError(f"rank {rank}: {world} ranks but some share a GPU ({', '.join(clash)}): RCCL refuses duplicate devices")
+        comm = cls(rank, world, device, uid)
         comm.barrier()
         return comm
 

@@ -64,6 +64,8 @@ def _run(seed, n_cases, size, lanczos) -> int:
         if rng.random() < 0.2: env["BODGE_AMD_ALTERNATE"] = "0"
         if rng.random() < 0.3: env["BODGE_AMD_STREAMS"] = str(rng.choice([1, 2, 3, 4]))  # batches side by side on that many streams
         if rng.random() < 0.15: env["BODGE_AMD_KEEP_LAST"] = "1"
+        # the sweeps of a chunk in one launch (cheb_march3): tickets, fixed units, or one launch per sweep for all lane groups
+        if rng.random() < 0.3: env["BODGE_AMD_MARCH"] = str(rng.choice([1, 2, 3]))
         # a third of the cases start from unit vectors (LDOS): the stencil kernels then advance a band of planes only
         unit = rng.random() < 0.33
         if unit:
@@ -87,7 +89,7 @@ def _run(seed, n_cases, size, lanczos) -> int:
         n = 4 * lat.size
         err = max(np.abs(got[0] - one[0]).max(), np.abs(got[1] - one[1]).max()) / (1.0 if unit else n)
         tag = (f"case {case}: {shape} {model} steps={steps} vectors={vectors} {'unit' if unit else f'kind={kind}'} {env} -> steps/launch "
-               f"{perf['steps_per_launch']} rolling {perf['rolling']} onsite-streamed {perf['onsite_streamed']} streams {perf['streams']}")
+               f"{perf['steps_per_launch']} rolling {perf['rolling']} onsite-streamed {perf['onsite_streamed']} streams {perf['streams']} persistent {perf['persistent']}")
         if not err <= 1e-12:
             failures += 1
             print("FAIL", tag, "err", err, flush=True)
