@@ -765,7 +765,20 @@ inline void scatter_for_tridiagonal(bdg_system* sys, double* a, hipStream_t st) 
 // ascending) in the 4*nb complex entries from z_out + 8*nb*m.
 // K10 (twostage.hpp): a (n x n real symmetric, row-major, both triangles; overwritten) -> diagonal d and sub-diagonal e of
 // an orthogonally similar tridiagonal matrix, through a band of half-width kTsBand.  Everything is enqueued on `st`.
-int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStream_t st) {
+// What the eigenvectors of the two-stage route need afterwards: the block reflectors of stage 1 (V and T of every
+// panel) and the band matrix as it was before the bulge chasing, by rows.
+struct TsKeep {
+    DeviceBuffer<double> v_all, t_all, full;
+    std::vector<int64_t> v_at;   // offset of panel p's V (m_p + 16 rows of B entries) in v_all
+    std::vector<int64_t> rows;   // m_p
+    void release() {
+        v_all.release();
+        t_all.release();
+        full.release();
+    }
+};
+
+int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStream_t st, TsKeep* keep = nullptr) {
     constexpr int B = bdg::kTsBand;
     DeviceBuffer<double> work, band;
     DeviceBuffer<unsigned> sync;
@@ -809,6 +822,19 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
         // stream beside the bulk of panel p's rank-2B update: first the strip of the update that panel p + 1 lives in,
         // then both at once.  V alternates between two buffers (the update still reads panel p's).
         double* vbuf[2] = {v, v2};
+        if (keep) {
+            int64_t total = 0;
+            for (int64_t j0 = 0; j0 + B + 1 < n; j0 += B) {
+                keep->v_at.push_back(total);
+                keep->rows.push_back(n - j0 - B);
+                total += (n - j0 - B + 16) * B;
+            }
+            if (int rc = keep->v_all.reserve((size_t)std::max<int64_t>(total, 1))) return rc;
+            if (int rc = keep->t_all.reserve((size_t)std::max<int64_t>(n_panels, 1) * B * B)) return rc;
+            if (int rc = keep->full.reserve((size_t)(n + B + 2) * bdg::kTsRowLd)) return rc;
+        }
+        auto v_of = [&](int64_t panel) { return keep ? keep->v_all.ptr + keep->v_at[(size_t)panel] : vbuf[panel & 1]; };
+        auto t_of = [&](int64_t panel) { return keep ? keep->t_all.ptr + (size_t)panel * B * B : t; };
         auto factorise = [&](int64_t panel, int64_t j0, hipStream_t on) -> int {
             const int64_t r0 = j0 + B, m = n - r0;
             bdg::TsPanelArgs q{};
@@ -818,8 +844,8 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
             q.r0 = (int)r0;
             q.m = (int)m;
             q.reflectors = (int)std::min<int64_t>(B, m - 1);
-            q.v = vbuf[panel & 1];
-            q.t = t;
+            q.v = v_of(panel);
+            q.t = t_of(panel);
             q.partial = partial;
             q.rowi = rowi;
             q.counter = panel_counter + panel;
@@ -842,7 +868,7 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
                 rc.scale = qr_scale;
                 rc.beta = qr_beta;
                 rc.wrows = qr_w;
-                rc.t = t;
+                rc.t = t_of(panel);
                 rc.unsafe = unsafe + panel;
                 bdg::ts_qr_recur<<<1, 256, 0, on>>>(rc);
                 bdg::ts_qr_apply<<<qr_grid, 256, 0, on>>>(a, (int)n, (int)j0, (int)r0, (int)m, q.reflectors, qr_scale, qr_beta, qr_w,
@@ -865,7 +891,8 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
             if (int rc = factorise(0, 0, st)) return rc;
         for (int64_t j0 = 0; j0 + B + 1 < n; j0 += B, ++panel) {
             const int64_t r0 = j0 + B, m = n - r0;
-            const double* vp = vbuf[panel & 1];
+            const double* vp = v_of(panel);
+            const double* tp = t_of(panel);
             // X = A22 V in k slices: enough waves (16 rows each) for every SIMD of the device
             const int64_t row_waves = (m + 15) / 16;
             const int slices = (int)std::clamp<int64_t>((2048 + row_waves - 1) / row_waves, 1, kSlices);
@@ -874,8 +901,8 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
             bdg::ts_symm<<<dim3((unsigned)((m + 63) / 64), (unsigned)used), 256, 0, st>>>(a, (int)n, (int)r0, (int)m, vp, xpart, k_slice);
             const unsigned parts = (unsigned)((m + 255) / 256);
             bdg::ts_xz<<<parts, 256, 0, st>>>(xpart, used, vp, (int)m, x, zpart);
-            bdg::ts_small<<<1, 256, 0, st>>>(zpart, (int)parts, t, mm);
-            bdg::ts_w<<<(unsigned)((m + 16 + 255) / 256), 256, 0, st>>>(x, vp, t, mm, (int)m, w);
+            bdg::ts_small<<<1, 256, 0, st>>>(zpart, (int)parts, tp, mm);
+            bdg::ts_w<<<(unsigned)((m + 16 + 255) / 256), 256, 0, st>>>(x, vp, tp, mm, (int)m, w);
             const bool more = j0 + B + B + 1 < n;  // another panel follows
             const unsigned tile_rows = (unsigned)((m + 63) / 64);
             bdg::ts_rank2k<<<dim3(1, tile_rows), 256, 0, st>>>(a, (int)n, (int)r0, (int)m, vp, w, 1);
@@ -897,6 +924,7 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemsetAsync(band.ptr, 0, (size_t)(n + 4 * B) * bdg::kTsBandLd * sizeof(double), st));
         bdg::ts_extract_band<<<2048, 256, 0, st>>>(a, (int)n, band.ptr);
+        if (keep) bdg::ts_expand_band<<<2048, 256, 0, st>>>(band.ptr, (int)n, keep->full.ptr);
         if (const char* env = knob::raw("BODGE_AMD_EIGH_STAGE2"); !(env && env[0] == '0')) {
             bdg::TsChaseArgs c{};
             c.ab = band.ptr;
@@ -967,6 +995,8 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
     DeviceBuffer<bdg::TdCluster> clusters_dev;
     DeviceBuffer<double2> emitted;
     DeviceBuffer<bdg::TdScalars<T>> scal;
+    TsKeep keep;
+    bool two_stage = false;
     auto body = [&]() -> int {
         if (int rc = a.reserve((size_t)n * n + 64)) return rc;  // (+64: ts_symm reads up to 15 entries past a row's end)
         constexpr int kVectors = 4 + 2 * bdg::kTdDefer;  // (the last one holds the 2 K dot products handed from step to step)
@@ -997,14 +1027,18 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
         double* d = diag.ptr;
         double* e = diag.ptr + n;
         // eigenvalues only, real matrices: through the band (K10, BLAS-3); BODGE_AMD_EIGH_STAGES=1|2 overrides
-        bool two_stage = false;
         if constexpr (std::is_same_v<T, double>) {
             // (measured, scratch/r4_twostage_check.py: 92 against 92 ms at n = 3600, 0.36 against 1.1 s at 10^4, 7.8 against 50 s at 4e4)
             two_stage = n >= 6000;
             if (const char* env = knob::raw("BODGE_AMD_EIGH_STAGES")) two_stage = atoi(env) == 2 && n > 2 * bdg::kTsBand + 2;
-            two_stage = two_stage && !z_out && !n_vectors;  // (eigenvectors: the one-stage route, whose reflectors the back-transformation knows)
+            // (eigenvectors through the band as well: inverse iteration on the band matrix, then the block reflectors of stage 1;
+            // BODGE_AMD_EIGH_BAND_VECTORS=0 keeps the one-stage route for them)
+            const bool want_vectors = z_out || n_vectors;
+            bool band_vectors = true;
+            if (const char* env = knob::raw("BODGE_AMD_EIGH_BAND_VECTORS")) band_vectors = atoi(env) != 0;
+            two_stage = two_stage && (!want_vectors || band_vectors);
             if (two_stage)
-                if (int rc = tridiagonalise_two_stage(a.ptr, n, d, e, st)) return rc;
+                if (int rc = tridiagonalise_two_stage(a.ptr, n, d, e, st, want_vectors ? &keep : nullptr)) return rc;
         }
         for (int64_t j = 0; j < n && !two_stage; ++j) {
             T* v_unf = v[(j + 1) & 1];  // made at step j-1; its w is finished by this step's vector kernel
@@ -1076,12 +1110,37 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
             if (run == 1) clusters.push_back({(int)(k - first - 1), 2});
             else if (run > 1) ++clusters.back().count;
         }
-        const int n_waves = (int)std::min<int64_t>(n_vec, 7168);
         if (int rc = zt.reserve((size_t)n * n_vec)) return rc;
-        if (int rc = scratch.reserve((size_t)n_waves * 6 * n + (size_t)n_vec)) return rc;
-        double* shift_dev = scratch.ptr + (size_t)n_waves * 6 * n;
-        HIP_TRY(hipMemcpyAsync(shift_dev, shift.data(), sizeof(double) * n_vec, hipMemcpyHostToDevice, st));
-        bdg::td_inverse_iteration<<<n_waves, 64, 0, st>>>(d, e, (int)n, shift_dev, (int)n_vec, span, scratch.ptr, zt.ptr, (int)n_vec);
+        if (two_stage) {
+            if constexpr (std::is_same_v<T, double>) {
+                // eigenvectors of the band matrix: one wave per eigenvalue, as many at once as the scratch space allows
+                a.release();  // (the dense matrix is not needed any more)
+                size_t free_bytes = 0, total_bytes = 0;
+                HIP_TRY(hipMemGetInfo(&free_bytes, &total_bytes));
+                const size_t per_wave = bdg::ts_vector_scratch((int)n) * sizeof(double);
+                const int64_t room = (int64_t)((double)free_bytes * 0.6 / (double)per_wave);
+                const int n_waves = (int)std::clamp<int64_t>(std::min<int64_t>(n_vec, room), 1, 9 * 256);
+                if (int rc = scratch.reserve((size_t)n_waves * bdg::ts_vector_scratch((int)n) + (size_t)n_vec)) return rc;
+                double* shift_dev = scratch.ptr + (size_t)n_waves * bdg::ts_vector_scratch((int)n);
+                HIP_TRY(hipMemcpyAsync(shift_dev, shift.data(), sizeof(double) * n_vec, hipMemcpyHostToDevice, st));
+                bdg::TsVectorArgs va{};
+                va.full = keep.full.ptr;
+                va.n = (int)n;
+                va.shift = shift_dev;
+                va.n_vec = (int)n_vec;
+                va.norm = span;
+                va.scratch = scratch.ptr;
+                va.z = zt.ptr;
+                va.ld = (int)n_vec;
+                bdg::ts_band_vectors<<<n_waves, 64, 0, st>>>(va);
+            }
+        } else {
+            const int n_waves = (int)std::min<int64_t>(n_vec, 7168);
+            if (int rc = scratch.reserve((size_t)n_waves * 6 * n + (size_t)n_vec)) return rc;
+            double* shift_dev = scratch.ptr + (size_t)n_waves * 6 * n;
+            HIP_TRY(hipMemcpyAsync(shift_dev, shift.data(), sizeof(double) * n_vec, hipMemcpyHostToDevice, st));
+            bdg::td_inverse_iteration<<<n_waves, 64, 0, st>>>(d, e, (int)n, shift_dev, (int)n_vec, span, scratch.ptr, zt.ptr, (int)n_vec);
+        }
         if (!clusters.empty()) {
             if (int rc = clusters_dev.reserve(clusters.size())) return rc;
             HIP_TRY(hipMemcpyAsync(clusters_dev.ptr, clusters.data(), sizeof(bdg::TdCluster) * clusters.size(), hipMemcpyHostToDevice, st));
@@ -1119,7 +1178,29 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
             *n_chunks = (int)std::max<int64_t>(1, std::min<int64_t>(chunk_cap, (rows + chunk_rows - 1) / chunk_rows));
             *rows_per_chunk = (int)((rows + *n_chunks - 1) / *n_chunks);
         };
-        if (n >= 2) {
+        if (two_stage) {
+            if constexpr (std::is_same_v<T, double>) {
+                // Y = H_0 H_1 ... H_{P-1} Z with the block reflectors of stage 1, last panel first
+                constexpr int B = bdg::kTsBand;
+                const unsigned col_tiles = (unsigned)((n_vec + 31) / 32);
+                const int padded = (int)col_tiles * 32;
+                DeviceBuffer<double> spart;
+                if (int rc = spart.reserve((size_t)((n + 255) / 256) * B * padded)) return rc;
+                for (int64_t p = (int64_t)keep.rows.size() - 1; p >= 0; --p) {
+                    const int64_t m = keep.rows[(size_t)p], r0 = n - m;
+                    const double* vp = keep.v_all.ptr + keep.v_at[(size_t)p];
+                    const double* tp = keep.t_all.ptr + (size_t)p * B * B;
+                    const unsigned slices = (unsigned)((m + 255) / 256);
+                    bdg::ts_vtz<<<dim3(col_tiles, slices), 64, 0, st>>>(vp, (int)m, y.ptr, (int)ld, (int)r0, (int)n_vec, spart.ptr);
+                    const unsigned row_blocks = (unsigned)std::clamp<int64_t>((m + 63) / 64, 1, 64);
+                    bdg::ts_zupdate<<<dim3(col_tiles, row_blocks), 256, 0, st>>>(vp, tp, (int)m, y.ptr, (int)ld, (int)r0, (int)n_vec,
+                                                                               spart.ptr, (int)slices, padded);
+                }
+                HIP_TRY(hipGetLastError());
+                HIP_TRY(hipStreamSynchronize(st));
+                spart.release();
+            }
+        } else if (n >= 2) {
             int64_t hi = n - 2;
             int count = (int)std::min<int64_t>(kGroup, hi + 1);
             int64_t row0 = hi - count + 2;
@@ -1155,6 +1236,7 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
         return BDG_OK;
     };
     const int rc = body();
+    keep.release();
     a.release();
     vectors.release();
     taus.release();

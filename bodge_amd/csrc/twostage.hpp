@@ -875,4 +875,259 @@ __global__ void ts_band_to_tridiagonal(const double* __restrict__ ab, int n, dou
     }
 }
 
+// ================================================================================================ eigenvectors
+// The eigenvectors of the two-stage route do not go back through the bulge chasing (a million reflectors of 32 rows,
+// each over the whole block of eigenvectors): with the eigenvalues known, the eigenvectors of the BAND matrix come from
+// inverse iteration on the band itself (kept aside before the chase), and only the block reflectors of stage 1 - GEMM
+// shaped - are applied afterwards.
+//
+// ts_expand_band: row storage of the symmetric band, full[i * kTsRowLd + k] = B(i, i - B + k), k = 0 .. 2B.
+constexpr int kTsRowLd = 2 * kTsBand + 2;
+__global__ void ts_expand_band(const double* __restrict__ ab, int n, double* __restrict__ full) {
+    constexpr int B = kTsBand;
+    for (int64_t e = blockIdx.x * (int64_t)blockDim.x + threadIdx.x; e < (int64_t)(n + B + 2) * kTsRowLd; e += (int64_t)gridDim.x * blockDim.x) {
+        const int i = (int)(e / kTsRowLd), k = (int)(e % kTsRowLd);
+        const int c = i - B + k;
+        double v = 0.0;
+        if (i < n && k <= 2 * B && c >= 0 && c < n) v = c <= i ? ab[(size_t)c * kTsBandLd + (i - c)] : ab[(size_t)i * kTsBandLd + (c - i)];
+        full[e] = v;
+    }
+}
+
+// ts_band_vectors: one wave per eigenvalue (scratch/r4_band_invit_proto.py is the numpy model).
+//   LU of B - lambda with partial pivoting: at step j the candidates for the pivot are the B + 1 rows not yet used among
+//   rows 0 .. j + B; all their entries lie in columns j .. j + 2B.  They sit in LDS, one SLOT per row (a row keeps its slot
+//   until it is the pivot; the next row of the band then moves in), columns in a circular frame of 2B + 1 positions: lane
+//   l works on column j + 1 + l.  Per step: pivot by a wave reduction, 33 multipliers, one rank-1 update of 33 x 64.
+//   U's rows (65 entries) and the multipliers per slot go to global scratch.
+//   Forward solve: the right-hand side of the row in slot s travels in lane s.  Backward: lane l holds x[j + 1 + l].
+//   Three solves from a pseudo-random start, normalised; tiny pivots perturbed (dlagts).
+struct TsVectorArgs {
+    const double* full;    // ts_expand_band
+    int n;
+    const double* shift;   // [n_vec]
+    int n_vec;
+    double norm;           // of the band matrix (for the pivot floor)
+    double* scratch;       // per workgroup: U [n][kTsRowLd], multipliers [n][kTsLmLd], y [n], x [n]
+    double* z;             // [n][ld]: column k = eigenvector of shift[k]
+    int ld;
+};
+constexpr int kTsLmLd = kTsBand + 3;  // 33 multipliers + the pivot's slot
+__host__ __device__ inline size_t ts_vector_scratch(int n) { return (size_t)n * (kTsRowLd + kTsLmLd + 2) + 64; }
+
+__global__ __launch_bounds__(64) void ts_band_vectors(TsVectorArgs q) {
+    constexpr int B = kTsBand, CW = 2 * B + 1, SLOTS = B + 1;
+    __shared__ double w[SLOTS * CW];
+    __shared__ double lmul[SLOTS];
+    const int lane = threadIdx.x, n = q.n;
+    double* u_rows = q.scratch + (size_t)blockIdx.x * ts_vector_scratch(n);
+    double* lm_rows = u_rows + (size_t)n * kTsRowLd;
+    double* y = lm_rows + (size_t)n * kTsLmLd;
+    double* x = y + n;
+    const double tiny = 2.220446049250313e-16 * q.norm;
+    auto wave_sync = [] {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+    };
+    auto wave_sum = [](double v) {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+        return v;
+    };
+    for (int k_eig = blockIdx.x; k_eig < q.n_vec; k_eig += gridDim.x) {
+        const double lambda = q.shift[k_eig];
+        // ---- the first B + 1 rows into their slots: frame = columns 0 .. 2B at positions 0 .. 2B
+        for (int e = lane; e < SLOTS * CW; e += 64) {
+            const int sl = e / CW, col = e % CW;
+            const int kk = col - sl + B;  // index into the row's band
+            double v = 0.0;
+            if (sl < n && kk >= 0 && kk <= 2 * B) v = q.full[(size_t)sl * kTsRowLd + kk] - (col == sl ? lambda : 0.0);
+            w[e] = v;
+        }
+        int row_in_slot = lane;   // lanes 0 .. B: the row their slot holds
+        int pos = (lane + 1) % CW;  // this lane's column j + 1 + lane, as a position of the frame
+        int pos_j = 0;              // ... and column j's
+        wave_sync();
+        for (int j = 0; j < n; ++j) {
+            const int i_new = j + B + 1;
+            double incoming = 0.0, incoming_last = 0.0;  // row i_new: columns j + 1 + lane, and j + 2B + 1
+            if (i_new < n) {
+                incoming = q.full[(size_t)i_new * kTsRowLd + lane] - (lane == B ? lambda : 0.0);
+                if (lane == 0) incoming_last = q.full[(size_t)i_new * kTsRowLd + 2 * B];
+            }
+            // ---- pivot: the largest entry of column j among the slots
+            const bool candidate = lane < SLOTS && row_in_slot < n;
+            const double v = candidate ? w[lane * CW + pos_j] : 0.0;
+            double best = candidate ? fabs(v) : -1.0;
+            int best_at = lane;
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) {
+                const double other = __shfl_xor(best, off);
+                const int other_at = __shfl_xor(best_at, off);
+                if (other > best || (other == best && other_at < best_at)) {
+                    best = other;
+                    best_at = other_at;
+                }
+            }
+            const int p = best_at;  // (the same in every lane)
+            double pv = __shfl(v, p);
+            if (fabs(pv) < tiny) pv = pv < 0.0 ? -tiny : tiny;
+            const double lm = (candidate && lane != p) ? v / pv : 0.0;
+            if (lane < SLOTS) {
+                lmul[lane] = lm;
+                lm_rows[(size_t)j * kTsLmLd + lane] = lm;
+            } else if (lane == SLOTS) {
+                lm_rows[(size_t)j * kTsLmLd + SLOTS] = (double)p;
+            }
+            wave_sync();
+            // ---- row j of U, and the update of the other rows
+            const double u = w[p * CW + pos];
+            u_rows[(size_t)j * kTsRowLd + 1 + lane] = u;
+            if (lane == 0) u_rows[(size_t)j * kTsRowLd] = pv;
+#pragma unroll 4
+            for (int sl = 0; sl < SLOTS; ++sl)
+                if (sl != p) w[sl * CW + pos] -= lmul[sl] * u;
+            if (lane < SLOTS && lane != p) w[lane * CW + pos_j] = 0.0;  // (column j's position is column j + 2B + 1's next)
+            // ---- the pivot's slot takes row j + B + 1
+            w[p * CW + pos] = incoming;
+            if (lane == 0) w[p * CW + pos_j] = incoming_last;
+            if (lane == p) row_in_slot = i_new;
+            pos = pos + 1 == CW ? 0 : pos + 1;
+            pos_j = pos_j + 1 == CW ? 0 : pos_j + 1;
+            wave_sync();
+        }
+        // ---- inverse iteration
+        for (int i = lane; i < n; i += 64) {
+            const uint64_t hsh = splitmix64(((uint64_t)(k_eig + 1) << 32) ^ (uint64_t)i);
+            x[i] = (double)(hsh >> 11) * (2.0 / 9007199254740992.0) - 1.0;
+        }
+        wave_sync();
+        for (int iteration = 0; iteration < 3; ++iteration) {
+            double norm2 = 0.0;
+            for (int i = lane; i < n; i += 64) norm2 += x[i] * x[i];
+            norm2 = wave_sum(norm2);
+            const double scale = norm2 > 0.0 ? 1.0 / sqrt(norm2) : 1.0;
+            // forward: lane s carries the right-hand side of the row in slot s
+            double xs = (lane < SLOTS && lane < n) ? x[lane] * scale : 0.0;
+            double lm_next = lane <= SLOTS ? lm_rows[lane] : 0.0;
+            for (int j = 0; j < n; ++j) {
+                const double lm = lm_next;
+                if (j + 1 < n && lane <= SLOTS) lm_next = lm_rows[(size_t)(j + 1) * kTsLmLd + lane];
+                const double rhs_new = (j + B + 1 < n) ? x[j + B + 1] * scale : 0.0;
+                const int p = (int)__shfl(lm, SLOTS);
+                const double yj = __shfl(xs, p);
+                xs -= lm * yj;  // (zero for the pivot's slot and for lanes that hold no slot)
+                if (lane == p) xs = rhs_new;
+                if (lane == 0) y[j] = yj;
+            }
+            wave_sync();
+            // backward: U x = y, lane l holds x[j + 1 + l]
+            double win = 0.0;
+            double u_next = u_rows[(size_t)(n - 1) * kTsRowLd + 1 + lane], piv_next = u_rows[(size_t)(n - 1) * kTsRowLd];
+            for (int j = n - 1; j >= 0; --j) {
+                const double u = u_next, piv = piv_next;
+                if (j > 0) {
+                    u_next = u_rows[(size_t)(j - 1) * kTsRowLd + 1 + lane];
+                    piv_next = u_rows[(size_t)(j - 1) * kTsRowLd];
+                }
+                const double dot = wave_sum(u * win);
+                const double xj = (y[j] - dot) / piv;
+                win = __shfl_up(win, 1);
+                if (lane == 0) {
+                    win = xj;
+                    x[j] = xj;
+                }
+            }
+            wave_sync();
+        }
+        double norm2 = 0.0;
+        for (int i = lane; i < n; i += 64) norm2 += x[i] * x[i];
+        norm2 = wave_sum(norm2);
+        const double scale = norm2 > 0.0 ? 1.0 / sqrt(norm2) : 1.0;
+        for (int i = lane; i < n; i += 64) q.z[(size_t)i * q.ld + k_eig] = x[i] * scale;
+        wave_sync();
+    }
+}
+
+// ---- Z <- (I - V T V^T) Z on the rows r0 .. of Z (n x ld, eigenvectors as columns), one panel of stage 1 at a time, last
+// panel first.  ts_vtz: partial S = V^T Z per slice of 256 rows and tile of 32 columns; ts_zupdate: S = sum of the
+// slices, S' = T S, Z -= V S' - both fp64 MFMA, operands straight from memory (k orders as in ts_symm).
+__global__ __launch_bounds__(64) void ts_vtz(const double* __restrict__ v, int m, const double* __restrict__ z, int ld, int r0,
+                                             int n_cols, double* __restrict__ spart) {
+    constexpr int B = kTsBand;
+    const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
+    const int col0 = blockIdx.x * 32;
+    const int g0 = blockIdx.y * 256, g1 = min(m, g0 + 256);
+    v4f64 acc[2][2];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) acc[p >> 1][p & 1] = v4f64{0.0, 0.0, 0.0, 0.0};
+    const bool c0 = col0 + i < n_cols, c1 = col0 + 16 + i < n_cols;
+#pragma unroll 4
+    for (int k = g0; k < g1; k += 4) {
+        const int row = k + kk;
+        double v0 = 0.0, v1 = 0.0, z0 = 0.0, z1 = 0.0;
+        if (row < g1) {
+            v0 = v[(size_t)row * B + i];
+            v1 = v[(size_t)row * B + i + 16];
+            const double* zr = z + (size_t)(r0 + row) * ld + col0;
+            if (c0) z0 = zr[i];
+            if (c1) z1 = zr[i + 16];
+        }
+        acc[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, z0, acc[0][0], 0, 0, 0);
+        acc[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, z1, acc[0][1], 0, 0, 0);
+        acc[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, z0, acc[1][0], 0, 0, 0);
+        acc[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, z1, acc[1][1], 0, 0, 0);
+    }
+    // spart[slice][32 rows of S][n_cols padded to tiles]
+    double* out = spart + ((size_t)blockIdx.y * B) * (gridDim.x * 32) + col0;
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) out[(size_t)((p >> 1) * 16 + kk + 4 * r) * (gridDim.x * 32) + (p & 1) * 16 + i] = acc[p >> 1][p & 1][r];
+}
+
+__global__ __launch_bounds__(256) void ts_zupdate(const double* __restrict__ v, const double* __restrict__ t, int m, double* __restrict__ z,
+                                                  int ld, int r0, int n_cols, const double* __restrict__ spart, int slices, int padded) {
+    constexpr int B = kTsBand;
+    __shared__ double sm[B][33], sp[B][33];
+    const int col0 = blockIdx.x * 32;
+    // S of this column tile (sum of the slices), then S' = T S
+    for (int e = threadIdx.x; e < B * 32; e += 256) {
+        const int r = e / 32, c = e % 32;
+        double sum = 0.0;
+        for (int sl = 0; sl < slices; ++sl) sum += spart[((size_t)sl * B + r) * padded + col0 + c];
+        sm[r][c] = sum;
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < B * 32; e += 256) {
+        const int r = e / 32, c = e % 32;
+        double sum = 0.0;
+        for (int k = r; k < B; ++k) sum += t[r * B + k] * sm[k][c];  // (T upper triangular)
+        sp[r][c] = sum;
+    }
+    __syncthreads();
+    // Z[rows of this wave][col tile] -= V[rows][0..31] S'
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kk = lane >> 4;
+    for (int row0 = (blockIdx.y * 4 + wave) * 16; row0 < m; row0 += gridDim.y * 64) {
+        v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
+        const double* vr = v + (size_t)min(row0 + i, m - 1) * B;
+#pragma unroll
+        for (int k = 0; k < B; k += 4) {
+            const double av = vr[k + kk];
+            acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, sp[k + kk][i], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(av, sp[k + kk][i + 16], acc1, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            const int gr = row0 + kk + 4 * r;
+            if (gr < m) {
+                double* zr = z + (size_t)(r0 + gr) * ld + col0;
+                if (col0 + i < n_cols) zr[i] -= acc0[r];
+                if (col0 + i + 16 < n_cols) zr[i + 16] -= acc1[r];
+            }
+        }
+    }
+}
+
 }  // namespace bdg
