@@ -879,7 +879,7 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
             return BDG_OK;
         };
         // (pays while the bulk of an update outlasts the chain: two events per panel cost more than they hide on small blocks)
-        bool lookahead = n >= 6000;
+        bool lookahead = n >= 5000;
         if (const char* env = knob::raw("BODGE_AMD_EIGH_LOOKAHEAD")) lookahead = atoi(env) != 0;
         if (lookahead && !side) {
             HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
@@ -1029,7 +1029,8 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
         // eigenvalues only, real matrices: through the band (K10, BLAS-3); BODGE_AMD_EIGH_STAGES=1|2 overrides
         if constexpr (std::is_same_v<T, double>) {
             // (measured, scratch/r4_twostage_check.py: 92 against 92 ms at n = 3600, 0.36 against 1.1 s at 10^4, 7.8 against 50 s at 4e4)
-            two_stage = n >= 6000;
+            // eigenpairs: 147 against 187 ms at n = 3600, 0.72 against 1.68 s at 10^4 (scratch/r4_twostage_vectors.py)
+            two_stage = (z_out || n_vectors) ? n >= 3000 : n >= 5000;
             if (const char* env = knob::raw("BODGE_AMD_EIGH_STAGES")) two_stage = atoi(env) == 2 && n > 2 * bdg::kTsBand + 2;
             // (eigenvectors through the band as well: inverse iteration on the band matrix, then the block reflectors of stage 1;
             // BODGE_AMD_EIGH_BAND_VECTORS=0 keeps the one-stage route for them)
@@ -1132,6 +1133,8 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
                 va.scratch = scratch.ptr;
                 va.z = zt.ptr;
                 va.ld = (int)n_vec;
+                va.iterations = 3;
+                if (const char* env = knob::raw("BODGE_AMD_EIGH_BAND_ITERATIONS")) va.iterations = std::clamp(atoi(env), 1, 8);
                 bdg::ts_band_vectors<<<n_waves, 64, 0, st>>>(va);
             }
         } else {
@@ -1185,16 +1188,17 @@ int eig_tridiagonal_typed(bdg_system* sys, double* w_out, double lower_bound, in
                 const unsigned col_tiles = (unsigned)((n_vec + 31) / 32);
                 const int padded = (int)col_tiles * 32;
                 DeviceBuffer<double> spart;
-                if (int rc = spart.reserve((size_t)((n + 255) / 256) * B * padded)) return rc;
+                if (int rc = spart.reserve((size_t)((n + 255) / 256 + 1) * B * padded)) return rc;
+                double* sprime = spart.ptr + (size_t)((n + 255) / 256) * B * padded;
                 for (int64_t p = (int64_t)keep.rows.size() - 1; p >= 0; --p) {
                     const int64_t m = keep.rows[(size_t)p], r0 = n - m;
                     const double* vp = keep.v_all.ptr + keep.v_at[(size_t)p];
                     const double* tp = keep.t_all.ptr + (size_t)p * B * B;
                     const unsigned slices = (unsigned)((m + 255) / 256);
                     bdg::ts_vtz<<<dim3(col_tiles, slices), 64, 0, st>>>(vp, (int)m, y.ptr, (int)ld, (int)r0, (int)n_vec, spart.ptr);
-                    const unsigned row_blocks = (unsigned)std::clamp<int64_t>((m + 63) / 64, 1, 64);
-                    bdg::ts_zupdate<<<dim3(col_tiles, row_blocks), 256, 0, st>>>(vp, tp, (int)m, y.ptr, (int)ld, (int)r0, (int)n_vec,
-                                                                               spart.ptr, (int)slices, padded);
+                    bdg::ts_sprime<<<col_tiles, 256, 0, st>>>(tp, spart.ptr, (int)slices, padded, sprime);
+                    const unsigned row_blocks = (unsigned)std::clamp<int64_t>((m + 63) / 64, 1, 32);
+                    bdg::ts_zupdate<<<dim3(col_tiles, row_blocks), 256, 0, st>>>(vp, (int)m, y.ptr, (int)ld, (int)r0, (int)n_vec, sprime, padded);
                 }
                 HIP_TRY(hipGetLastError());
                 HIP_TRY(hipStreamSynchronize(st));

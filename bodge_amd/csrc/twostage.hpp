@@ -911,14 +911,47 @@ struct TsVectorArgs {
     double* scratch;       // per workgroup: U [n][kTsRowLd], multipliers [n][kTsLmLd], y [n], x [n]
     double* z;             // [n][ld]: column k = eigenvector of shift[k]
     int ld;
+    int iterations;        // solves from the pseudo-random start (3; dstein goes on until the vector has grown enough)
 };
 constexpr int kTsLmLd = kTsBand + 3;  // 33 multipliers + the pivot's slot
 __host__ __device__ inline size_t ts_vector_scratch(int n) { return (size_t)n * (kTsRowLd + kTsLmLd + 2) + 64; }
 
+// Sum / maximum over the 64 lanes without the LDS crossbar: quad permutes and row mirrors leave every lane of a row of 16
+// with its row's result, row_bcast15 / row_bcast31 carry it on; the total is read from lane 63.  (A butterfly of
+// ds_bpermute costs ~100 cycles a round in a dependent chain - the backward solve makes one reduction per row.)
+template <int CTRL, int ROW_MASK>
+__device__ inline double ts_dpp(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xF, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ inline double ts_wave_total(double v) {
+    v += ts_dpp<0xB1, 0xF>(v);   // quad_perm [1,0,3,2]
+    v += ts_dpp<0x4E, 0xF>(v);   // quad_perm [2,3,0,1]
+    v += ts_dpp<0x141, 0xF>(v);  // row_half_mirror
+    v += ts_dpp<0x140, 0xF>(v);  // row_mirror
+    v += ts_dpp<0x142, 0xA>(v);  // row_bcast15 into rows 1 and 3
+    v += ts_dpp<0x143, 0xC>(v);  // row_bcast31 into rows 2 and 3
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+__device__ inline double ts_wave_max_nonnegative(double v) {  // (v >= 0 or -1 for lanes that do not take part: 0 bits never win)
+    v = fmax(v, ts_dpp<0xB1, 0xF>(v));
+    v = fmax(v, ts_dpp<0x4E, 0xF>(v));
+    v = fmax(v, ts_dpp<0x141, 0xF>(v));
+    v = fmax(v, ts_dpp<0x140, 0xF>(v));
+    const double r1 = ts_dpp<0x142, 0xA>(v);
+    v = fmax(v, r1);
+    const double r2 = ts_dpp<0x143, 0xC>(v);
+    v = fmax(v, r2);
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), 63), __builtin_amdgcn_readlane(__double2loint(v), 63));
+}
+
+__device__ inline double ts_readlane(double v, int from) {  // (`from` uniform)
+    return __hiloint2double(__builtin_amdgcn_readlane(__double2hiint(v), from), __builtin_amdgcn_readlane(__double2loint(v), from));
+}
+
 __global__ __launch_bounds__(64) void ts_band_vectors(TsVectorArgs q) {
-    constexpr int B = kTsBand, CW = 2 * B + 1, SLOTS = B + 1;
-    __shared__ double w[SLOTS * CW];
-    __shared__ double lmul[SLOTS];
+    constexpr int B = kTsBand, SLOTS = B + 1;
     const int lane = threadIdx.x, n = q.n;
     double* u_rows = q.scratch + (size_t)blockIdx.x * ts_vector_scratch(n);
     double* lm_rows = u_rows + (size_t)n * kTsRowLd;
@@ -937,65 +970,66 @@ __global__ __launch_bounds__(64) void ts_band_vectors(TsVectorArgs q) {
     };
     for (int k_eig = blockIdx.x; k_eig < q.n_vec; k_eig += gridDim.x) {
         const double lambda = q.shift[k_eig];
-        // ---- the first B + 1 rows into their slots: frame = columns 0 .. 2B at positions 0 .. 2B
-        for (int e = lane; e < SLOTS * CW; e += 64) {
-            const int sl = e / CW, col = e % CW;
-            const int kk = col - sl + B;  // index into the row's band
-            double v = 0.0;
-            if (sl < n && kk >= 0 && kk <= 2 * B) v = q.full[(size_t)sl * kTsRowLd + kk] - (col == sl ? lambda : 0.0);
-            w[e] = v;
+        // The window in registers: wr[s] = the entry of the row in slot s at this lane's column.  The frame of step j
+        // is columns j .. j + 2B = 65 columns for 64 lanes: lane L holds the column congruent to L (mod 64) among
+        // j + 1 .. j + 64; column j (congruent to column j + 64) is read off first, and the one entry a row can have in
+        // column j + 64 before the update - that of the row that moved in last - waits in `pending` until then.
+        double wr[SLOTS];
+#pragma unroll
+        for (int sl = 0; sl < SLOTS; ++sl) {
+            const int kk = lane - sl + B;  // column `lane` of row sl, as an index into the row's band
+            wr[sl] = (sl < n && kk >= 0 && kk <= 2 * B) ? q.full[(size_t)sl * kTsRowLd + kk] - (lane == sl ? lambda : 0.0) : 0.0;
         }
-        int row_in_slot = lane;   // lanes 0 .. B: the row their slot holds
-        int pos = (lane + 1) % CW;  // this lane's column j + 1 + lane, as a position of the frame
-        int pos_j = 0;              // ... and column j's
-        wave_sync();
+        int newest = B;                                                           // slot of the row that moved in last
+        double pending = B < n ? q.full[(size_t)B * kTsRowLd + 2 * B] : 0.0;       // its entry in column (its row) + B
+        int row_in_slot = lane;  // lanes 0 .. B: the row their slot holds
         for (int j = 0; j < n; ++j) {
-            const int i_new = j + B + 1;
-            double incoming = 0.0, incoming_last = 0.0;  // row i_new: columns j + 1 + lane, and j + 2B + 1
+            const int pj = j & 63, i_new = j + B + 1;
+            const int rel = (lane - (j + 1)) & 63;  // this lane's column is j + 1 + rel
+            double incoming = 0.0, next_pending = 0.0;
             if (i_new < n) {
-                incoming = q.full[(size_t)i_new * kTsRowLd + lane] - (lane == B ? lambda : 0.0);
-                if (lane == 0) incoming_last = q.full[(size_t)i_new * kTsRowLd + 2 * B];
+                incoming = q.full[(size_t)i_new * kTsRowLd + rel] - (rel == B ? lambda : 0.0);
+                next_pending = q.full[(size_t)i_new * kTsRowLd + 2 * B];
+            }
+            // ---- column j: from lane pj's registers to lane s for slot s
+            double v = 0.0;
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const double entry = ts_readlane(wr[sl], pj);
+                if (lane == sl) v = entry;
+                if (lane == pj) wr[sl] = 0.0;  // (the lane's column is j + 64 from now on)
+            }
+            if (lane == pj) {
+#pragma unroll
+                for (int sl = 0; sl < SLOTS; ++sl)
+                    if (sl == newest) wr[sl] = pending;
             }
             // ---- pivot: the largest entry of column j among the slots
             const bool candidate = lane < SLOTS && row_in_slot < n;
-            const double v = candidate ? w[lane * CW + pos_j] : 0.0;
-            double best = candidate ? fabs(v) : -1.0;
-            int best_at = lane;
-#pragma unroll
-            for (int off = 32; off >= 1; off >>= 1) {
-                const double other = __shfl_xor(best, off);
-                const int other_at = __shfl_xor(best_at, off);
-                if (other > best || (other == best && other_at < best_at)) {
-                    best = other;
-                    best_at = other_at;
-                }
-            }
-            const int p = best_at;  // (the same in every lane)
-            double pv = __shfl(v, p);
+            const double mine = candidate ? fabs(v) : -1.0;
+            const double best = ts_wave_max_nonnegative(mine);
+            const unsigned long long at = __ballot(candidate && mine == best);
+            const int p = at ? __builtin_ctzll(at) : 0;  // (the first slot with the largest entry; uniform)
+            double pv = ts_readlane(v, p);
             if (fabs(pv) < tiny) pv = pv < 0.0 ? -tiny : tiny;
             const double lm = (candidate && lane != p) ? v / pv : 0.0;
-            if (lane < SLOTS) {
-                lmul[lane] = lm;
-                lm_rows[(size_t)j * kTsLmLd + lane] = lm;
-            } else if (lane == SLOTS) {
-                lm_rows[(size_t)j * kTsLmLd + SLOTS] = (double)p;
-            }
-            wave_sync();
-            // ---- row j of U, and the update of the other rows
-            const double u = w[p * CW + pos];
-            u_rows[(size_t)j * kTsRowLd + 1 + lane] = u;
-            if (lane == 0) u_rows[(size_t)j * kTsRowLd] = pv;
-#pragma unroll 4
+            if (lane < SLOTS) lm_rows[(size_t)j * kTsLmLd + lane] = lm;
+            else if (lane == SLOTS) lm_rows[(size_t)j * kTsLmLd + SLOTS] = (double)p;
+            // ---- row j of U, the update of the other rows, and row j + B + 1 into the pivot's slot
+            double u = 0.0;
+#pragma unroll
             for (int sl = 0; sl < SLOTS; ++sl)
-                if (sl != p) w[sl * CW + pos] -= lmul[sl] * u;
-            if (lane < SLOTS && lane != p) w[lane * CW + pos_j] = 0.0;  // (column j's position is column j + 2B + 1's next)
-            // ---- the pivot's slot takes row j + B + 1
-            w[p * CW + pos] = incoming;
-            if (lane == 0) w[p * CW + pos_j] = incoming_last;
+                if (sl == p) u = wr[sl];
+            u_rows[(size_t)j * kTsRowLd + 1 + rel] = u;
+            if (lane == 0) u_rows[(size_t)j * kTsRowLd] = pv;
+#pragma unroll
+            for (int sl = 0; sl < SLOTS; ++sl) {
+                const double lms = ts_readlane(lm, sl);
+                wr[sl] = sl == p ? incoming : wr[sl] - lms * u;
+            }
             if (lane == p) row_in_slot = i_new;
-            pos = pos + 1 == CW ? 0 : pos + 1;
-            pos_j = pos_j + 1 == CW ? 0 : pos_j + 1;
-            wave_sync();
+            newest = p;
+            pending = next_pending;
         }
         // ---- inverse iteration
         for (int i = lane; i < n; i += 64) {
@@ -1003,27 +1037,39 @@ __global__ __launch_bounds__(64) void ts_band_vectors(TsVectorArgs q) {
             x[i] = (double)(hsh >> 11) * (2.0 / 9007199254740992.0) - 1.0;
         }
         wave_sync();
-        for (int iteration = 0; iteration < 3; ++iteration) {
+        for (int iteration = 0; iteration < q.iterations; ++iteration) {
             double norm2 = 0.0;
             for (int i = lane; i < n; i += 64) norm2 += x[i] * x[i];
             norm2 = wave_sum(norm2);
             const double scale = norm2 > 0.0 ? 1.0 / sqrt(norm2) : 1.0;
-            // forward: lane s carries the right-hand side of the row in slot s
+            // forward: lane s carries the right-hand side of the row in slot s.  x and y move in chunks of 64 (lane i of a
+            // chunk <-> entry t + i): one load / store per 64 steps, the step's value by readlane.
             double xs = (lane < SLOTS && lane < n) ? x[lane] * scale : 0.0;
             double lm_next = lane <= SLOTS ? lm_rows[lane] : 0.0;
+            double x_chunk = 0.0, y_chunk = 0.0;
+            int x_base = -1000;
             for (int j = 0; j < n; ++j) {
                 const double lm = lm_next;
                 if (j + 1 < n && lane <= SLOTS) lm_next = lm_rows[(size_t)(j + 1) * kTsLmLd + lane];
-                const double rhs_new = (j + B + 1 < n) ? x[j + B + 1] * scale : 0.0;
-                const int p = (int)__shfl(lm, SLOTS);
-                const double yj = __shfl(xs, p);
+                const int want = j + B + 1;
+                if (want - x_base >= 64 || want < x_base) {
+                    x_base = want;
+                    x_chunk = x_base + lane < n ? x[x_base + lane] * scale : 0.0;
+                }
+                const double rhs_new = ts_readlane(x_chunk, want - x_base);
+                const int p = (int)ts_readlane(lm, SLOTS);
+                const double yj = ts_readlane(xs, p);
                 xs -= lm * yj;  // (zero for the pivot's slot and for lanes that hold no slot)
                 if (lane == p) xs = rhs_new;
-                if (lane == 0) y[j] = yj;
+                if (lane == (j & 63)) y_chunk = yj;
+                if ((j & 63) == 63 || j == n - 1) {
+                    const int at = (j & ~63) + lane;
+                    if (at <= j) y[at] = y_chunk;
+                }
             }
             wave_sync();
             // backward: U x = y, lane l holds x[j + 1 + l]
-            double win = 0.0;
+            double win = 0.0, out_chunk = 0.0;
             double u_next = u_rows[(size_t)(n - 1) * kTsRowLd + 1 + lane], piv_next = u_rows[(size_t)(n - 1) * kTsRowLd];
             for (int j = n - 1; j >= 0; --j) {
                 const double u = u_next, piv = piv_next;
@@ -1031,12 +1077,15 @@ __global__ __launch_bounds__(64) void ts_band_vectors(TsVectorArgs q) {
                     u_next = u_rows[(size_t)(j - 1) * kTsRowLd + 1 + lane];
                     piv_next = u_rows[(size_t)(j - 1) * kTsRowLd];
                 }
-                const double dot = wave_sum(u * win);
-                const double xj = (y[j] - dot) / piv;
-                win = __shfl_up(win, 1);
-                if (lane == 0) {
-                    win = xj;
-                    x[j] = xj;
+                if ((j & 63) == 63 || j == n - 1) y_chunk = (j & ~63) + lane < n ? y[(j & ~63) + lane] : 0.0;
+                const double dot = ts_wave_total(u * win);
+                const double xj = (ts_readlane(y_chunk, j & 63) - dot) / piv;
+                win = ts_dpp<0x138, 0xF>(win);  // wave_shr:1 - every lane takes its lower neighbour's entry
+                if (lane == 0) win = xj;
+                if (lane == (j & 63)) out_chunk = xj;
+                if ((j & 63) == 0) {
+                    const int at = j + lane;
+                    if (at < n) x[at] = out_chunk;
                 }
             }
             wave_sync();
@@ -1087,15 +1136,16 @@ __global__ __launch_bounds__(64) void ts_vtz(const double* __restrict__ v, int m
         for (int r = 0; r < 4; ++r) out[(size_t)((p >> 1) * 16 + kk + 4 * r) * (gridDim.x * 32) + (p & 1) * 16 + i] = acc[p >> 1][p & 1][r];
 }
 
-__global__ __launch_bounds__(256) void ts_zupdate(const double* __restrict__ v, const double* __restrict__ t, int m, double* __restrict__ z,
-                                                  int ld, int r0, int n_cols, const double* __restrict__ spart, int slices, int padded) {
+// S' = T (sum of the slices of S), one workgroup per tile of 32 columns
+__global__ __launch_bounds__(256) void ts_sprime(const double* __restrict__ t, const double* __restrict__ spart, int slices, int padded,
+                                                 double* __restrict__ sprime) {
     constexpr int B = kTsBand;
-    __shared__ double sm[B][33], sp[B][33];
+    __shared__ double sm[B][33];
     const int col0 = blockIdx.x * 32;
-    // S of this column tile (sum of the slices), then S' = T S
     for (int e = threadIdx.x; e < B * 32; e += 256) {
         const int r = e / 32, c = e % 32;
         double sum = 0.0;
+#pragma unroll 8
         for (int sl = 0; sl < slices; ++sl) sum += spart[((size_t)sl * B + r) * padded + col0 + c];
         sm[r][c] = sum;
     }
@@ -1104,10 +1154,18 @@ __global__ __launch_bounds__(256) void ts_zupdate(const double* __restrict__ v, 
         const int r = e / 32, c = e % 32;
         double sum = 0.0;
         for (int k = r; k < B; ++k) sum += t[r * B + k] * sm[k][c];  // (T upper triangular)
-        sp[r][c] = sum;
+        sprime[(size_t)r * padded + col0 + c] = sum;
     }
+}
+
+// Z[rows][tile of 32 columns] -= V[rows][0 .. 31] S', a wave per 16 rows
+__global__ __launch_bounds__(256) void ts_zupdate(const double* __restrict__ v, int m, double* __restrict__ z, int ld, int r0, int n_cols,
+                                                  const double* __restrict__ sprime, int padded) {
+    constexpr int B = kTsBand;
+    __shared__ double sp[B][33];
+    const int col0 = blockIdx.x * 32;
+    for (int e = threadIdx.x; e < B * 32; e += 256) sp[e / 32][e % 32] = sprime[(size_t)(e / 32) * padded + col0 + e % 32];
     __syncthreads();
-    // Z[rows of this wave][col tile] -= V[rows][0..31] S'
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kk = lane >> 4;
     for (int row0 = (blockIdx.y * 4 + wave) * 16; row0 < m; row0 += gridDim.y * 64) {
         v4f64 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = {0.0, 0.0, 0.0, 0.0};
