@@ -789,7 +789,7 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
     const int64_t max_parts = (n + 255) / 256;       // parts of Z = V^T X
     // work: V, X, W (n x B each), T, M (B x B), Z parts, QR partials [2][256][2B], row broadcast [2][B], the k slices of X
     const size_t work_count = (size_t)3 * n * B + 2 * B * B + (size_t)max_parts * B * B + (size_t)2 * 256 * 2 * B + 2 * B +
-                              (size_t)kSlices * n * B + (size_t)((n + 127) / 128 + 1) * B * B + 2 * B + B * B + (size_t)n * B;
+                              (size_t)kSlices * n * B + (size_t)((n + 127) / 128 + 1) * 2 * B * B + 2 * B + B * B + (size_t)2 * n * B + B * B + B;
     auto body = [&]() -> int {
         if (int rc = work.reserve(work_count)) return rc;
         if (int rc = band.reserve((size_t)(n + 4 * B) * bdg::kTsBandLd)) return rc;
@@ -807,12 +807,19 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
         double* rowi = partial + (size_t)2 * 256 * 2 * B;
         double* xpart = rowi + 2 * B;
         double* gpart = xpart + (size_t)kSlices * n * B;
-        double* qr_scale = gpart + (size_t)((n + 127) / 128 + 1) * B * B;
+        double* qr_scale = gpart + (size_t)((n + 127) / 128 + 1) * 2 * B * B;
         double* qr_beta = qr_scale + B;
         double* qr_w = qr_beta + B;
         double* v2 = qr_w + B * B;  // V of every other panel
+        double* panel_copy = v2 + (size_t)n * B;  // the panel as it was (n x B), for the verification and a second factorisation
+        double* qr_m = panel_copy + (size_t)n * B;
+        double* qr_norms = qr_m + B * B;
+        double verify_tolerance = 2e-13;  // (a sound panel: a few 1e-15; the failures seen: 1e-11 and more)
+        if (const char* env = knob::raw("BODGE_AMD_EIGH_VERIFY")) verify_tolerance = atof(env);
         bool gram_qr = true;
         if (const char* env = knob::raw("BODGE_AMD_EIGH_GRAM_QR")) gram_qr = atoi(env) != 0;
+        double gram_floor = bdg::kTsGramFloor;
+        if (const char* env = knob::raw("BODGE_AMD_EIGH_GRAM_FLOOR")) gram_floor = atof(env);
         unsigned* panel_counter = sync.ptr;                 // one barrier counter per panel
         unsigned* unsafe = sync.ptr + n_panels + n + 8;     // [n_panels]: panels the Gram route gave up
         unsigned* progress = sync.ptr + n_panels;           // [n]
@@ -854,8 +861,8 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
             if (gram_qr) {
                 // reflectors from the Gram matrix of the panel (no grid barrier); panels that lose too much of a column
                 // to cancellation are factorised by ts_panel_qr instead (`unsafe` decides on the device)
-                const unsigned gparts = (unsigned)std::max<int64_t>(1, (m - B + 127) / 128);
-                bdg::ts_gram<<<gparts, 64, 0, on>>>(a, (int)n, (int)j0, (int)r0, (int)m, gpart);
+                const unsigned gparts = (unsigned)std::max<int64_t>(1, (m - B + bdg::kTsGramRows - 1) / bdg::kTsGramRows);
+                bdg::ts_gram<<<gparts, 256, 0, on>>>(a, (int)n, (int)j0, (int)r0, (int)m, gpart, B);
                 bdg::TsRecurArgs rc{};
                 rc.a = a;
                 rc.n = (int)n;
@@ -868,12 +875,20 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
                 rc.scale = qr_scale;
                 rc.beta = qr_beta;
                 rc.wrows = qr_w;
-                rc.t = t_of(panel);
                 rc.unsafe = unsafe + panel;
+                rc.floor = gram_floor;
+                rc.colnorm2 = qr_norms;
                 bdg::ts_qr_recur<<<1, 256, 0, on>>>(rc);
                 bdg::ts_qr_apply<<<qr_grid, 256, 0, on>>>(a, (int)n, (int)j0, (int)r0, (int)m, q.reflectors, qr_scale, qr_beta, qr_w,
-                                                         unsafe + panel, q.v);
+                                                         unsafe + panel, q.v, panel_copy);
+                // T from the stored V, and the check of Q^T P against the R that was written (flag 2 = factorise again)
+                const unsigned vparts = (unsigned)((m + bdg::kTsGramRows - 1) / bdg::kTsGramRows);
+                bdg::ts_vgram2<<<vparts, 256, 0, on>>>(q.v, panel_copy, (int)m, gpart);
+                bdg::ts_t_from_v<<<1, 256, 0, on>>>(gpart, (int)vparts, q.reflectors, unsafe + panel, qr_scale, q.t, qr_m);
+                bdg::ts_qr_verify<<<(unsigned)((m + 255) / 256), 256, 0, on>>>(a, (int)n, (int)j0, (int)r0, (int)m, q.v, panel_copy, qr_m, qr_norms,
+                                                                              verify_tolerance, unsafe + panel);
                 q.only_if = unsafe + panel;
+                q.source = panel_copy;
             }
             bdg::ts_panel_qr<<<qr_grid, 256, 0, on>>>(q);
             return BDG_OK;

@@ -96,6 +96,7 @@ struct TsPanelArgs {
     double* rowi;    // [2][B]
     unsigned* counter;
     const unsigned* only_if;  // nullptr, or: run only if this word is non-zero (the Gram route gave the panel up)
+    const double* source;     // nullptr (the panel is read from a), or the copy ts_qr_apply made of it before overwriting it
 };
 
 __global__ __launch_bounds__(256) void ts_panel_qr(TsPanelArgs q) {
@@ -111,7 +112,11 @@ __global__ __launch_bounds__(256) void ts_panel_qr(TsPanelArgs q) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     double p[B];
 #pragma unroll
-    for (int c = 0; c < B; ++c) p[c] = live ? q.a[(size_t)(q.r0 + g) * q.n + q.j0 + c] : 0.0;
+    for (int c = 0; c < B; ++c) {
+        // (flagged by the recurrence: the panel is untouched; flagged by the verification: it holds R already, the copy is the panel)
+        const bool from_copy = q.source && *q.only_if == 2u;
+        p[c] = !live ? 0.0 : from_copy ? q.source[(size_t)g * B + c] : q.a[(size_t)(q.r0 + g) * q.n + q.j0 + c];
+    }
     for (int e = threadIdx.x; e < B * (B + 1); e += 256) (&tmat[0][0])[e] = 0.0;
     double vprev = 0.0;  // this row's entry of the previous reflector
     unsigned phase = 0;
@@ -220,14 +225,19 @@ __global__ __launch_bounds__(256) void ts_panel_qr(TsPanelArgs q) {
 // workgroup runs all B steps on the top B x B block and G: reflector scales, the rows w(i), T), ts_qr_apply (every row
 // applies the B reflectors to itself) - no barrier at all.  The price is cancellation: the remaining norm of a column
 // comes as a difference, with an error of eps G[i][i]; the reflector built from it is orthogonal to eps G[i][i] / (what
-// remains).  ts_qr_recur therefore raises `unsafe` when less than 1 % of a column's squared norm remains (defect above
-// 1e-13), and the panel is then factorised by ts_panel_qr, which sums the rows themselves.
-constexpr double kTsGramFloor = 1e-2;
+// remains) - and the errors of one such column feed the columns after it: a d-wave lattice of 8 x 21 sites whose worst column
+// kept 3 % came out with eigenvalues 6e-10 off (tests/fuzz_dense.py, seed 7, case 45; 2e-14 with any floor from 0.1 up).
+// ts_qr_recur therefore raises `unsafe` when less than a quarter of a column's squared norm remains, and the panel is then
+// factorised by ts_panel_qr, which sums the rows themselves (one panel in twenty to a hundred on lattice matrices).
+constexpr double kTsGramFloor = 0.25;
 
-__global__ __launch_bounds__(64) void ts_gram(const double* __restrict__ a, int n, int j0, int r0, int m, double* __restrict__ gpart) {
+constexpr int kTsGramRows = 512;  // rows of a panel per workgroup of the Gram kernels (four waves of 128)
+__global__ __launch_bounds__(256) void ts_gram(const double* __restrict__ a, int n, int j0, int r0, int m, double* __restrict__ gpart,
+                                               int first_row) {
     constexpr int B = kTsBand;
-    const int lane = threadIdx.x, i = lane & 15, kk = lane >> 4;
-    const int g0 = B + blockIdx.x * 128, g1 = min(m, g0 + 128);  // rows of the panel below its top block
+    __shared__ double zs[4][B * B];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kk = lane >> 4;
+    const int g0 = first_row + blockIdx.x * kTsGramRows + wave * 128, g1 = min(m, g0 + 128);  // (the panel: its rows below the top block)
     v4f64 acc[3];
 #pragma unroll
     for (int p = 0; p < 3; ++p) acc[p] = v4f64{0.0, 0.0, 0.0, 0.0};
@@ -244,15 +254,18 @@ __global__ __launch_bounds__(64) void ts_gram(const double* __restrict__ a, int 
         acc[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(p0, p1, acc[1], 0, 0, 0);
         acc[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(p1, p1, acc[2], 0, 0, 0);
     }
-    double* out = gpart + (size_t)blockIdx.x * B * B;
+    double* mine = zs[wave];
 #pragma unroll
     for (int r = 0; r < 4; ++r) {
         const int row = kk + 4 * r;
-        out[(size_t)row * B + i] = acc[0][r];
-        out[(size_t)row * B + 16 + i] = acc[1][r];
-        out[(size_t)(16 + i) * B + row] = acc[1][r];
-        out[(size_t)(16 + row) * B + 16 + i] = acc[2][r];
+        mine[row * B + i] = acc[0][r];
+        mine[row * B + 16 + i] = acc[1][r];
+        mine[(16 + i) * B + row] = acc[1][r];
+        mine[(16 + row) * B + 16 + i] = acc[2][r];
     }
+    __syncthreads();
+    double* out = gpart + (size_t)blockIdx.x * B * B;
+    for (int e = threadIdx.x; e < B * B; e += 256) out[e] = (zs[0][e] + zs[1][e]) + (zs[2][e] + zs[3][e]);
 }
 
 struct TsRecurArgs {
@@ -263,19 +276,18 @@ struct TsRecurArgs {
     double* scale;   // [B]  1 / (alpha - beta) of every reflector
     double* beta;    // [B]
     double* wrows;   // [B][B]  w(i)[c] = tau_i (row i of the current panel + scale_i S_c), c > i
-    double* t;       // [B][B]
-    unsigned* unsafe;  // raised when a column keeps less than kTsGramFloor of its squared norm
+    unsigned* unsafe;  // raised when a column keeps less than `floor` of its squared norm
+    double floor;
+    double* colnorm2;  // [B] squared norms of the panel's columns (the scale ts_qr_verify measures against)
 };
 
 __global__ __launch_bounds__(256) void ts_qr_recur(TsRecurArgs q) {
     constexpr int B = kTsBand, L = B + 1;
-    __shared__ double gt[B * L];    // G of the rows below the top block
     __shared__ double top[B * L];   // the top block: rows final above the diagonal sweep (R), reflector entries below
-    __shared__ double top0[B * L];  // ... as it came
-    __shared__ double cm[B * L];    // current columns below the top block = original columns x cm
-    __shared__ double cv[B * L];    // reflector entries below the top block = original columns x cv
-    __shared__ double wm[B * L], vtv[B * L], tmat[B * L], m1[B * L];
-    __shared__ double rem[B], sc[B], be[B], ta[B];
+    __shared__ double full[B * L];  // F = G + top^T top: inner products of the whole columns
+    __shared__ double left[B * L];  // ... of what is left of them below the rows already final
+    __shared__ double wm[B * L];
+    __shared__ double sc[B], be[B];
     __shared__ int bad;
     const int t = threadIdx.x;
     if (t == 0) bad = 0;
@@ -283,30 +295,24 @@ __global__ __launch_bounds__(256) void ts_qr_recur(TsRecurArgs q) {
         const int r = e / B, c = e % B;
         double sum = 0.0;
         for (int w = 0; w < q.parts; ++w) sum += q.gpart[(size_t)w * B * B + e];
-        gt[r * L + c] = sum;
-        const double v = r < q.m ? q.a[(size_t)(q.r0 + r) * q.n + q.j0 + c] : 0.0;
-        top[r * L + c] = v;
-        top0[r * L + c] = v;
-        cm[r * L + c] = r == c ? 1.0 : 0.0;
-        cv[r * L + c] = 0.0;
+        full[r * L + c] = sum;  // (G of the rows below the top block, for now)
+        top[r * L + c] = r < q.m ? q.a[(size_t)(q.r0 + r) * q.n + q.j0 + c] : 0.0;
         wm[r * L + c] = 0.0;
-        tmat[r * L + c] = 0.0;
     }
     __syncthreads();
-    // F = G + top0^T top0: inner products of the whole columns; `left` starts as F and loses R[k][a] R[k][b] with every
-    // finished row k: left[i][c] = inner product of the current columns i and c over the rows i.. (what step i needs)
     for (int e = t; e < B * B; e += 256) {
         const int r = e / B, c = e % B;
-        double full = gt[r * L + c];
-        for (int k = 0; k < B; ++k) full += top0[k * L + r] * top0[k * L + c];
-        vtv[r * L + c] = full;  // (F; vtv is free until the end)
-        m1[r * L + c] = full;   // left
+        double sum = full[r * L + c];
+        for (int k = 0; k < B; ++k) sum += top[k * L + r] * top[k * L + c];
+        left[r * L + c] = sum;
     }
+    __syncthreads();
+    for (int e = t; e < B * B; e += 256) full[e / B * L + e % B] = left[e / B * L + e % B];
     __syncthreads();
     for (int i = 0; i < q.reflectors; ++i) {
         const double alpha = top[i * L + i];
-        const double rem_i = m1[i * L + i];
-        if (t == 0 && rem_i < kTsGramFloor * vtv[i * L + i]) bad = 1;
+        const double rem_i = left[i * L + i];
+        if (t == 0 && rem_i < q.floor * full[i * L + i]) bad = 1;
         const double sigma = fmax(rem_i - alpha * alpha, 0.0);
         double beta = alpha, tau = 0.0, scale = 0.0;
         if (sigma > 0.0) {
@@ -317,90 +323,172 @@ __global__ __launch_bounds__(256) void ts_qr_recur(TsRecurArgs q) {
         if (t < B) {
             const int c = t;
             // S_c = sum over the rows below row i;  w_c = tau (P[i][c] + scale S_c)
-            wm[i * L + c] = c > i ? tau * (top[i * L + c] + scale * (m1[i * L + c] - alpha * top[i * L + c])) : 0.0;
+            wm[i * L + c] = c > i ? tau * (top[i * L + c] + scale * (left[i * L + c] - alpha * top[i * L + c])) : 0.0;
         }
         if (t == 0) {
             sc[i] = scale;
             be[i] = beta;
-            ta[i] = tau;
         }
         __syncthreads();
+        // the top block: rows i.. take the reflector
         for (int e = t; e < B * B; e += 256) {
             const int g = e / B, c = e % B;
-            // the top block: rows i.. take the reflector
-            if (g >= i) {
-                const double vg = g == i ? 1.0 : top[g * L + i] * scale;
-                if (c > i) top[g * L + c] -= vg * wm[i * L + c];
-            }
-            // columns below the top block: column c loses scale w_c times column i
-            if (c > i) cm[g * L + c] -= scale * cm[g * L + i] * wm[i * L + c];
+            if (g >= i && c > i) top[g * L + c] -= (g == i ? 1.0 : top[g * L + i] * scale) * wm[i * L + c];
         }
         __syncthreads();
         if (t < B) {
             const int g = t;
-            cv[g * L + i] = scale * cm[g * L + i];
             if (g == i) top[g * L + i] = beta;
             else if (g > i) top[g * L + i] *= scale;
         }
-        __syncthreads();
-        // row i is final: R[i][i] = beta, R[i][c] = top[i][c]; the columns' remaining inner products lose it
+        // row i is final: R[i][c] = top[i][c]; the columns' remaining inner products lose it
         for (int e = t; e < B * B; e += 256) {
             const int a = e / B, c = e % B;
-            if (a > i && c > i) m1[a * L + c] -= top[i * L + a] * top[i * L + c];
+            if (a > i && c > i) left[a * L + c] -= top[i * L + a] * top[i * L + c];
         }
         __syncthreads();
     }
-    // V^T V = (top part) + cv^T G cv; then T column by column
-    for (int e = t; e < B * B; e += 256) {
-        const int r = e / B, c = e % B;
-        double sum = 0.0;
-        for (int k = 0; k < B; ++k) sum += gt[r * L + k] * cv[k * L + c];
-        m1[r * L + c] = sum;
-    }
-    __syncthreads();
-    for (int e = t; e < B * B; e += 256) {
-        const int r = e / B, c = e % B;  // columns r < c of V
-        double sum = 0.0;
-        if (r < c && c < q.reflectors) {
-            for (int k = 0; k < B; ++k) sum += cv[k * L + r] * m1[k * L + c];
-            for (int g = c; g < B; ++g) {  // rows of the top block where both reflectors live (v_c starts at row c)
-                const double vr = top[g * L + r];  // (g > r: stored entry)
-                const double vc = g == c ? 1.0 : top[g * L + c];
-                sum += vr * vc;
-            }
-        }
-        vtv[r * L + c] = sum;
-    }
-    __syncthreads();
-    for (int col = 0; col < q.reflectors; ++col) {
-        if (t < B) {
-            const int row = t;
-            if (row < col) {
-                double sum = 0.0;
-                for (int k = row; k < col; ++k) sum += tmat[row * L + k] * vtv[k * L + col];
-                tmat[row * L + col] = -ta[col] * sum;
-            } else if (row == col) {
-                tmat[row * L + col] = ta[col];
-            }
-        }
-        __syncthreads();
-    }
-    for (int e = t; e < B * B; e += 256) {
-        q.wrows[e] = wm[e / B * L + e % B];
-        q.t[e] = tmat[e / B * L + e % B];
-    }
+    for (int e = t; e < B * B; e += 256) q.wrows[e] = wm[e / B * L + e % B];
     if (t < B) {
         q.scale[t] = t < q.reflectors ? sc[t] : 0.0;
         q.beta[t] = t < q.reflectors ? be[t] : 0.0;
+        q.colnorm2[t] = full[t * L + t];
     }
     if (t == 0) *q.unsafe = bad ? 1u : 0u;
+}
+
+// ---- T from the stored V, and the verification of the factorisation.
+// ts_vgram2: V^T V and V^T P (P = the copy of the panel) in one MFMA pass over the rows.
+__global__ __launch_bounds__(256) void ts_vgram2(const double* __restrict__ v, const double* __restrict__ pc, int m, double* __restrict__ gpart) {
+    constexpr int B = kTsBand;
+    __shared__ double zs[4][2 * B * B];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, i = lane & 15, kk = lane >> 4;
+    const int g0 = blockIdx.x * kTsGramRows + wave * 128, g1 = min(m, g0 + 128);
+    v4f64 vv[3], vp[2][2];
+#pragma unroll
+    for (int p = 0; p < 3; ++p) vv[p] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+    for (int p = 0; p < 4; ++p) vp[p >> 1][p & 1] = v4f64{0.0, 0.0, 0.0, 0.0};
+#pragma unroll 2
+    for (int k = g0; k < g1; k += 4) {
+        const int row = k + kk;
+        double v0 = 0.0, v1 = 0.0, p0 = 0.0, p1 = 0.0;
+        if (row < g1) {
+            v0 = v[(size_t)row * B + i];
+            v1 = v[(size_t)row * B + i + 16];
+            p0 = pc[(size_t)row * B + i];
+            p1 = pc[(size_t)row * B + i + 16];
+        }
+        vv[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v0, vv[0], 0, 0, 0);
+        vv[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, v1, vv[1], 0, 0, 0);
+        vv[2] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, v1, vv[2], 0, 0, 0);
+        vp[0][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, p0, vp[0][0], 0, 0, 0);
+        vp[0][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v0, p1, vp[0][1], 0, 0, 0);
+        vp[1][0] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, p0, vp[1][0], 0, 0, 0);
+        vp[1][1] = __builtin_amdgcn_mfma_f64_16x16x4f64(v1, p1, vp[1][1], 0, 0, 0);
+    }
+    double* mine = zs[wave];  // [V^T V | V^T P]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = kk + 4 * r;
+        mine[row * B + i] = vv[0][r];
+        mine[row * B + 16 + i] = vv[1][r];
+        mine[(16 + i) * B + row] = vv[1][r];
+        mine[(16 + row) * B + 16 + i] = vv[2][r];
+#pragma unroll
+        for (int p = 0; p < 4; ++p) mine[B * B + ((p >> 1) * 16 + row) * B + (p & 1) * 16 + i] = vp[p >> 1][p & 1][r];
+    }
+    __syncthreads();
+    double* out = gpart + (size_t)blockIdx.x * 2 * B * B;
+    for (int e = threadIdx.x; e < 2 * B * B; e += 256) out[e] = (zs[0][e] + zs[1][e]) + (zs[2][e] + zs[3][e]);
+}
+
+// T of the block reflector from the V that was stored: tau_i = 2 / |v_i|^2 and T[:i, i] = -tau_i T[:i, :i] (V^T V)[:i, i] make
+// I - V T V^T the exact product of the reflectors of these very vectors - orthogonal to rounding whatever the accuracy of
+// the vectors themselves (what ts_qr_recur derives from downdated inner products is not: T carried its cancellation on).
+// Also M = T^T (V^T P): Q^T P = P - V M, what ts_qr_verify holds against the R that was written.
+__global__ __launch_bounds__(256) void ts_t_from_v(const double* __restrict__ gpart, int parts, int reflectors, const unsigned* __restrict__ unsafe,
+                                                   const double* __restrict__ scale, double* __restrict__ t, double* __restrict__ mout) {
+    constexpr int B = kTsBand, L = B + 1;
+    if (*unsafe) return;  // (ts_panel_qr writes T for this panel)
+    __shared__ double g[B * L], tm[B * L], vp[B * L];
+    const int tid = threadIdx.x;
+    for (int e = tid; e < B * B; e += 256) {
+        double sum = 0.0, sum2 = 0.0;
+        for (int w = 0; w < parts; ++w) {
+            sum += gpart[(size_t)w * 2 * B * B + e];
+            sum2 += gpart[(size_t)w * 2 * B * B + B * B + e];
+        }
+        g[e / B * L + e % B] = sum;
+        vp[e / B * L + e % B] = sum2;
+        tm[e / B * L + e % B] = 0.0;
+    }
+    __syncthreads();
+    if (tid < 64) {  // (the recurrence: one wave, column by column)
+        for (int col = 0; col < reflectors; ++col) {
+            const double norm2 = g[col * L + col];
+            // (scale = 0: the column was already zero below the diagonal and no reflector was made; a reflector whose tail has
+            // rounded away is still one - |v|^2 = 1, tau = 2: it flips the sign of the pivot, and R holds beta = -alpha)
+            const double tau = scale[col] != 0.0 ? 2.0 / norm2 : 0.0;
+            if (tid < col) {
+                double sum = 0.0;
+                for (int k = tid; k < col; ++k) sum += tm[tid * L + k] * g[k * L + col];
+                tm[tid * L + col] = -tau * sum;
+            } else if (tid == col) {
+                tm[tid * L + col] = tau;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+        }
+    }
+    __syncthreads();
+    for (int e = tid; e < B * B; e += 256) {
+        const int r = e / B, c = e % B;
+        t[e] = (r < reflectors && c < reflectors) ? tm[r * L + c] : 0.0;
+        double sum = 0.0;  // M[r][c] = sum_k T[k][r] (V^T P)[k][c], k <= r
+        for (int k = 0; k <= r; ++k) sum += tm[k * L + r] * vp[k * L + c];
+        mout[e] = sum;
+    }
+}
+
+// Q^T P = P - V M against what was written (R in the first rows, zeros below): a panel whose worst entry is off by more than
+// `tolerance` x (the largest column norm of the panel) is flagged 2, and ts_panel_qr factorises it again from the copy.
+__global__ __launch_bounds__(256) void ts_qr_verify(const double* __restrict__ a, int n, int j0, int r0, int m, const double* __restrict__ v,
+                                                    const double* __restrict__ pc, const double* __restrict__ mm, const double* __restrict__ colnorm2,
+                                                    double tolerance, unsigned* __restrict__ unsafe) {
+    constexpr int B = kTsBand;
+    if (*unsafe == 1u) return;
+    __shared__ double ms[B][B];
+    __shared__ double limit;
+    for (int e = threadIdx.x; e < B * B; e += 256) ms[e / B][e % B] = mm[e];
+    if (threadIdx.x == 0) {
+        double largest = 0.0;
+        for (int c = 0; c < B; ++c) largest = fmax(largest, colnorm2[c]);
+        limit = tolerance * sqrt(largest);
+    }
+    __syncthreads();
+    const int g = blockIdx.x * 256 + threadIdx.x;
+    if (g >= m) return;
+    double vr[B];
+#pragma unroll
+    for (int c = 0; c < B; ++c) vr[c] = v[(size_t)g * B + c];
+    double worst = 0.0;
+#pragma unroll 4
+    for (int c = 0; c < B; ++c) {
+        double value = pc[(size_t)g * B + c];
+#pragma unroll
+        for (int k = 0; k < B; ++k) value -= vr[k] * ms[k][c];
+        worst = fmax(worst, fabs(value - a[(size_t)(r0 + g) * n + j0 + c]));
+    }
+    if (worst > limit) atomicMax(unsafe, 2u);
 }
 
 // every row applies the reflectors to itself (ts_qr_recur found them), writes its row of V, and R / zeros into A
 __global__ __launch_bounds__(256) void ts_qr_apply(double* __restrict__ a, int n, int j0, int r0, int m, int reflectors,
                                                    const double* __restrict__ scale, const double* __restrict__ beta,
                                                    const double* __restrict__ wrows, const unsigned* __restrict__ unsafe,
-                                                   double* __restrict__ v) {
+                                                   double* __restrict__ v, double* __restrict__ panel_copy) {
     constexpr int B = kTsBand;
     if (*unsafe) return;  // (ts_panel_qr factorises this panel)
     __shared__ double wm[B][B], sc[B], be[B];
@@ -419,7 +507,10 @@ __global__ __launch_bounds__(256) void ts_qr_apply(double* __restrict__ a, int n
     }
     double p[B];
 #pragma unroll
-    for (int c = 0; c < B; ++c) p[c] = a[(size_t)(r0 + g) * n + j0 + c];
+    for (int c = 0; c < B; ++c) {
+        p[c] = a[(size_t)(r0 + g) * n + j0 + c];
+        panel_copy[(size_t)g * B + c] = p[c];  // (ts_qr_verify checks the factorisation against it; ts_panel_qr starts from it if that fails)
+    }
 #pragma unroll
     for (int i = 0; i < B; ++i) {
         if (i < reflectors && g >= i) {
