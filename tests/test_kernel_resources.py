@@ -25,7 +25,8 @@ def resources():
 
 
 def _row(resources, name):
-    matches = [row for key, row in resources.items() if key.startswith(f"void bdg::{name}(")]
+    # (template instances demangle with their return type, plain kernels without)
+    matches = [row for key, row in resources.items() if key.startswith(f"void bdg::{name}(") or key.startswith(f"bdg::{name}(")]
     assert len(matches) == 1, (name, [k for k in resources if name.split("<")[0] in k][:5])
     return matches[0]
 
@@ -74,3 +75,22 @@ def test_streamed_onsite_sweep_keeps_two_waves_per_simd(resources):
     for reverse, gen in (("false", "false"), ("true", "false"), ("false", "true")):  # bond blocks streamed as well: no table code
         row = _row(resources, f"cheb_sweep3<bdg::RealPHMode, 4, {reverse}, {gen}, 2>")
         assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (reverse, gen, row)
+
+
+@pytest.mark.timeout(600)
+def test_chunk_kernel_and_dense_two_stage_kernels_keep_their_registers(resources):
+    """Round 4: cheb_march3 (the sweeps of a chunk in one launch) carries the unit body of cheb_sweep3 twice (with and
+    without the generated start block) plus its claim / wait code: two waves per SIMD, a few loop-invariant values in
+    scratch at most.  The MFMA kernels of the two-stage dense route (csrc/twostage.hpp) must not spill at all; the bulge
+    chasing and the band inverse iteration keep their blocks / window in registers (one wave per workgroup: the budget
+    is the whole file), again without scratch."""
+    for mode in ("RealPHMode", "ComplexPHMode", "RealMode", "ComplexMode"):
+        for lanes in (2, 4):
+            row = _row(resources, f"cheb_march3<bdg::{mode}, {lanes}, 0>")
+            assert row["scratch"] <= 96 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, row)
+    for name in ("ts_symm", "ts_rank2k", "ts_xz", "ts_gram", "ts_vgram2", "ts_vtz", "ts_zupdate", "ts_qr_apply", "ts_qr_verify"):
+        row = _row(resources, name)
+        assert row["scratch"] == 0, (name, row)
+    for name in ("ts_chase", "ts_band_vectors"):
+        row = _row(resources, name)
+        assert row["scratch"] == 0 and row["vgpr"] <= 256, (name, row)
