@@ -26,6 +26,12 @@
 //                                            tridiagonalisation route above);  BODGE_AMD_EIGH_REAL=0  complex arithmetic for a real matrix
 //     BODGE_AMD_EIGH_DEFER=1..4              reflector pairs kept pending in the tridiagonalisation (default 4 from 5000 rows, else 1)
 //     BODGE_AMD_EIGH_CHUNKS=cap[,rows]       row chunks of a back-transformation pass: at most `cap` (default 48) of at least `rows` rows (64)
+//     BODGE_AMD_EIGH_STAGES=1|2              real matrices: one-stage tridiagonalisation (tridiag.hpp) / through a band (twostage.hpp); default 2 from
+//                                            5000 rows (eigenvalues) / 3000 rows (eigenpairs).  Pieces of the two-stage route, for tests and A/B runs:
+//                                            _GRAM_QR=0 (every panel with a grid barrier per column), _GRAM_FLOOR=x (share of a column's squared norm below
+//                                            which the Gram route gives a panel up; 0.25), _VERIFY=tol (tolerance of the check of Q^T P; 2e-13),
+//                                            _LOOKAHEAD=0|1, _BAND_VECTORS=0 (eigenvectors by the one-stage route), _BAND_ITERATIONS=n (3),
+//                                            _STAGE2=0, _CHASE_GRID=n, _CHASE_PROFILE (phase times of the bulge chasing on stderr)
 //     BODGE_AMD_ONSITE_STREAM=0              (read at upload) no bond-only dictionary + on-site stream for matrices with > 256 distinct blocks
 //     BODGE_AMD_NO_DIAGONAL_BLOCKS           withhold the "diagonal as a 4x4 matrix" flag of dictionary blocks (read at upload)
 //   launch shape and memory hints
