@@ -110,6 +110,17 @@ def build_system(shape, model="swave", zeeman=0.05, gap=0.1, mu=3.0, seed=11):
             for axis in (1, 2):
                 if shape[axis] > 1:
                     H.set_bonds(-1.0 * ba.σ0, axis=axis)
+        elif model == "landau":  # the texture model in a magnetic field: Landau-gauge Peierls phases exp(±i B y) on the x bonds
+            th, ph = rng.uniform(0, np.pi, sites)[:, None, None], rng.uniform(0, 2 * np.pi, sites)[:, None, None]
+            H.set_sites(mu * ba.σ0 - 0.3 * (np.sin(th) * np.cos(ph) * ba.σ1 + np.sin(th) * np.sin(ph) * ba.σ2 + np.cos(th) * ba.σ3))
+            Δ.set_sites(-gap * ba.jσ2)
+            pairs = lattice.bond_array(axis=0, coords=True)
+            flux = 0.0123 * pairs[:, 0, 1]
+            phase = np.exp(1j * np.where(pairs[:, 1, 0] > pairs[:, 0, 0], flux, -flux))
+            H.set_bonds(-phase[:, None, None] * ba.σ0, axis=0)
+            for axis in (1, 2):
+                if shape[axis] > 1:
+                    H.set_bonds(-1.0 * ba.σ0, axis=axis)
         elif model == "dwave":
             pairs = lattice.bond_array(coords=True)
             H.set_sites(mu * ba.σ0)
@@ -365,7 +376,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="0 disables the cpu_baseline leg")
     ap.add_argument("--temperature", type=float, default=0.5)
     ap.add_argument("--user-calls", type=int, default=1, help="0 skips the wall times of free_energy / diagonalize / ldos through the Python API")
-    ap.add_argument("--model", default="swave", choices=["swave", "dwave", "potential", "texture", "ssd", "peierls"])
+    ap.add_argument("--model", default="swave", choices=["swave", "dwave", "potential", "texture", "ssd", "peierls", "landau"])
     ap.add_argument("--mode", default="vectors", choices=["vectors", "slab"],
                     help="vectors: H replicated, start vectors sharded (weak scaling, headline); "
                          "slab: lattice planes sharded with per-step halo exchange (strong scaling, config 4)")
@@ -537,7 +548,8 @@ def main():
         record["one_step"] = out["one_step"]
         record["workload"] = {"potential": "random on-site potential and gap amplitude (10^6 distinct diagonal blocks), real",
                               "texture": "exchange field of varying direction on every site (10^6 distinct diagonal blocks), complex",
-                              "ssd": "every term scaled by the reference's ssd() envelope (on-site AND bond blocks position dependent), real"}[model]
+                              "ssd": "every term scaled by the reference's ssd() envelope (on-site AND bond blocks position dependent), real",
+                              "landau": "exchange field of varying direction on every site and Landau-gauge Peierls phases on the x bonds (2000 distinct complex bond blocks), complex"}[model]
         record["distinct_blocks_total"] = "> 256" if pf["dict_skipped"] == 1 else pf["dict_blocks"]
         return record
 
@@ -552,6 +564,7 @@ def main():
     position_pass = other_matrix("potential", VEC_RADEMACHER) if world == 1 and args.model == "swave" else None
     texture_pass = other_matrix("texture", VEC_Z4) if world == 1 and args.model == "swave" else None
     ssd_pass = other_matrix("ssd", VEC_RADEMACHER) if world == 1 and args.model == "swave" else None
+    landau_pass = other_matrix("landau", VEC_Z4) if world == 1 and args.model == "swave" else None
     complex_one_step = (alternative({"BODGE_AMD_SWEEP": "0", "BODGE_AMD_DICT": "0", "BODGE_AMD_REAL": "0"})
                         if probe["real_arithmetic"] else None)
     complex_sweep = alternative({"BODGE_AMD_REAL": "0"}) if probe["real_arithmetic"] and probe["steps_per_launch"] >= 2 else None
@@ -656,6 +669,7 @@ def main():
         "streamed_blocks_kernels": position_pass,
         "complex128_kernels": texture_pass,
         "streamed_bonds_kernels": ssd_pass,
+        "complex128_bonds_kernels": landau_pass,
         "complex128_sweep_kernels": complex_sweep,
         "streamed_blocks_one_step_kernels": streamed_one_step,
         "complex128_one_step_kernels": complex_one_step,

@@ -184,20 +184,20 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
             wanted = may_stream && dedupe(true, (int)kStreamedId) && !distinct.empty();
             onsite_streamed = wanted;
             if (!wanted && may_stream) {
-                // Third form: bond blocks position dependent too.  Every block of the matrix real; diagonal blocks
-                // packable as above; off-diagonal blocks diagonal as 4x4 matrices of the Nambu form diag(a, b, -a, -b).
-                // Then nothing is tabulated (one dummy table entry keeps the table plumbing uniform).
+                // Third form: bond blocks position dependent too.  Diagonal blocks packable as above; off-diagonal
+                // blocks diagonal as 4x4 matrices of the Nambu form diag(a, b, -conj a, -conj b), exactly.  Then nothing
+                // is tabulated (one dummy table entry keeps the table plumbing uniform); real arithmetic needs every
+                // block real on top (is_real below), complex arithmetic takes the 224-byte records.
                 bool ok = true;
                 for (int64_t i = 0; i < nb && ok; ++i)
                     for (int64_t k = indptr[i]; k < indptr[i + 1] && ok; ++k) {
                         const double* blk = data + 32 * k;
-                        for (int e = 0; e < 16 && ok; ++e) ok = blk[2 * e + 1] == 0.0;  // real
-                        if (!ok) break;
                         if (indices[k] == i) ok = onsite_packable(blk);
                         else {
                             for (int e = 0; e < 16 && ok; ++e)
-                                if ((e >> 2) != (e & 3)) ok = blk[2 * e] == 0.0;
-                            ok = ok && blk[2 * 10] == -blk[2 * 0] && blk[2 * 15] == -blk[2 * 5];
+                                if ((e >> 2) != (e & 3)) ok = blk[2 * e] == 0.0 && blk[2 * e + 1] == 0.0;
+                            ok = ok && blk[2 * 10] == -blk[2 * 0] && blk[2 * 10 + 1] == blk[2 * 0 + 1] &&
+                                 blk[2 * 15] == -blk[2 * 5] && blk[2 * 15 + 1] == blk[2 * 5 + 1];
                         }
                     }
                 if (ok) {
@@ -308,6 +308,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
     if (hipGetDeviceProperties(&prop, device) != hipSuccess)
         return cleanup(fail(BDG_EDEVICE, "hipGetDeviceProperties failed"));
     sys->num_cus = prop.multiProcessorCount;
+    sys->lds_per_cu = std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor, prop.sharedMemPerBlockOptin ? prop.sharedMemPerBlockOptin : prop.maxSharedMemoryPerMultiProcessor);
     if (hipStreamCreateWithFlags(&sys->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&sys->ev_start) != hipSuccess || hipEventCreate(&sys->ev_stop) != hipSuccess)
         return cleanup(fail(BDG_EDEVICE, "stream/event creation failed"));
@@ -510,7 +511,7 @@ int bdg_destroy(bdg_system* sys) {
     for (auto& buf : sys->packed) buf.release();
     for (auto& buf : sys->dict_table) buf.release();
     for (auto& buf : sys->onsite) buf.release();
-    sys->site_records.release();
+    for (auto& buf : sys->site_records) buf.release();
     sys->dict_ids.release();
     sys->dict_diagonal.release();
     sys->dict_full.release();

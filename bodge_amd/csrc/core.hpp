@@ -147,6 +147,7 @@ struct bdg_system : StreamSet {
     int max_row_blocks = 0;
     int64_t bandwidth = 0;  // max |column - row| over the stored blocks (square matrices)
     int num_cus = 0;
+    size_t lds_per_cu = 0;  // LDS bytes of a CU (and the most one workgroup may take)
     int lanes_override = 0;
     DeviceBuffer<int> indptr, indices;
     DeviceBuffer<double2> blocks;
@@ -164,13 +165,14 @@ struct bdg_system : StreamSet {
     // (cheb_sweep3<..., OS>); every other kernel family streams all blocks of such a matrix.
     bool onsite_streamed = false;
     DeviceBuffer<double2> onsite[2];  // [0] complex (6 x 16 B per site), [1] real (4 x 16 B); built on first use
-    // ... and when the bond blocks differ from bond to bond as well (the reference's ssd() profile, bond disorder) but
-    // are all diagonal as 4x4 matrices (spin-diagonal hopping, no bond pairing) and the matrix is real: no table at
-    // all, every site carries its four bond blocks (two doubles each) next to its on-site block in one 128-byte
-    // record (`site_records`, built once the lattice shape is known); real arithmetic only.
+    // ... and when the bond blocks differ from bond to bond as well (the reference's ssd() profile, bond disorder,
+    // Peierls phases of a position-dependent gauge) but are all diagonal as 4x4 matrices of the Nambu form
+    // diag(a, b, -conj a, -conj b) (spin-diagonal hopping, no bond pairing): no table at all, every site carries its
+    // four bond blocks next to its on-site block in one record (`site_records`, built once the lattice shape is known):
+    // [1] real arithmetic (real matrices), 128 B per site; [0] complex arithmetic, 224 B per site.
     bool bonds_streamed = false;
-    DeviceBuffer<double2> site_records;
-    int site_records_plane = 0;  // lattice plane size the records were built for
+    DeviceBuffer<double2> site_records[2];
+    int site_records_plane[2] = {0, 0};  // lattice plane size the records were built for
     DeviceBuffer<int> dict_ids;
     DeviceBuffer<int> dict_diagonal;      // per distinct block: 1 = diagonal as a 4x4 matrix (stencil kernels)
     DeviceBuffer<double2> dict_full;      // n_unique x 16 complex entries

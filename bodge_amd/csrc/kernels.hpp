@@ -445,6 +445,12 @@ struct ComplexPHMode {
         cfms_conj(acc[3], a10, x[2]);
         cfms_conj(acc[3], a11, x[3]);
     }
+    // a streamed bond block diag(A00, A11, -conj A00, -conj A11) (sweep.hpp, OS = 2; two record slots A00, A11): the
+    // products of mac_diag_compact on the same numbers
+    static constexpr int kBondSlots = 2;
+    __device__ static inline void mac_bond(double2 acc[4], const double2* bond, const double2 x[4]) {
+        mac_diag_compact(acc, bond, x);
+    }
     __device__ static inline void dots(double dot[4], const double2 c, const double2 n) {
         ComplexMode::dots(dot, c, n);
     }
@@ -511,8 +517,10 @@ struct RealPHMode {
         rfma(acc[3], -s0.y, x[2]);
         rfma(acc[3], -s1.x, x[3]);
     }
-    // a streamed bond block diag(a.x, a.y, -a.x, -a.y) (sweep.hpp, OS = 2): mac_diag's products in mac_diag's order
-    __device__ static inline void mac_bond(double2 acc[4], const double2 a, const double2 x[4]) {
+    // a streamed bond block diag(a.x, a.y, -a.x, -a.y) (sweep.hpp, OS = 2; one record slot): mac_diag's products in mac_diag's order
+    static constexpr int kBondSlots = 1;
+    __device__ static inline void mac_bond(double2 acc[4], const double2* bond, const double2 x[4]) {
+        const double2 a = bond[0];
         rfma(acc[0], a.x, x[0]);
         rfma(acc[1], a.y, x[1]);
         rfma(acc[2], -a.x, x[2]);

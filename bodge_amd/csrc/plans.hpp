@@ -304,15 +304,17 @@ int ensure_onsite(bdg_system* sys, bool real, const double2** out) {
 }
 
 // Per-site records (on-site + four bond blocks) of a matrix whose bond blocks are streamed too; needs the lattice shape.
-int ensure_site_records(bdg_system* sys, int plane, const double2** out) {
-    if (!sys->site_records.ptr || sys->site_records_plane != plane) {
-        if (int rc = sys->site_records.reserve((size_t)sys->nb * 8)) return rc;
+int ensure_site_records(bdg_system* sys, int plane, bool real, const double2** out) {
+    DeviceBuffer<double2>& buf = sys->site_records[real ? 1 : 0];
+    int& built_for = sys->site_records_plane[real ? 1 : 0];
+    if (!buf.ptr || built_for != plane) {
+        if (int rc = buf.reserve((size_t)sys->nb * (real ? 8 : 14))) return rc;
         bdg::pack_site_records<<<(unsigned)std::min<int64_t>(4096, (sys->nb + 255) / 256), 256, 0, sys->stream>>>(
-            sys->indptr.ptr, sys->indices.ptr, sys->blocks.ptr, (int)sys->nb, plane, sys->site_records.ptr);
+            sys->indptr.ptr, sys->indices.ptr, sys->blocks.ptr, (int)sys->nb, plane, real ? 1 : 0, buf.ptr);
         HIP_TRY(hipGetLastError());
-        sys->site_records_plane = plane;
+        built_for = plane;
     }
-    *out = sys->site_records.ptr;
+    *out = buf.ptr;
     return BDG_OK;
 }
 
@@ -464,19 +466,60 @@ SweepKernel sweep3_gen_kernel(const ModeInfo& mode, int lanes) {
     return sweep3_gen_kernel_for<ComplexMode>(lanes);
 }
 
-// cheb_sweep3 with streamed on-site blocks: particle-hole modes, 4 lanes per site; `bonds`: the bond blocks as well (real only)
-SweepKernel sweep3_streamed_kernel(const ModeInfo& mode, bool reverse, bool gen, bool bonds = false) {
+// cheb_sweep3 with streamed on-site blocks (particle-hole modes); `bonds`: the bond blocks as well.  The forms built:
+//   on-site records, real:     4 lanes x 4 waves (two workgroups per CU), 2 lanes x 4 waves (two per CU while the bond table
+//                              is small) and 2 lanes x 7 waves (one per CU)
+//   on-site records, complex:  4 lanes x 4 waves, 2 lanes x 7 waves
+//   site records (bonds too):  real 4 lanes x 4 waves, complex 4 lanes x 7 waves
+template <typename Mode, int RL, int OS, int WAVES>
+SweepKernel sweep3_streamed_pick(bool reverse, bool gen) {
+    return gen ? bdg::cheb_sweep3<Mode, RL, false, true, OS, WAVES>
+               : reverse ? bdg::cheb_sweep3<Mode, RL, true, false, OS, WAVES> : bdg::cheb_sweep3<Mode, RL, false, false, OS, WAVES>;
+}
+SweepKernel sweep3_streamed_kernel(const ModeInfo& mode, int lanes, int waves, bool reverse, bool gen, bool bonds = false) {
     if (!mode.ph) return nullptr;
     if (bonds) {
-        if (!mode.real) return nullptr;
-        return gen ? bdg::cheb_sweep3<RealPHMode, 4, false, true, 2>
-                   : reverse ? bdg::cheb_sweep3<RealPHMode, 4, true, false, 2> : bdg::cheb_sweep3<RealPHMode, 4, false, false, 2>;
+        if (mode.real) return lanes == 4 && waves == 4 ? sweep3_streamed_pick<RealPHMode, 4, 2, 4>(reverse, gen) : nullptr;
+        return lanes == 4 && waves == 7 ? sweep3_streamed_pick<ComplexPHMode, 4, 2, 7>(reverse, gen) : nullptr;
     }
-    if (mode.real)
-        return gen ? bdg::cheb_sweep3<RealPHMode, 4, false, true, 1>
-                   : reverse ? bdg::cheb_sweep3<RealPHMode, 4, true, false, 1> : bdg::cheb_sweep3<RealPHMode, 4, false, false, 1>;
-    return gen ? bdg::cheb_sweep3<ComplexPHMode, 4, false, true, 1>
-               : reverse ? bdg::cheb_sweep3<ComplexPHMode, 4, true, false, 1> : bdg::cheb_sweep3<ComplexPHMode, 4, false, false, 1>;
+    if (mode.real) {
+        if (lanes == 4 && waves == 4) return sweep3_streamed_pick<RealPHMode, 4, 1, 4>(reverse, gen);
+        if (lanes == 2 && waves == 4) return sweep3_streamed_pick<RealPHMode, 2, 1, 4>(reverse, gen);
+        if (lanes == 2 && waves == 7) return sweep3_streamed_pick<RealPHMode, 2, 1, 7>(reverse, gen);
+        return nullptr;
+    }
+    if (lanes == 4 && waves == 4) return sweep3_streamed_pick<ComplexPHMode, 4, 1, 4>(reverse, gen);
+    if (lanes == 2 && waves == 7) return sweep3_streamed_pick<ComplexPHMode, 2, 1, 7>(reverse, gen);
+    return nullptr;
+}
+
+// LDS of one workgroup of cheb_sweep3: table + compact diagonals + per wave three hand-over rows and (streamed forms)
+// the ring of three planes of records.
+size_t sweep3_lds_bytes(const bdg_system* sys, const ModeInfo& mode, int lanes, int waves) {
+    size_t bytes = (size_t)sys->n_unique * mode.stride * sizeof(double2) +
+                   (size_t)sys->n_unique * (mode.id == 0 ? 4 : mode.id == 3 ? 1 : 2) * sizeof(double2);
+    size_t per_wave = (size_t)3 * bdg::kWave * 4 * sizeof(double2);
+    if (sys->onsite_streamed) {
+        const int stride = sys->bonds_streamed ? (mode.real ? bdg::sweep3_record_stride<RealPHMode, 2>() : bdg::sweep3_record_stride<ComplexPHMode, 2>())
+                                               : (mode.real ? bdg::sweep3_record_stride<RealPHMode, 1>() : bdg::sweep3_record_stride<ComplexPHMode, 1>());
+        per_wave += (size_t)3 * (bdg::kWave / lanes) * stride * sizeof(double2);
+    }
+    return bytes + (size_t)waves * per_wave;
+}
+
+// Waves per workgroup of the streamed form with `lanes` lanes per site (0 = that form does not exist or does not fit
+// the LDS of this device): the shape that keeps the most waves on a CU.
+int streamed_waves_for(const bdg_system* sys, const ModeInfo& mode, int lanes) {
+    if (!sys->onsite_streamed || !mode.ph) return 0;
+    int best = 0, best_resident = 0;
+    for (int waves : {4, 7}) {
+        if (!sweep3_streamed_kernel(mode, lanes, waves, false, false, sys->bonds_streamed)) continue;
+        const size_t lds = sweep3_lds_bytes(sys, mode, lanes, waves);
+        if (lds > sys->lds_per_cu) continue;
+        const int resident = waves * (int)std::min<size_t>(waves > 4 ? 1 : 2, sys->lds_per_cu / lds);
+        if (resident > best_resident) best = waves, best_resident = resident;
+    }
+    return best;
 }
 
 SweepKernel sweep3_kernel(const ModeInfo& mode, int lanes, bool reverse) {
@@ -520,6 +563,7 @@ struct SweepPlan {
     MarchKernel march = nullptr;       // depth 3: all sweeps of a reduction chunk in one launch (nullptr = not available)
     int march_grid = 0;                // workgroups of such a launch
     int grid = 0;
+    int wg_waves = bdg::kSweepWaves;   // waves per workgroup (the streamed forms with one workgroup per CU: 7)
     size_t lds_bytes = 0;
     bdg::SweepArgs args{};
     int waves = 0;  // resident waves of a launch (what a launch over a band of planes cuts its segments for)
@@ -651,37 +695,38 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     plan->lanes = lanes;
     plan->depth = depth;
     const bool streamed = sys->onsite_streamed, bonds = sys->bonds_streamed;
-    if (streamed && (lanes != 4 || depth != 3 || !mode.ph || (bonds && !mode.real)))
-        return fail(BDG_EINVAL, "streamed on-site blocks need the three-step sweep with 4 lanes per site and particle-hole packed blocks (real arithmetic if the bond blocks are streamed too)");
-    plan->kernel = streamed ? sweep3_streamed_kernel(mode, false, false, bonds)
+    const int wg_waves = streamed ? streamed_waves_for(sys, mode, lanes) : bdg::kSweepWaves;
+    if (streamed && (depth != 3 || wg_waves == 0))
+        return fail(BDG_EINVAL, "streamed on-site blocks need the three-step sweep, particle-hole packed blocks and a lane count whose ring of records fits the LDS (%d lanes do not)", lanes);
+    plan->wg_waves = wg_waves;
+    plan->kernel = streamed ? sweep3_streamed_kernel(mode, lanes, wg_waves, false, false, bonds)
                             : depth == 3 ? sweep3_kernel(mode, lanes, false) : sweep_kernel(mode, lanes, false);
-    plan->kernel_reverse = streamed ? sweep3_streamed_kernel(mode, true, false, bonds)
+    plan->kernel_reverse = streamed ? sweep3_streamed_kernel(mode, lanes, wg_waves, true, false, bonds)
                                     : depth == 3 ? sweep3_kernel(mode, lanes, true) : sweep_kernel(mode, lanes, true);
-    plan->kernel_gen = streamed ? sweep3_streamed_kernel(mode, false, true, bonds) : depth == 3 ? sweep3_gen_kernel(mode, lanes) : nullptr;
+    plan->kernel_gen = streamed ? sweep3_streamed_kernel(mode, lanes, wg_waves, false, true, bonds) : depth == 3 ? sweep3_gen_kernel(mode, lanes) : nullptr;
     if (!plan->kernel) return fail(BDG_EINVAL, "the sweep kernel has 1, 2 or 4 lanes per site, not %d", lanes);
     const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
     if (table > table_limit(sys)) return fail(BDG_EINVAL, "block table too large for the sweep kernel");
-    size_t rows = (size_t)bdg::kSweepWaves * depth * bdg::kWave * 4 * sizeof(double2);
-    if (depth == 3)  // compact diagonals behind the table (cheb_sweep3)
-        rows += (size_t)sys->n_unique * (mode.id == 0 ? 4 : mode.id == 3 ? 1 : 2) * sizeof(double2);
-    if (streamed)  // ring of three planes of per-site records per wave (stride 9: on-site + four bond blocks)
-        rows += (size_t)bdg::kSweepWaves * 3 * (bdg::kWave / lanes) *
-                (bonds ? 9 : mode.real ? RealPHMode::kOnsiteStride : ComplexPHMode::kOnsiteStride) * sizeof(double2);
-    plan->lds_bytes = table + rows;
+    if (depth == 3) {
+        plan->lds_bytes = sweep3_lds_bytes(sys, mode, lanes, wg_waves);
+    } else {
+        plan->lds_bytes = table + (size_t)bdg::kSweepWaves * depth * bdg::kWave * 4 * sizeof(double2);
+    }
     if (plan->lds_bytes > 64 * 1024)
         for (SweepKernel k : {plan->kernel, plan->kernel_reverse, plan->kernel_gen})
             if (k) HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize,
                                         (int)plan->lds_bytes));
     // one launch per chunk: the write-through stores address a buffer through a 32-bit byte offset
-    plan->march = depth == 3 && (size_t)sys->ncols * lanes * 4 * sizeof(double2) < ((size_t)1 << 31) && sys->ncols == sys->nb
+    plan->march = depth == 3 && wg_waves == bdg::kWavesPerBlock &&
+                          (size_t)sys->ncols * lanes * 4 * sizeof(double2) < ((size_t)1 << 31) && sys->ncols == sys->nb
                       ? march3_kernel(mode, lanes, streamed, bonds) : nullptr;
     if (plan->march && plan->lds_bytes > 64 * 1024)
         HIP_TRY(hipFuncSetAttribute(reinterpret_cast<const void*>(plan->march), hipFuncAttributeMaxDynamicSharedMemorySize,
                                     (int)plan->lds_bytes));
     int per_cu = 0;
     HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, reinterpret_cast<const void*>(plan->kernel),
-                                                         bdg::kSweepThreads, plan->lds_bytes));
-    per_cu = std::max(1, std::min(per_cu, 2 * bdg::kWavesPerBlock / bdg::kSweepWaves));
+                                                         wg_waves * bdg::kWave, plan->lds_bytes));
+    per_cu = std::max(1, std::min(per_cu, wg_waves > 4 ? 1 : 2 * bdg::kWavesPerBlock / bdg::kSweepWaves));
     if (const char* cap = knob::raw("BODGE_AMD_BLOCKS_PER_CU")) per_cu = std::max(1, atoi(cap));
     const int64_t plane = (int64_t)sys->shape[1] * sys->shape[2];
     bdg::SweepArgs& a = plan->args;
@@ -689,7 +734,7 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     a.stencil = sys->stencil.ptr;
     if (int rc = ensure_dict_table(sys, mode, &a.dict_table)) return rc;
     if (bonds) {
-        if (int rc = ensure_site_records(sys, (int)plane, &a.onsite)) return rc;
+        if (int rc = ensure_site_records(sys, (int)plane, mode.real, &a.onsite)) return rc;
     } else if (streamed) {
         if (int rc = ensure_onsite(sys, mode.real, &a.onsite)) return rc;
     }
@@ -703,7 +748,7 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     // (not with streamed on-site blocks: their complex form keeps one workgroup per CU, and half the segments took the
     // texture matrix from 35.5 to 23.2 k vector-steps/s; the real form gains 1.7 % - within the noise)
     if (streamed) share = 1;
-    const int waves = std::max(bdg::kSweepWaves, per_cu * sys->num_cus * bdg::kSweepWaves / std::max(1, share));
+    const int waves = std::max(wg_waves, per_cu * sys->num_cus * wg_waves / std::max(1, share));
     // (launches side by side: the count that fills the share of the slots - 26 against 25 segments is the 2 % the model says)
     int n_segs = choose_segments(a.n_cols, a.lx, waves, 2 * depth, 8, share > 1 ? 0.985 : 0.97);
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_SEGMENTS")) n_segs = atoi(env);
@@ -717,11 +762,11 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     a.wrap_p = sys->stencil_wrap_p ? 1 : 0;
     a.wrap_x = sys->stencil_wrap_x ? 1 : 0;
     const int64_t units = (int64_t)a.n_cols * a.n_segs;
-    const int grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus, (units + bdg::kSweepWaves - 1) / bdg::kSweepWaves);
+    const int grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus, (units + wg_waves - 1) / wg_waves);
     plan->grid = std::max(8, (grid + 7) / 8 * 8);
     // (a chunk in one launch: `share` lane groups are tasks of the same launch - every wave slot of the device)
     const int march_grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus,
-                                                  (units * std::max(1, share) + bdg::kSweepWaves - 1) / bdg::kSweepWaves);
+                                                  (units * std::max(1, share) + wg_waves - 1) / wg_waves);
     plan->march_grid = std::max(8, (march_grid + 7) / 8 * 8);
     return BDG_OK;
 }
@@ -732,7 +777,7 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
 // With streamed on-site blocks each site adds its packed record (64 B real / 96 B complex), read once.
 double sweep_bytes(const bdg_system* sys, const ModeInfo& mode, int lanes) {
     const double onsite = !sys->onsite_streamed ? 0.0
-                          : sys->bonds_streamed ? 128.0  // on-site + four bond blocks per site
+                          : sys->bonds_streamed ? (mode.real ? 128.0 : 224.0)  // on-site + four bond blocks per site
                           : 16.0 * (mode.real ? RealPHMode::kOnsiteSlots : ComplexPHMode::kOnsiteSlots);
     return (8.0 + onsite) * (double)sys->nb + (mode.block_bytes - 4.0) * sys->n_unique +
            4.0 * (4.0 * lanes * sizeof(double2)) * (double)sys->nb;
@@ -765,7 +810,19 @@ int sweep_depth_for(const bdg_system* sys, int lanes) {
 // 466 / 388 / 271 k against 447 / 319 / 240 k; profiles/r03_lanes_midsize.log).  `whole_call`: n_active counts the
 // call, which batch_width then cuts; a batch (begin) takes the lanes that hold it.
 int sweep_lanes_for(const bdg_system* sys, int n_active, int per_lane, bool unit_start = false, bool whole_call = false) {
-    if (sys->onsite_streamed) return 4;  // 16 site slots per wave: the ring of on-site records fits beside the rows
+    if (sys->onsite_streamed) {
+        // real arithmetic, on-site records: 2 lanes per site (32-slot windows, 19 % halo instead of 38 %; two lane groups
+        // of 4 vectors side by side: 100.4 against 94.5 k vector-steps/s on 1000 x 1000) while the bond table leaves room
+        // for two workgroups per CU; complex arithmetic keeps 4 lanes (the 2-lane form needs one workgroup of seven
+        // waves per CU for its ring: 40.1 against 41.9 k), and so do the site records (bond blocks too)
+        const ModeInfo mode = mode_info(per_lane == 2, true);
+        int lanes = mode.real && !sys->bonds_streamed && streamed_waves_for(sys, mode, 2) == 4 ? 2 : 4;
+        if (const char* env = knob::raw("BODGE_AMD_SWEEP_LANES")) {
+            const int forced = atoi(env);
+            if ((forced == 2 || forced == 4) && streamed_waves_for(sys, mode, forced) != 0) lanes = forced;
+        }
+        return lanes;
+    }
     if (const char* env = knob::raw("BODGE_AMD_SWEEP_LANES")) {
         const int forced = atoi(env);
         if (forced == 1 || forced == 2 || forced == 4) return forced;

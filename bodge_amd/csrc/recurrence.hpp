@@ -110,7 +110,6 @@ struct Batch {
         // wide arithmetic mode can exceed that: it takes the one-step kernels, which then stream its blocks)
         if ((size_t)sys->n_unique * mode.stride * sizeof(double2) > table_limit(sys)) stencil_kind = 0;
         if (sys->onsite_streamed && !mode.ph) stencil_kind = 0;  // (packed on-site records assume the Nambu form)
-        if (sys->bonds_streamed && !mode.real) stencil_kind = 0;  // (bond records exist in real arithmetic only: Z4 vectors take the one-step kernels)
         if (stencil_kind != 0 && start.kind == StartKind::Unit &&
             !(start.stencil >= 0 ? start.stencil != 0 : unit_run_wants_stencil(sys, start.rows, n_active, n_steps)))
             stencil_kind = 0;
@@ -592,7 +591,7 @@ struct Batch {
         bytes_moved += (sweep_bytes(sys, mode, rl) -
                         vector_bytes() * ((n == 0 ? 1 : 0) + (n == 0 && gen_start ? 1 : 0) + (a.discard ? 2 : now == 1 ? 1 : 0))) *
                        ((double)(a.x_hi - a.x_lo) / a.lx);
-        kernel<<<splan.grid, bdg::kSweepThreads, splan.lds_bytes, st>>>(a);
+        kernel<<<splan.grid, splan.wg_waves * bdg::kWave, splan.lds_bytes, st>>>(a);
         ++n_launches;
         double2* old_cur = cur;
         double2* old_prev = prev;

@@ -144,16 +144,18 @@ __global__ void build_stencil(const int* __restrict__ indptr, const int* __restr
     }
 }
 
-// Per-site records of a matrix whose bond blocks are streamed too (real, bond blocks diagonal as 4x4 matrices):
-// eight 16-byte slots per block row - the packed on-site block of RealPHMode::mac_onsite (slots 0..3), then
-// (A00, A11) of the blocks at the stencil offsets -P, -1, +1, +P (slots 4..7; zeros where not stored), found
-// by the rule of build_stencil (wrap-around blocks of periodic lattices included).
+// Per-site records of a matrix whose bond blocks are streamed too (bond blocks diagonal as 4x4 matrices of the Nambu
+// form diag(a, b, -conj a, -conj b)): the packed on-site block of Mode::mac_onsite, then (A00, A11) of the blocks at
+// the stencil offsets -P, -1, +1, +P (zeros where not stored), found by the rule of build_stencil (wrap-around blocks
+// of periodic lattices included).
+//   real_out:  8 slots of 16 bytes - on-site slots 0..3, one slot (A00, A11) per bond                     (128 B per site)
+//   otherwise: 14 slots - on-site slots 0..5, two slots A00, A11 per bond (Peierls phases, complex hopping)  (224 B per site)
 __global__ void pack_site_records(const int* __restrict__ indptr, const int* __restrict__ indices,
-                                  const double2* __restrict__ blocks, int nb, int plane, double2* __restrict__ out) {
+                                  const double2* __restrict__ blocks, int nb, int plane, int real_out, double2* __restrict__ out) {
     const int lx = nb / plane;
     for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nb; i += gridDim.x * blockDim.x) {
         const double2 zero = make_double2(0.0, 0.0);
-        double2 rec[8] = {zero, zero, zero, zero, zero, zero, zero, zero};
+        double2 rec[14] = {zero, zero, zero, zero, zero, zero, zero, zero, zero, zero, zero, zero, zero, zero};
         const int p = i % plane, x = i / plane;
         for (int k = indptr[i]; k < indptr[i + 1]; ++k) {
             const double2* blk = blocks + (size_t)k * 16;
@@ -168,17 +170,25 @@ __global__ void pack_site_records(const int* __restrict__ indptr, const int* __r
             else if (off == -(plane - 1) && p == plane - 1) slot = 3;
             else if (off == (lx - 1) * plane && x == 0) slot = 0;
             else if (off == -(lx - 1) * plane && x == lx - 1) slot = 4;
-            if (slot == 2) {
+            const int bond = slot < 2 ? slot : slot - 1;
+            if (slot == 2 && real_out) {
                 rec[0] = make_double2(blk[0].x, blk[1].x);
                 rec[1] = make_double2(blk[5].x, 0.0);
                 rec[2] = make_double2(blk[2].x, blk[3].x);
                 rec[3] = make_double2(blk[6].x, blk[7].x);
+            } else if (slot == 2) {  // (pack_onsite's complex record)
+                rec[0] = make_double2(blk[0].x, blk[5].x);
+                rec[1] = blk[1];
+                rec[2] = blk[2], rec[3] = blk[3], rec[4] = blk[6], rec[5] = blk[7];
+            } else if (slot >= 0 && real_out) {
+                rec[4 + bond] = make_double2(blk[0].x, blk[5].x);
             } else if (slot >= 0) {
-                rec[4 + (slot < 2 ? slot : slot - 1)] = make_double2(blk[0].x, blk[5].x);
+                rec[6 + 2 * bond] = blk[0];
+                rec[7 + 2 * bond] = blk[5];
             }
         }
-#pragma unroll
-        for (int e = 0; e < 8; ++e) out[(size_t)i * 8 + e] = rec[e];
+        const int slots = real_out ? 8 : 14;
+        for (int e = 0; e < slots; ++e) out[(size_t)i * slots + e] = rec[e];
     }
 }
 
@@ -440,6 +450,12 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
 #ifndef BDG_COMPACT_DIAG
 #define BDG_COMPACT_DIAG 1  // (0: A/B builds that read diagonal blocks from the full table entries)
 #endif
+#ifndef BDG_OS_EXPERIMENT
+#define BDG_OS_EXPERIMENT 0
+#endif
+#ifndef BDG_COMPLEX_ONSITE_STRIDE
+#define BDG_COMPLEX_ONSITE_STRIDE 6  // (7 = ComplexPHMode::kOnsiteStride, the padded stride of round 3, for A/B builds)
+#endif
 constexpr int kSweep3Owned = kSweepSlots - 6;  // 10 owned positions per wave window (4 lanes per site)
 constexpr int sweep3_owned(int rl) { return kWave / rl - 6; }
 
@@ -462,15 +478,19 @@ constexpr int sweep3_owned(int rl) { return kWave / rl - 6; }
 // block plus (A00, A11) of its four bond blocks, 8 slots = 128 B (pack_site_records), no table at all.
 template <typename Mode, int OS>
 constexpr int sweep3_record_slots() {
-    if constexpr (OS == 2) return 8;
+    if constexpr (OS == 2) return Mode::kOnsiteSlots + 4 * Mode::kBondSlots;
     else if constexpr (OS == 1) return Mode::kOnsiteSlots;
     else return 0;
 }
+// LDS stride of a site's record in 16-byte slots: such that the sites a 16-byte read of the wave touches together fall
+// on different banks (real: 4 / 8 slots would put every fourth / second site on the same banks - one slot of padding;
+// complex: 6 and 14 slots are 24 and 56 banks, whose multiples do not collide within eight sites - no padding, which is
+// what lets the ring of a 32-slot window fit)
 template <typename Mode, int OS>
 constexpr int sweep3_record_stride() {
-    if constexpr (OS == 2) return 9;
-    else if constexpr (OS == 1) return Mode::kOnsiteStride;
-    else return 0;
+    if constexpr (OS == 0) return 0;
+    else if constexpr (Mode::kVec == 2) return sweep3_record_slots<Mode, OS>() + 1;
+    else return OS == 2 ? sweep3_record_slots<Mode, OS>() : BDG_COMPLEX_ONSITE_STRIDE;
 }
 template <typename Mode, int OS>
 constexpr int sweep3_ring_slots(int slots) {
@@ -493,8 +513,27 @@ struct Sweep3Lds {
 };
 
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int sweep_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kRawBufferFlags = 0x00020000;  // raw buffer resource of gfx9 / CDNA: 32-bit data format, no swizzle
 constexpr int kAuxSc1 = 16;                  // cache-policy bits of the raw buffer builtins: sc1 = write-through
+constexpr int kAuxNt = 2;                    // ... nt = non-temporal (what __builtin_nontemporal_load / _store set)
+
+// Buffer addressing (BUF): every global access of a unit goes through a raw buffer instruction whose descriptor is the
+// plane it touches - base = buffer + (component * rows + plane * P) * RL * 16 bytes, made from wave-uniform values in
+// scalar registers - and whose per-lane offset is (position * RL + r) * 16: ONE 32-bit register for the whole unit,
+// where flat addressing keeps a 64-bit address per component and buffer.  The compiler hoisted those out of the plane
+// loop and, at the 256-register limit of the streamed forms, parked them in scratch: every reload then waits with
+// s_waitcnt vmcnt(0), i.e. for every prefetched plane in flight - the record loads of the complex streamed form cost
+// 0.10 of its 0.37 ms that way (profiles/r04_onsite_ab.log).  Used by the forms that spilled (complex streamed forms, 2-lane
+// streamed forms).
+#ifndef BDG_SWEEP_BUFFER_OPS
+#define BDG_SWEEP_BUFFER_OPS 0  // 1: in every form (A/B builds)
+#endif
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t sweep_plane_rsrc(const void* buf, size_t byte_offset, int bytes) {
+    const uint64_t base = reinterpret_cast<uint64_t>(buf) + byte_offset;
+    const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)base), hi = __builtin_amdgcn_readfirstlane((uint32_t)(base >> 32));
+    return __builtin_amdgcn_make_buffer_rsrc(reinterpret_cast<void*>(((uint64_t)hi << 32) | lo), 0, bytes, kRawBufferFlags);
+}
 
 // Lane state of the generated start block (GEN): the lane's vector(s) - real modes carry vectors 2r, 2r+1 in
 // (x, y), complex modes vector r.
@@ -566,9 +605,29 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
     auto act = [&](int k) { return rev ? x0 + x1 - 1 - k : k; };
     auto ring = [&](int k) { return a.wrap_x ? (k < 0 ? k + a.lx : (k >= a.lx ? k - a.lx : k)) : k; };
     auto in_lattice = [&](int k) { return a.wrap_x || (act(k) >= 0 && act(k) < a.lx); };
+    // (where flat addressing does not spill it is 2-7 % faster - fewer scalar instructions per access: the dictionary forms
+    // and the real 4-lane streamed forms keep it)
+    constexpr bool BUF = (OS != 0 && (Mode::kVec == 1 || RL == 2)) || BDG_SWEEP_BUFFER_OPS;
+    const int plane_bytes = a.plane * RL * (int)sizeof(double2);
+    const int lane_bytes = (pw * RL + r) * (int)sizeof(double2);  // (stores: owned lanes only, where p == pw)
     auto load_plane = [&](const double2* buf, bool nt, int k, bool wanted, double2 out[4]) {
         k = ring(act(k));
-        if (wanted && k >= 0 && k < a.lx) {
+        if constexpr (BUF) {
+#pragma unroll
+            for (int al = 0; al < 4; ++al) out[al] = zero;
+            if (k >= 0 && k < a.lx) {  // (uniform)
+                __amdgpu_buffer_rsrc_t rsrc[4];
+#pragma unroll
+                for (int al = 0; al < 4; ++al)
+                    rsrc[al] = sweep_plane_rsrc(buf, ((size_t)al * nb + (size_t)k * a.plane) * RL * sizeof(double2), plane_bytes);
+                if (wanted) {
+#pragma unroll
+                    for (int al = 0; al < 4; ++al)
+                        out[al] = __builtin_bit_cast(double2, nt ? __builtin_amdgcn_raw_buffer_load_b128(rsrc[al], lane_bytes, 0, kAuxNt)
+                                                                 : __builtin_amdgcn_raw_buffer_load_b128(rsrc[al], lane_bytes, 0, 0));
+                }
+            }
+        } else if (wanted && k >= 0 && k < a.lx) {
             const size_t site = (size_t)k * a.plane + pw;
 #pragma unroll
             for (int al = 0; al < 4; ++al)
@@ -589,6 +648,13 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
             for (int al = 0; al < 4; ++al)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[al]), rsrc,
                                                        (int)(vslot(al, site, r, nb, RL) * sizeof(double2)), 0, kAuxSc1);
+        } else if constexpr (BUF) {
+#pragma unroll
+            for (int al = 0; al < 4; ++al) {
+                const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(buf, ((size_t)al * nb + (size_t)act(k) * a.plane) * RL * sizeof(double2), plane_bytes);
+                if (nt_store) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[al]), rsrc, lane_bytes, 0, kAuxNt);
+                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[al]), rsrc, lane_bytes, 0, 0);
+            }
         } else {
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
@@ -623,7 +689,14 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
     auto load_ids = [&](int k) {
         uint2 w = make_uint2(0xFFFFFFFFu, 0xFFu);
         k = ring(act(k));
-        if (ok1 && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + pw];
+        if constexpr (BUF) {
+            if (k >= 0 && k < a.lx) {  // (uniform)
+                const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(a.stencil, (size_t)k * a.plane * sizeof(uint2), a.plane * (int)sizeof(uint2));
+                if (ok1) w = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, pw * (int)sizeof(uint2), 0, 0));
+            }
+        } else if (ok1 && k >= 0 && k < a.lx) {
+            w = a.stencil[(size_t)k * a.plane + pw];
+        }
         return w;
     };
     auto id_of = [](uint2 w, int slot) { return slot < 4 ? (w.x >> (8 * slot)) & 0xFFu : w.y & 0xFFu; };
@@ -665,7 +738,7 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
         // one bond block times the neighbour's entries: from the table, or (OS = 2) from the site's record
         auto bond = [&](int slot, const double2 v[4]) {
             if constexpr (OS == 2) {
-                if (id_of(w, slot) != kNoBlock) Mode::mac_bond(acc, rec[4 + (slot < 2 ? slot : slot - 1)], v);
+                if (id_of(w, slot) != kNoBlock) Mode::mac_bond(acc, rec + Mode::kOnsiteSlots + Mode::kBondSlots * (slot < 2 ? slot : slot - 1), v);
             } else {
                 mac(w, slot, v, acc);
             }
@@ -678,7 +751,9 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
             bond(1, x);
         }
         if constexpr (OS != 0) {
+#if !(BDG_OS_EXPERIMENT & 4)
             if (id_of(w, 2) != kNoBlock) Mode::mac_onsite(acc, rec, mid);
+#endif
         } else {
             mac(w, 2, mid, acc);
         }
@@ -708,9 +783,13 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
                 out[j] = zero;
                 // (plain loads: the halo slots of the neighbouring windows read the same records - 16 slots
                 // per 10 owned - and should find them in L2; a.stream bit 3 = non-temporal, for A/B runs)
-                if (wanted && slot < SLOTS && (in_e || a.wrap_p) && k >= 0 && k < a.lx) {
-                    const double2* src = a.onsite + ((size_t)k * a.plane + pwe) * PIECES + part;
-                    out[j] = (a.stream & 8) ? load_stream(src) : *src;
+                if (wanted && k >= 0 && k < a.lx) {  // (uniform)
+                    const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(a.onsite, (size_t)k * a.plane * PIECES * sizeof(double2),
+                                                                         a.plane * PIECES * (int)sizeof(double2));
+                    const int piece_bytes = (pwe * PIECES + part) * (int)sizeof(double2);
+                    if (slot < SLOTS && (in_e || a.wrap_p))
+                        out[j] = __builtin_bit_cast(double2, (a.stream & 8) ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, piece_bytes, 0, kAuxNt)
+                                                                            : __builtin_amdgcn_raw_buffer_load_b128(rsrc, piece_bytes, 0, 0));
                 }
             }
         }
@@ -804,7 +883,11 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
         // (OS) on-site records of plane k+1: asked for here rather than at the top of the iteration - they are
         // not needed before its end, and 4-8 registers held across steps 1 and 2 are 4-8 registers spilled
         [[maybe_unused]] double2 nx_os[OSL];
+#if BDG_OS_EXPERIMENT & 1  // (timing builds: what the record loads / the ring writes / the on-site product cost; results wrong)
+        load_onsite(k + 1, false, nx_os);
+#else
         load_onsite(k + 1, more, nx_os);
+#endif
 
         // ---- step 3 on plane k-2: level 3 = c2 H level2 - level1       (row_2 = level 2, plane k-2)
         if (steps >= 3 && owned && k - 2 >= x0 && k - 2 < x1) {
@@ -830,7 +913,9 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
         wave_sync();
         put_own(row_1, new1);  // level 1, plane k
         put_own(row_2, new2);  // level 2, plane k-1
+#if !(BDG_OS_EXPERIMENT & 2)
         put_onsite(k + 1, nx_os);  // (OS) takes the ring entry of plane k-2, which step 3 has just finished with
+#endif
         ids_2 = ids_1;
         ids_1 = ids_0;
         ids_0 = nx_ids;
@@ -841,7 +926,7 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
     }
 }
 
-template <typename Mode, int OS>
+template <typename Mode, int OS, int THREADS = kBlockThreads>
 __device__ inline Sweep3Lds sweep3_stage_lds(double2* lds, const SweepArgs& a, int slots, int wave) {
     constexpr int SPB = Mode::kSlotsPerBlock;
     constexpr int STRIDE = Mode::kBlockStride;
@@ -849,7 +934,7 @@ __device__ inline Sweep3Lds sweep3_stage_lds(double2* lds, const SweepArgs& a, i
     const int ring = sweep3_ring_slots<Mode, OS>(slots);
     // LDS: [table][compact diagonals][per wave: three rows of 64 lanes x 4 entries; OS: + ring of three planes of on-site blocks]
     const double2* table = static_cast<const double2*>(a.dict_table);
-    for (int e = threadIdx.x; e < a.n_unique * SPB; e += kBlockThreads)
+    for (int e = threadIdx.x; e < a.n_unique * SPB; e += THREADS)
         lds[(e / SPB) * STRIDE + (e % SPB)] = table[e];
     // compact copies of the block diagonals behind the table: a block flagged diagonal (plain hopping: four of the
     // five blocks of a row in the s-wave models) then costs Mode::kDiagSlots 16-byte LDS reads instead of mac_diag's
@@ -862,30 +947,33 @@ __device__ inline Sweep3Lds sweep3_stage_lds(double2* lds, const SweepArgs& a, i
     w.row_2 = w.row_1 + kWave * 4;
     w.os_ring = w.row_2 + kWave * 4;
     __syncthreads();
-    for (int id = threadIdx.x; id < a.n_unique; id += kBlockThreads) Mode::pack_diag(w.diag + id * DSL, lds + id * STRIDE);
+    for (int id = threadIdx.x; id < a.n_unique; id += THREADS) Mode::pack_diag(w.diag + id * DSL, lds + id * STRIDE);
     __syncthreads();
     return w;
 }
 
-template <typename Mode, int RL, bool REV, bool GEN = false, int OS = 0>
-__global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
+// WAVES: waves per workgroup.  4 with two workgroups per CU is the default; the streamed forms whose ring of records
+// leaves room for fewer than eight waves on a CU run ONE workgroup of 5..7 waves per CU instead (160 KB of LDS: seven
+// waves of 12 KB rows + a ring of up to 10.5 KB), which keeps 2 lanes per site (32-slot windows) within reach.
+template <typename Mode, int RL, bool REV, bool GEN = false, int OS = 0, int WAVES = kWavesPerBlock>
+__global__ __launch_bounds__(WAVES * kWave, WAVES > 4 ? 1 : 2) void cheb_sweep3(SweepArgs a) {
     extern __shared__ double2 lds[];
     const int lane = threadIdx.x & (kWave - 1);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x / kWave);
-    const Sweep3Lds w = sweep3_stage_lds<Mode, OS>(lds, a, kWave / RL, wave);
+    const Sweep3Lds w = sweep3_stage_lds<Mode, OS, WAVES * kWave>(lds, a, kWave / RL, wave);
 
     const int n_units = a.n_cols * a.n_segs;
     const int xcd = blockIdx.x & 7;
     const int u_lo = (int)(((int64_t)n_units * xcd) >> 3);
     const int u_hi = (int)(((int64_t)n_units * (xcd + 1)) >> 3);
-    const int waves_per_xcd = (gridDim.x >> 3) * kWavesPerBlock;
+    const int waves_per_xcd = (gridDim.x >> 3) * WAVES;
 
     double dot1[4] = {0.0, 0.0, 0.0, 0.0}, dot2[4] = {0.0, 0.0, 0.0, 0.0}, dot3[4] = {0.0, 0.0, 0.0, 0.0};
     Sweep3Gen gen;
     if constexpr (GEN) gen = sweep3_gen_keys<Mode>(a.gen_seed, a.gen_first_id, a.gen_active, lane % RL);
 
     const Sweep3Task task{a.cur, a.prev, a.out1, a.out2, a.coef1, a.steps, a.discard};
-    for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
+    for (int u = u_lo + (int)(blockIdx.x >> 3) * WAVES + wave; u < u_hi; u += waves_per_xcd) {
         const int seg = u / a.n_cols, col = u - seg * a.n_cols;
         const bool rev = REV != (bool)(a.zigzag & seg & 1);  // wave-uniform
         sweep3_unit<Mode, RL, GEN, OS, false>(a, task, w, gen, lane, seg, col, rev, dot1, dot2, dot3);
@@ -893,14 +981,14 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_sweep3(SweepArgs a) {
 
     const int steps = a.steps;
     __syncthreads();
-    sweep_reduce_dots<Mode, RL, kWavesPerBlock>(dot1, reinterpret_cast<double*>(lds), a.partial1, lane, wave);
+    sweep_reduce_dots<Mode, RL, WAVES>(dot1, reinterpret_cast<double*>(lds), a.partial1, lane, wave);
     if (steps >= 2) {
         __syncthreads();
-        sweep_reduce_dots<Mode, RL, kWavesPerBlock>(dot2, reinterpret_cast<double*>(lds), a.partial2, lane, wave);
+        sweep_reduce_dots<Mode, RL, WAVES>(dot2, reinterpret_cast<double*>(lds), a.partial2, lane, wave);
     }
     if (steps >= 3) {
         __syncthreads();
-        sweep_reduce_dots<Mode, RL, kWavesPerBlock>(dot3, reinterpret_cast<double*>(lds), a.partial3, lane, wave);
+        sweep_reduce_dots<Mode, RL, WAVES>(dot3, reinterpret_cast<double*>(lds), a.partial3, lane, wave);
     }
 }
 

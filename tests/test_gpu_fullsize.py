@@ -367,7 +367,7 @@ def test_complex_hamiltonian_full_length_at_full_size(api, hip_library):
             assert abs(f_gpu - f_ref) <= 1e-10 * abs(f_ref), env
 
 
-@pytest.mark.parametrize("kind", ["potential", "texture", "ssd"])
+@pytest.mark.parametrize("kind", ["potential", "texture", "ssd", "landau"])
 def test_position_dependent_onsite_terms_full_length_at_full_size(api, hip_library, kind):
     """1000 x 1000 with a different on-site block at every site (10^6 distinct blocks - no dictionary),
     M = 512: the three-step sweep that streams the on-site blocks (cheb_sweep3 OS, sweep.hpp) against
@@ -376,7 +376,9 @@ def test_position_dependent_onsite_terms_full_length_at_full_size(api, hip_libra
     gap amplitude, real arithmetic, 8 Rademacher vectors; "texture": an exchange field whose direction
     varies from site to site (σ1, σ2, σ3 components: complex blocks), 4 Z4 vectors; "ssd": every term -
     hopping included - scaled by the reference's sine-squared envelope (ref hamiltonian.py:488-531):
-    the bond blocks are streamed as well (cheb_sweep3 OS = 2)."""
+    the bond blocks are streamed as well (cheb_sweep3 OS = 2); "landau" (round 4): the texture model in a magnetic
+    field - Peierls phases exp(±i B y) of the Landau gauge on the x bonds, 2000 distinct complex bond blocks: complex
+    site records (224 B per site), 4 Z4 vectors."""
     from bodge_amd import chebyshev
     from bodge_amd.solver import DeviceSolver
     from oracle import cheb_c
@@ -401,12 +403,18 @@ def test_position_dependent_onsite_terms_full_length_at_full_size(api, hip_libra
             th, ph = rng.uniform(0, np.pi, sites)[:, None, None], rng.uniform(0, 2 * np.pi, sites)[:, None, None]
             H.set_sites(3.0 * api.σ0 - 0.3 * (np.sin(th) * np.cos(ph) * api.σ1 + np.sin(th) * np.sin(ph) * api.σ2 + np.cos(th) * api.σ3))
             Δ.set_sites(-0.1 * api.jσ2)
-        if kind != "ssd":
+        if kind == "landau":
+            pairs = lattice.bond_array(axis=0, coords=True)  # directed x bonds: a phase one way, its conjugate back
+            flux = 0.0123 * pairs[:, 0, 1]
+            phase = np.exp(1j * np.where(pairs[:, 1, 0] > pairs[:, 0, 0], flux, -flux))
+            H.set_bonds(-phase[:, None, None] * api.σ0, axis=0)
+            H.set_bonds(-1.0 * api.σ0, axis=1)
+        elif kind != "ssd":
             H.set_bonds(-1.0 * api.σ0)
     indptr, indices, data = system.bsr_arrays()
     scale = chebyshev.spectral_bound(indptr, data)
     bsr = system.matrix("bsr")
-    real = kind != "texture"
+    real = kind not in ("texture", "landau")
     assert (np.abs(data.imag).max() == 0) == real
     n, moments, temperature = bsr.shape[0], 512, 0.5
     vectors, vec_kind = (8, cheb_ref.VEC_RADEMACHER) if real else (4, cheb_ref.VEC_Z4)
@@ -419,9 +427,13 @@ def test_position_dependent_onsite_terms_full_length_at_full_size(api, hip_libra
     with DeviceSolver(indptr, indices, data) as solver:
         solver.set_lattice_shape(lattice.shape)
         (d, e), perf = _with_env(solver, {}, scale, moments // 2, vectors, seed=4, kind=vec_kind)
-        assert perf["onsite_streamed"] == (2 if kind == "ssd" else 1) and perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == 4, perf
+        bonds_too = kind in ("ssd", "landau")
+        assert perf["onsite_streamed"] == (2 if bonds_too else 1) and perf["steps_per_launch"] == 3, perf
+        two_lanes = kind == "potential"  # (real on-site records: 32-slot windows since round 4, two lane groups of 4 vectors)
+        assert perf["lanes_per_row"] == (2 if two_lanes else 4), perf
         assert perf["real_arithmetic"] == (1 if real else 0) and perf["dict_blocks"] == 1 and perf["dict_skipped"] == 1
-        assert perf["launches"] == 4 * 21 + 2  # one lane group: four chunks of 63 steps, then 3 + 1
+        # per lane group four chunks of 63 steps, then 3 + 1
+        assert perf["launches"] == (2 if two_lanes else 1) * (4 * 21 + 2)
         (d1, e1), perf1 = _with_env(solver, {"BODGE_AMD_SWEEP": "0"}, scale, moments // 2, vectors, seed=4, kind=vec_kind)
         assert perf1["onsite_streamed"] == 0 and perf1["steps_per_launch"] == 1 and perf1["dict_blocks"] == 0
     for got_d, got_e in ((d, e), (d1, e1)):

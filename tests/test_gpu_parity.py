@@ -398,19 +398,27 @@ def _position_dependent_system(api, shape, kind, seed=0, periodic=False):
     ((30, 32, 1), "potential", cheb_ref.VEC_RADEMACHER, True),   # torus: halo slots wrap, on-site records fetched per piece
     ((21, 30, 1), "texture", cheb_ref.VEC_Z4, True),
 ])
-def test_three_step_sweep_with_streamed_onsite_blocks(api, solver_cls, knobs, block_storage, shape, kind, vec_kind, periodic):
+@pytest.mark.parametrize("lanes", [2, 4])
+def test_three_step_sweep_with_streamed_onsite_blocks(api, solver_cls, knobs, block_storage, shape, kind, vec_kind, periodic, lanes):
     """cheb_sweep3<..., OS> (sweep.hpp): matrices with more than 256 distinct blocks whose bonds repeat a
     few - the bond blocks sit in the LDS table, the diagonal block of every site is streamed once per
     launch into a three-plane LDS ring.  Every d_n, e_n against the CPU oracle and against the
     one-step (streamed-blocks) kernels on the same vectors; step counts that end a run on 1, 2 and 3
-    steps, partial lane groups, several batches, both marching directions, GEN on and off."""
+    steps, partial lane groups, several batches, both marching directions, GEN on and off.
+    Round 4: with 2 lanes per site (32-slot windows; the default in real arithmetic - in complex arithmetic one workgroup
+    of seven waves per CU, since the ring leaves no room for eight) as well as with 4."""
     system = _position_dependent_system(api, shape, kind, periodic=periodic)
     bsr = system.matrix("bsr")
     scale = cheb_ref.spectral_bound(bsr)
     n = bsr.shape[0]
     complex_run = vec_kind == cheb_ref.VEC_Z4 or kind == "texture"
-    per_group = 4 if complex_run else 8
+    per_group = lanes * (1 if complex_run else 2)
     with solver_cls.from_hamiltonian(system) as dev:
+        if block_storage == "dictionary" and lanes == 2:  # the default: 2 lanes in real arithmetic, 4 in complex
+            knobs.set("BODGE_AMD_SWEEP", "1")
+            dev.dots_random(scale, 3, 2, seed=5, kind=vec_kind)
+            assert dev.perf()["onsite_streamed"] == 1 and dev.perf()["lanes_per_row"] == (4 if complex_run else 2), dev.perf()
+        knobs.set("BODGE_AMD_SWEEP_LANES", str(lanes))
         for steps, vectors, extra in [(9, per_group, {}), (7, 3, {}), (8, per_group + 3, {"BODGE_AMD_SWEEP_ZIGZAG": "0"}),
                                       (6, 2, {"BODGE_AMD_ALTERNATE": "0", "BODGE_AMD_SWEEP_SEGMENTS": "3"}),
                                       (9, per_group, {"BODGE_AMD_SWEEP_GEN": "0"}),
@@ -428,7 +436,7 @@ def test_three_step_sweep_with_streamed_onsite_blocks(api, solver_cls, knobs, bl
             for key in extra:
                 knobs.unset(key)
             if block_storage == "dictionary":
-                assert perf["onsite_streamed"] == 1 and perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == 4, perf
+                assert perf["onsite_streamed"] == 1 and perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == lanes, perf
                 assert 0 < perf["dict_blocks"] <= 16 and perf["real_arithmetic"] == (0 if complex_run else 1)
                 assert perf["launches"] == -(-vectors // per_group) * -(-steps // 3)
             else:  # BODGE_AMD_DICT=0: no dictionary of any kind, one step per launch
@@ -471,6 +479,8 @@ def test_sweeps_of_a_chunk_in_one_launch_match_one_launch_per_sweep(api, solver_
     complex_run = vec_kind == cheb_ref.VEC_Z4 or kind in ("peierls", "texture")
     per_group = 4 if complex_run else 8
     knobs.set("BODGE_AMD_SWEEP", "1")
+    if kind in ("potential", "texture", "ssd"):
+        knobs.set("BODGE_AMD_SWEEP_LANES", "4")  # (the chunk kernel exists for the 4-lane streamed forms only)
     with solver_cls.from_hamiltonian(system) as dev:
         for steps, vectors, extra in [(9, per_group, {}), (70, 2 * per_group, {}), (8, 3, {}), (64, per_group + 1, {"BODGE_AMD_SWEEP_SEGMENTS": "3"}),
                                       (13, 5 * per_group, {}), (7, 2 * per_group, {"BODGE_AMD_SWEEP_GEN": "0"}),
@@ -530,7 +540,8 @@ def test_a_persistent_launch_that_gives_up_waiting_is_repeated_sweep_by_sweep(ap
 def _ssd_system(api, shape, kind, seed=0):
     """Every term of the s-wave model scaled by a position-dependent factor: "ssd" = the reference's sine-squared
     deformation (ref hamiltonian.py:488-531: φ at the site for on-site terms, at the bond midpoint for hopping),
-    "bond_disorder" = random hopping amplitudes and spin splitting on every bond, "ssd_dwave" = ssd on a model with
+    "bond_disorder" = random hopping amplitudes and spin splitting on every bond, "bond_phases" = the same with a Peierls phase on
+    every bond and an exchange field of random direction on every site (complex blocks), "ssd_dwave" = ssd on a model with
     pairing on the bonds (bond blocks no longer diagonal)."""
     lattice = api.CubicLattice(shape)
     system = api.Hamiltonian(lattice)
@@ -552,26 +563,36 @@ def _ssd_system(api, shape, kind, seed=0):
             lo, hi = idx.min(axis=1), idx.max(axis=1)  # the same amplitude both ways
             t = (0.8 + 0.4 * ((lo * 7919 + hi * 104729) % 1009) / 1009.0)[:, None, None]
             dt = (0.1 * ((lo * 31 + hi * 17) % 101) / 101.0)[:, None, None]
-            H.set_sites((3.0 + rng.uniform(-0.5, 0.5, lattice.size))[:, None, None] * api.σ0)
+            if kind == "bond_phases":  # a Peierls phase of its own on every bond: a phase one way, its conjugate back
+                θ = 2 * np.pi * ((lo * 271 + hi * 65537) % 997) / 997.0
+                t = t * np.exp(1j * np.where(idx[:, 1] > idx[:, 0], θ, -θ))[:, None, None]
+                th, ph = rng.uniform(0, np.pi, lattice.size)[:, None, None], rng.uniform(0, 2 * np.pi, lattice.size)[:, None, None]
+                H.set_sites(3.0 * api.σ0 - 0.3 * (np.sin(th) * np.cos(ph) * api.σ1 + np.sin(th) * np.sin(ph) * api.σ2 + np.cos(th) * api.σ3))
+            else:
+                H.set_sites((3.0 + rng.uniform(-0.5, 0.5, lattice.size))[:, None, None] * api.σ0)
             Δ.set_sites(-0.1 * api.jσ2)
             H.set_bonds(-t * api.σ0 + dt * api.σ3)
     return system
 
 
-@pytest.mark.parametrize("shape,kind", [((48, 50, 1), "ssd"), ((33, 61, 1), "bond_disorder"), ((30, 1, 44), "ssd")])
+@pytest.mark.parametrize("shape,kind", [((48, 50, 1), "ssd"), ((33, 61, 1), "bond_disorder"), ((30, 1, 44), "ssd"),
+                                        ((33, 61, 1), "bond_phases"), ((40, 1, 30), "bond_phases")])
 def test_three_step_sweep_with_streamed_bond_blocks(api, solver_cls, knobs, block_storage, shape, kind):
-    """cheb_sweep3<RealPHMode, 4, ., ., OS = 2>: matrices in which the BOND blocks differ from bond to bond as well - what the
-    reference's `ssd()` makes of a model - as long as they are real and diagonal as 4x4 matrices (spin-diagonal hopping, no
-    bond pairing).  No table: every site streams a 128-byte record (on-site block + its four bond blocks).  Against the oracle
-    and the one-step kernels; complex start vectors (no real arithmetic) and bond pairing must fall back by themselves."""
+    """cheb_sweep3<., 4, ., ., OS = 2>: matrices in which the BOND blocks differ from bond to bond as well - what the
+    reference's `ssd()` makes of a model, bond disorder, the Peierls phases of a position-dependent gauge - as long as they are
+    diagonal as 4x4 matrices (spin-diagonal hopping, no bond pairing).  No table: every site streams one record (on-site block
+    + its four bond blocks: 128 bytes in real arithmetic, 224 in complex - round 4).  Against the oracle and the one-step
+    kernels; complex start vectors on a real matrix take the complex records; bond pairing must fall back by itself."""
     system = _ssd_system(api, shape, kind)
     bsr = system.matrix("bsr")
     scale = cheb_ref.spectral_bound(bsr)
     n = bsr.shape[0]
+    complex_matrix = kind == "bond_phases"
+    per_group = 4 if complex_matrix else 8
     with solver_cls.from_hamiltonian(system) as dev:
-        for steps, vectors, extra in [(9, 8, {}), (7, 3, {}), (8, 11, {"BODGE_AMD_SWEEP_ZIGZAG": "0"}),
+        for steps, vectors, extra in [(9, per_group, {}), (7, 3, {}), (8, per_group + 3, {"BODGE_AMD_SWEEP_ZIGZAG": "0"}),
                                       (6, 2, {"BODGE_AMD_ALTERNATE": "0", "BODGE_AMD_SWEEP_SEGMENTS": "3"}),
-                                      (9, 8, {"BODGE_AMD_SWEEP_GEN": "0"}), (1, 3, {}), (2, 8, {})]:
+                                      (9, per_group, {"BODGE_AMD_SWEEP_GEN": "0"}), (1, 3, {}), (2, per_group, {})]:
             ref = cheb_ref.recurrence_dots(bsr, scale, 2 * steps, cheb_ref.random_block(n, 5, range(vectors)))
             knobs.set("BODGE_AMD_SWEEP", "0")
             one = dev.dots_random(scale, steps, vectors, seed=5)
@@ -585,18 +606,21 @@ def test_three_step_sweep_with_streamed_bond_blocks(api, solver_cls, knobs, bloc
                 knobs.unset(key)
             if block_storage == "dictionary":
                 # (the envelope is symmetric: on a small lattice its bond blocks may still number <= 254 and fit a table)
-                assert perf["onsite_streamed"] in ((2,) if kind == "bond_disorder" or shape == (48, 50, 1) else (1, 2)), perf
-                assert perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == 4, perf
-                assert perf["real_arithmetic"] == 1 and perf["launches"] == -(-vectors // 8) * -(-steps // 3)
+                assert perf["onsite_streamed"] in ((2,) if kind != "ssd" or shape == (48, 50, 1) else (1, 2)), perf
+                assert perf["steps_per_launch"] == 3 and perf["lanes_per_row"] == (4 if perf["onsite_streamed"] == 2 else 2), perf
+                assert perf["real_arithmetic"] == (0 if complex_matrix else 1)
+                if perf["onsite_streamed"] == 2:
+                    assert perf["launches"] == -(-vectors // per_group) * -(-steps // 3)
             else:
                 assert perf["onsite_streamed"] == 0 and perf["steps_per_launch"] == 1
             assert np.array_equal(got[0], again[0]) and np.array_equal(got[1], again[1])
             for other in (ref, one):
                 assert np.abs(got[0] - other[0]).max() <= 1e-12 * n and np.abs(got[1] - other[1]).max() <= 1e-12 * n
-        # complex start vectors: the records exist in real arithmetic only
+        # complex start vectors: the complex records (round 3: one step per launch)
         ref = cheb_ref.recurrence_dots(bsr, scale, 12, cheb_ref.random_block(n, 5, range(3), cheb_ref.VEC_Z4))
         got = dev.dots_random(scale, 6, 3, seed=5, kind=cheb_ref.VEC_Z4)
-        assert dev.perf()["steps_per_launch"] == 1 and dev.perf()["real_arithmetic"] == 0
+        perf = dev.perf()
+        assert perf["real_arithmetic"] == 0 and perf["steps_per_launch"] == (3 if block_storage == "dictionary" else 1), perf
         assert np.abs(got[0] - ref[0]).max() <= 1e-12 * n and np.abs(got[1] - ref[1]).max() <= 1e-12 * n
     # pairing on the bonds: the bond blocks are not diagonal, every block is distinct - one step per launch
     other = _ssd_system(api, (24, 30, 1), "ssd_dwave")
@@ -1486,6 +1510,7 @@ def test_eigenvalues_by_tridiagonalisation_match_the_reference(api, golden, knob
     ("chain300", {"BODGE_AMD_EIGH_STAGES": "2"}),                                         # n = 1200, a chain: panels of few non-zeros
     ("dwave8", {"BODGE_AMD_EIGH_STAGES": "2"}),                                           # zero modes, 3-D
     ("swave50_zeeman", {}),                                                               # n = 10^4: the default route
+    ("swave60_zeeman", {}),                                                               # n = 14 400 (golden recorded in round 4)
 ])
 def test_eigenvalues_by_the_two_stage_route_match_the_reference(api, golden, knobs, block_storage, name, options):
     """K10 (csrc/twostage.hpp): real symmetric matrix -> band of half-width 32 by block Householder panels (Gram-matrix QR,
@@ -1512,7 +1537,7 @@ def test_eigenvalues_by_the_two_stage_route_match_the_reference(api, golden, kno
             assert abs(value - golden.free_energy(name, temperature)) <= 1e-10 * abs(value)
 
 
-@pytest.mark.parametrize("name", ["swave30_zeeman", "peierls30", "chain300", "swave50_zeeman", "dwave8", "snf"])
+@pytest.mark.parametrize("name", ["swave30_zeeman", "peierls30", "chain300", "swave50_zeeman", "swave60_zeeman", "dwave8", "snf"])
 def test_dense_ladder_without_a_library(api, golden, block_storage, name):
     """BASELINE config 5's feasible ladder through the DEFAULT route of `diagonalize()` - the library's own
     Householder tridiagonalisation, bisection, inverse iteration and back-transformation (csrc/tridiag.hpp),

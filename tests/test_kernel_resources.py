@@ -55,7 +55,7 @@ def test_sweep_kernels_fit_two_waves_per_simd_without_spilling(resources):
                 assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, reverse, row)
             for lanes in (2, 4):
                 for gen in ("false", "true") if reverse == "false" else ("false",):  # (GEN: start block made in registers)
-                    row = _row(resources, f"cheb_sweep3<bdg::{mode}, {lanes}, {reverse}, {gen}, 0>")
+                    row = _row(resources, f"cheb_sweep3<bdg::{mode}, {lanes}, {reverse}, {gen}, 0, 4>")
                     assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, reverse, gen, row)
         for lanes in (2, 4):
             row = _row(resources, f"cheb_roll3<bdg::{mode}, {lanes}>")
@@ -64,17 +64,16 @@ def test_sweep_kernels_fit_two_waves_per_simd_without_spilling(resources):
 
 @pytest.mark.timeout(600)
 def test_streamed_onsite_sweep_keeps_two_waves_per_simd(resources):
-    """cheb_sweep3<..., OS> carries the prefetched on-site records on top of K7b's state.  It must keep
-    two waves per SIMD; the register allocator parks a few loop-invariant values in scratch (real: 12 B
-    touched in the prologue only, complex: 64 B with four reloads per iteration - measured harmless
-    next to ~30 global loads per iteration), and that must not grow unnoticed."""
-    for mode, limit in (("RealPHMode", 24), ("ComplexPHMode", 64)):
+    """cheb_sweep3<..., OS, WAVES> carries the prefetched records on top of K7b's state.  It must keep two waves per SIMD;
+    the register allocator parks a few loop-invariant values in scratch (measured harmless next to ~30 global loads per
+    iteration), and that must not grow unnoticed.  Round 4: the forms with 2 lanes per site (three record pieces per lane in
+    flight instead of two) and the complex site records, in workgroups of seven waves (one per CU)."""
+    forms = [("RealPHMode", 4, 1, 4, 24), ("ComplexPHMode", 4, 1, 4, 64), ("RealPHMode", 4, 2, 4, 0),
+             ("RealPHMode", 2, 1, 4, 48), ("RealPHMode", 2, 1, 7, 48), ("ComplexPHMode", 2, 1, 7, 112), ("ComplexPHMode", 4, 2, 7, 32)]
+    for mode, lanes, streamed, waves, limit in forms:
         for reverse, gen in (("false", "false"), ("true", "false"), ("false", "true")):
-            row = _row(resources, f"cheb_sweep3<bdg::{mode}, 4, {reverse}, {gen}, 1>")
-            assert row["scratch"] <= limit and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, reverse, gen, row)
-    for reverse, gen in (("false", "false"), ("true", "false"), ("false", "true")):  # bond blocks streamed as well: no table code
-        row = _row(resources, f"cheb_sweep3<bdg::RealPHMode, 4, {reverse}, {gen}, 2>")
-        assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (reverse, gen, row)
+            row = _row(resources, f"cheb_sweep3<bdg::{mode}, {lanes}, {reverse}, {gen}, {streamed}, {waves}>")
+            assert row["scratch"] <= limit and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, streamed, waves, reverse, gen, row)
 
 
 @pytest.mark.timeout(600)
