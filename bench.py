@@ -539,6 +539,11 @@ def main():
                     # (these passes start from an idle GPU - the matrix has just been assembled on the host - and the
                     # sweep kernels feel the shader clock for ~50 ms: a longer warm-up than the headline's W steps)
                     dev.moments_random(o_scale, 2 * max(args.warmup, 63), r_local, seed=0, kind=vec_kind)
+                    # (... and then some: 63 steps are 5-12 ms of GPU work, after a second of host assembly; at the driver's
+                    # --steps 20 the timed call is 2-5 ms long and ran 30 % below the rate of the same call in a loop)
+                    settle = time.perf_counter() + 0.15
+                    while time.perf_counter() < settle:
+                        dev.moments_random(o_scale, 2 * 63, r_local, seed=0, kind=vec_kind)
                     t_start = time.perf_counter()
                     dev.moments_random(o_scale, 2 * args.steps, r_local, seed=0, kind=vec_kind)
                     dt = time.perf_counter() - t_start

@@ -37,6 +37,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <memory>
 #include <mutex>
 #include <string>
@@ -309,7 +310,7 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
         return cleanup(fail(BDG_EDEVICE, "hipGetDeviceProperties failed"));
     sys->num_cus = prop.multiProcessorCount;
     sys->lds_per_cu = std::min<size_t>(prop.maxSharedMemoryPerMultiProcessor, prop.sharedMemPerBlockOptin ? prop.sharedMemPerBlockOptin : prop.maxSharedMemoryPerMultiProcessor);
-    if (hipStreamCreateWithFlags(&sys->stream, hipStreamNonBlocking) != hipSuccess ||
+    if (pooled_stream(device, -1, &sys->stream) != BDG_OK ||
         hipEventCreate(&sys->ev_start) != hipSuccess || hipEventCreate(&sys->ev_stop) != hipSuccess)
         return cleanup(fail(BDG_EDEVICE, "stream/event creation failed"));
     if (int rc = sys->indptr.reserve((size_t)nb + 1)) return cleanup(rc);

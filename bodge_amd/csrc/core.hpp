@@ -77,8 +77,39 @@ struct ExchangePeer {
 // The handle is the first such set; a call with several batches runs them side by side on further ones
 // (`side_sets`, created on first use) - the start and the end of a launch leave the memory system idle, and
 // launches of independent batches fill each other's gaps (recurrence.hpp: run_recurrence).
+// Streams are per device, not per handle.  ROCm serves the streams of a process from four hardware queues; the fifth
+// stream shares one.  With a stream pair per handle, the second handle of a process (bench.py's comparison matrices, a
+// user holding two Hamiltonians) could get both its streams on ONE queue: its two lane groups then ran one after the
+// other, each on half the wave slots - 0.36 instead of 0.22 ms per launch of the same call (profiles/r04_stream_pool.log).
+// So every handle of a device uses the same main stream and the same side streams (created on first use, kept for the
+// life of the process): null stream + main + side (+ the RCCL stream of slabs) stay within four queues however many
+// handles exist.  Calls on two handles of one device from two host threads are therefore ordered on the GPU like calls on
+// one handle - correct (every call waits for its own work; buffers are per handle), not concurrent.
+struct DeviceStreams {
+    hipStream_t main = nullptr;
+    std::vector<hipStream_t> side;
+};
+inline int pooled_stream(int device, int side_index /* -1 = the main stream */, hipStream_t* out) {
+    static std::mutex mutex;
+    static std::map<int, DeviceStreams> pool;
+    std::lock_guard<std::mutex> lock(mutex);
+    DeviceStreams& d = pool[device];
+    hipStream_t* slot = &d.main;
+    if (side_index >= 0) {
+        if ((int)d.side.size() <= side_index) d.side.resize((size_t)side_index + 1, nullptr);
+        slot = &d.side[(size_t)side_index];
+    }
+    if (!*slot && hipStreamCreateWithFlags(slot, hipStreamNonBlocking) != hipSuccess) {
+        *slot = nullptr;
+        (void)hipGetLastError();
+        return BDG_EDEVICE;
+    }
+    *out = *slot;
+    return BDG_OK;
+}
+
 struct StreamSet {
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;  // (from the device's pool: never destroyed here)
     std::vector<hipEvent_t> ev_pool;  // (start, stop) pairs: one per reduction chunk of a call
     DeviceBuffer<double2> vec_a, vec_b;
     DeviceBuffer<double2> vec_c, vec_d;  // multi-step sweeps: the new levels are written out of place
@@ -96,7 +127,6 @@ struct StreamSet {
         rows.release();
         for (hipEvent_t ev : ev_pool) (void)hipEventDestroy(ev);
         ev_pool.clear();
-        if (stream) (void)hipStreamDestroy(stream);
         stream = nullptr;
     }
 };

@@ -745,9 +745,10 @@ int make_sweep_plan(bdg_system* sys, const ModeInfo& mode, int lanes, int depth,
     const int owned = depth == 3 ? bdg::sweep3_owned(lanes) : bdg::sweep_owned(lanes);
     a.n_cols = (int)((plane + owned - 1) / owned);
     // one unit (segment x window) per resident wave, segments of at least 8 planes
-    // (not with streamed on-site blocks: their complex form keeps one workgroup per CU, and half the segments took the
-    // texture matrix from 35.5 to 23.2 k vector-steps/s; the real form gains 1.7 % - within the noise)
-    if (streamed) share = 1;
+    // (streamed forms: shared as the others since round 4 - real on-site records +2 %, 104.6 against 102.7 k vector-steps/s,
+    // complex +1 %; the forms with one workgroup of seven waves per CU lose 3 % with half the segments and keep them all;
+    // BODGE_AMD_STREAMED_SHARE=0: never)
+    if (const char* env = knob::raw("BODGE_AMD_STREAMED_SHARE"); streamed && (wg_waves > 4 || (env && env[0] == '0'))) share = 1;
     const int waves = std::max(wg_waves, per_cu * sys->num_cus * wg_waves / std::max(1, share));
     // (launches side by side: the count that fills the share of the slots - 26 against 25 segments is the 2 % the model says)
     int n_segs = choose_segments(a.n_cols, a.lx, waves, 2 * depth, 8, share > 1 ? 0.985 : 0.97);

@@ -80,7 +80,7 @@ struct Batch {
         if (set_index > 0) {
             while ((int)sys->side_sets.size() < set_index) {
                 auto side = std::make_unique<StreamSet>();
-                HIP_TRY(hipStreamCreateWithFlags(&side->stream, hipStreamNonBlocking));
+                if (int rc = pooled_stream(sys->device, (int)sys->side_sets.size(), &side->stream)) return fail(rc, "stream creation failed");
                 sys->side_sets.push_back(std::move(side));
             }
             ss = sys->side_sets[(size_t)set_index - 1].get();
@@ -979,7 +979,7 @@ int run_recurrence_once(bdg_system* sys, double scale, int n_steps, int n_vector
     }
     while ((int)sys->side_sets.size() < n_streams - 1) {
         auto side = std::make_unique<StreamSet>();
-        HIP_TRY(hipStreamCreateWithFlags(&side->stream, hipStreamNonBlocking));
+        if (int rc = pooled_stream(sys->device, (int)sys->side_sets.size(), &side->stream)) return fail(rc, "stream creation failed");
         sys->side_sets.push_back(std::move(side));
     }
     if (!sys->ev_side) HIP_TRY(hipEventCreateWithFlags(&sys->ev_side, hipEventDisableTiming));

@@ -607,7 +607,7 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
     auto in_lattice = [&](int k) { return a.wrap_x || (act(k) >= 0 && act(k) < a.lx); };
     // (where flat addressing does not spill it is 2-7 % faster - fewer scalar instructions per access: the dictionary forms
     // and the real 4-lane streamed forms keep it)
-    constexpr bool BUF = (OS != 0 && (Mode::kVec == 1 || RL == 2)) || BDG_SWEEP_BUFFER_OPS;
+    constexpr bool BUF = WT || (OS != 0 && (Mode::kVec == 1 || RL == 2)) || BDG_SWEEP_BUFFER_OPS;
     const int plane_bytes = a.plane * RL * (int)sizeof(double2);
     const int lane_bytes = (pw * RL + r) * (int)sizeof(double2);  // (stores: owned lanes only, where p == pw)
     auto load_plane = [&](const double2* buf, bool nt, int k, bool wanted, double2 out[4]) {
@@ -643,11 +643,11 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
         if (WT && !(a.stream & 16)) {  // (bit 4: plain stores all the same - measurements only)
             // write-through (sc1) stores: other workgroups of the same launch read these planes at the next level
             // (cheb_march3), so they must not linger in this XCD's L2
-            const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(buf, 0, (int)(4 * nb * RL * sizeof(double2)), kRawBufferFlags);
 #pragma unroll
-            for (int al = 0; al < 4; ++al)
-                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[al]), rsrc,
-                                                       (int)(vslot(al, site, r, nb, RL) * sizeof(double2)), 0, kAuxSc1);
+            for (int al = 0; al < 4; ++al) {
+                const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(buf, ((size_t)al * nb + (size_t)act(k) * a.plane) * RL * sizeof(double2), plane_bytes);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[al]), rsrc, lane_bytes, 0, kAuxSc1);
+            }
         } else if constexpr (BUF) {
 #pragma unroll
             for (int al = 0; al < 4; ++al) {

@@ -897,7 +897,9 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
         bool lookahead = n >= 5000;
         if (const char* env = knob::raw("BODGE_AMD_EIGH_LOOKAHEAD")) lookahead = atoi(env) != 0;
         if (lookahead && !side) {
-            HIP_TRY(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+            int device = 0;
+            HIP_TRY(hipGetDevice(&device));
+            if (int rc = pooled_stream(device, 0, &side)) return fail(rc, "stream creation failed");  // (the device's side stream: core.hpp)
             HIP_TRY(hipEventCreateWithFlags(&ev_strip, hipEventDisableTiming));
             HIP_TRY(hipEventCreateWithFlags(&ev_qr, hipEventDisableTiming));
         }
@@ -988,7 +990,6 @@ int tridiagonalise_two_stage(double* a, int64_t n, double* d, double* e, hipStre
     const int rc = body();
     if (side) {
         (void)hipStreamSynchronize(side);
-        (void)hipStreamDestroy(side);
         (void)hipEventDestroy(ev_strip);
         (void)hipEventDestroy(ev_qr);
     }
