@@ -15,6 +15,8 @@
 //     BODGE_AMD_SWEEP=0|1                    never / whenever possible use the lattice-stencil kernels (default: by size)
 //     BODGE_AMD_SWEEP_STEPS=2|3              steps per sweep (cheb_sweep / cheb_sweep3)
 //     BODGE_AMD_SWEEP_LANES=1|2|4            lanes per site of the sweep kernels
+//     BODGE_AMD_STREAMED_SHARE=0             streamed forms (position-dependent blocks): segments cut for the whole device by every launch
+//                                            (default: shared between the lane groups side by side, as for the dictionary forms)
 //     BODGE_AMD_SWEEP_GEN=0                  write the random start block with the fill kernel instead of making it in the first sweep
 //     BODGE_AMD_MARCH=1|2|3                  cheb_march3 for the three-step sweeps of random-start runs (default 0: one cheb_sweep3 launch per
 //                                            sweep and lane group).  1 = all sweeps of a 63-step chunk in one launch, tasks claimed by ticket,

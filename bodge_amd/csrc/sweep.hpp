@@ -471,11 +471,13 @@ constexpr int sweep3_owned(int rl) { return kWave / rl - 6; }
 // site is read from a per-site stream in HBM exactly once per launch (Mode::kOnsiteSlots x 16 B,
 // whole-wave contiguous loads one plane ahead of their first use) into a wave-private
 // LDS ring of three planes, because step j of iteration k works on plane k-j+1: plane k's blocks
-// serve step 1 now, step 2 in the next iteration and step 3 in the one after.  Only with 4 lanes
-// per site (16 slots: the ring is 3 x 16 x kOnsiteStride slots per wave) and the particle-hole modes.
-// OS = 2: the bond blocks are streamed as well (real matrices whose bond blocks are diagonal as 4x4 matrices - the
-// reference's ssd() profile on a model with on-site pairing, bond disorder): the record of a site is its packed on-site
-// block plus (A00, A11) of its four bond blocks, 8 slots = 128 B (pack_site_records), no table at all.
+// serve step 1 now, step 2 in the next iteration and step 3 in the one after.  Particle-hole modes; 4 lanes per site
+// (16 slots) or, since round 4, 2 lanes (32 slots: twice the ring - in workgroups of up to seven waves, one per CU,
+// where eight waves' rings do not fit the LDS any more: template parameter WAVES of cheb_sweep3).
+// OS = 2: the bond blocks are streamed as well (matrices whose bond blocks are diagonal as 4x4 matrices - the
+// reference's ssd() profile on a model with on-site pairing, bond disorder, Peierls phases of a position-dependent gauge):
+// the record of a site is its packed on-site block plus (A00, A11) of its four bond blocks - 8 slots = 128 B in real,
+// 14 slots = 224 B in complex arithmetic (pack_site_records) -, no table at all.
 template <typename Mode, int OS>
 constexpr int sweep3_record_slots() {
     if constexpr (OS == 2) return Mode::kOnsiteSlots + 4 * Mode::kBondSlots;

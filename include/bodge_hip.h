@@ -19,7 +19,9 @@
  * library copies to and from HBM.  Complex numbers are interleaved (re, im)
  * doubles, i.e. numpy complex128.  Every function returns 0 on success or a
  * negative BDG_E* code; `bdg_last_error()` then describes the failure (thread
- * local).  No callbacks, no exceptions, one host thread per handle.
+ * local).  No callbacks, no exceptions, one host thread per handle.  The handles
+ * of one device share that device's HIP streams (round 4): calls on two handles
+ * from two host threads are correct but ordered on the GPU, not concurrent.
  */
 #ifndef BODGE_HIP_H
 #define BODGE_HIP_H
