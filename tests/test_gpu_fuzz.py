@@ -27,11 +27,11 @@ def test_random_lattices_stencil_kernels_against_one_step_kernels(hip_library, s
 
 
 def test_random_systems_through_the_api_against_the_oracle(hip_library):
-    assert fuzz_api.run(seed=103, n_cases=30) == 0
+    assert fuzz_api.run(seed=103, n_cases=24) == 0
 
 
 def test_random_matrices_through_the_own_dense_route(hip_library):
-    assert fuzz_dense.run(seed=104, n_cases=24) == 0
+    assert fuzz_dense.run(seed=104, n_cases=18) == 0
 
 
 def test_random_matrices_through_the_two_stage_dense_route(hip_library):

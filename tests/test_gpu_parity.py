@@ -390,15 +390,17 @@ def _position_dependent_system(api, shape, kind, seed=0, periodic=False):
     return system
 
 
-@pytest.mark.parametrize("shape,kind,vec_kind,periodic", [
-    ((48, 50, 1), "potential", cheb_ref.VEC_RADEMACHER, False),  # real arithmetic, 8 vectors per launch
-    ((33, 61, 1), "texture", cheb_ref.VEC_Z4, False),            # complex blocks and vectors, odd sizes, ragged window
-    ((40, 37, 1), "gap", cheb_ref.VEC_RADEMACHER, False),        # pairing on the bonds
-    ((30, 1, 44), "potential", cheb_ref.VEC_Z4, False),          # complex vectors on a real matrix, (Lx, 1, Lz)
-    ((30, 32, 1), "potential", cheb_ref.VEC_RADEMACHER, True),   # torus: halo slots wrap, on-site records fetched per piece
-    ((21, 30, 1), "texture", cheb_ref.VEC_Z4, True),
+@pytest.mark.parametrize("shape,kind,vec_kind,periodic,lanes", [
+    ((48, 50, 1), "potential", cheb_ref.VEC_RADEMACHER, False, 2),  # real arithmetic, 4 vectors per launch (the default)
+    ((48, 50, 1), "potential", cheb_ref.VEC_RADEMACHER, False, 4),  # ... 8 vectors per launch
+    ((33, 61, 1), "texture", cheb_ref.VEC_Z4, False, 4),            # complex blocks and vectors, odd sizes, ragged window (the default)
+    ((33, 61, 1), "texture", cheb_ref.VEC_Z4, False, 2),            # ... workgroups of seven waves
+    ((40, 37, 1), "gap", cheb_ref.VEC_RADEMACHER, False, 2),        # pairing on the bonds
+    ((30, 1, 44), "potential", cheb_ref.VEC_Z4, False, 4),          # complex vectors on a real matrix, (Lx, 1, Lz)
+    ((30, 32, 1), "potential", cheb_ref.VEC_RADEMACHER, True, 2),   # torus: halo slots wrap, on-site records fetched per piece
+    ((21, 30, 1), "texture", cheb_ref.VEC_Z4, True, 4),
+    ((21, 30, 1), "texture", cheb_ref.VEC_Z4, True, 2),
 ])
-@pytest.mark.parametrize("lanes", [2, 4])
 def test_three_step_sweep_with_streamed_onsite_blocks(api, solver_cls, knobs, block_storage, shape, kind, vec_kind, periodic, lanes):
     """cheb_sweep3<..., OS> (sweep.hpp): matrices with more than 256 distinct blocks whose bonds repeat a
     few - the bond blocks sit in the LDS table, the diagonal block of every site is streamed once per
@@ -414,7 +416,7 @@ def test_three_step_sweep_with_streamed_onsite_blocks(api, solver_cls, knobs, bl
     complex_run = vec_kind == cheb_ref.VEC_Z4 or kind == "texture"
     per_group = lanes * (1 if complex_run else 2)
     with solver_cls.from_hamiltonian(system) as dev:
-        if block_storage == "dictionary" and lanes == 2:  # the default: 2 lanes in real arithmetic, 4 in complex
+        if block_storage == "dictionary":  # the default: 2 lanes in real arithmetic, 4 in complex
             knobs.set("BODGE_AMD_SWEEP", "1")
             dev.dots_random(scale, 3, 2, seed=5, kind=vec_kind)
             assert dev.perf()["onsite_streamed"] == 1 and dev.perf()["lanes_per_row"] == (4 if complex_run else 2), dev.perf()
