@@ -57,6 +57,14 @@ import time
 
 import numpy as np
 
+# ROCm serves the HIP streams of a process from four hardware queues by default; a fifth stream shares one.  A rank of a
+# multi-GPU run has the null stream, the library's main and side stream (the two lane groups of the call side by side) and
+# RCCL's own: so that main and side never end up on ONE queue (which serialises the lane groups: profiles/r04_stream_pool.log
+# shows that loss for a second handle), ranks of such a run ask for eight before the runtime starts.  At N = 1 the setting
+# changes nothing (scratch/r4_hwq.sh: 105.9-106.0 against 104.2-106.2 k) and is not made.
+if int(os.environ.get("WORLD_SIZE", "1")) > 1:
+    os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
