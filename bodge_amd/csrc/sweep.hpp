@@ -518,6 +518,7 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int sweep_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kRawBufferFlags = 0x00020000;  // raw buffer resource of gfx9 / CDNA: 32-bit data format, no swizzle
 constexpr int kAuxSc1 = 16;                  // cache-policy bits of the raw buffer builtins: sc1 = write-through
+constexpr int kBufferOutOfRange = 0x7FFFFFF0;  // an offset no plane descriptor covers: such loads return zeros, such stores do nothing
 constexpr int kAuxNt = 2;                    // ... nt = non-temporal (what __builtin_nontemporal_load / _store set)
 
 // Buffer addressing (BUF): every global access of a unit goes through a raw buffer instruction whose descriptor is the
@@ -529,7 +530,7 @@ constexpr int kAuxNt = 2;                    // ... nt = non-temporal (what __bu
 // 0.10 of its 0.37 ms that way (profiles/r04_onsite_ab.log).  Used by the forms that spilled (complex streamed forms, 2-lane
 // streamed forms).
 #ifndef BDG_SWEEP_BUFFER_OPS
-#define BDG_SWEEP_BUFFER_OPS 0  // 1: in every form (A/B builds)
+#define BDG_SWEEP_BUFFER_OPS 1  // 0: flat addressing in the forms that never spilled (A/B builds)
 #endif
 __device__ __forceinline__ __amdgpu_buffer_rsrc_t sweep_plane_rsrc(const void* buf, size_t byte_offset, int bytes) {
     const uint64_t base = reinterpret_cast<uint64_t>(buf) + byte_offset;
@@ -615,19 +616,17 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
     auto load_plane = [&](const double2* buf, bool nt, int k, bool wanted, double2 out[4]) {
         k = ring(act(k));
         if constexpr (BUF) {
+            // no branch: a plane that does not exist gets a descriptor of length zero, a lane that does not take part an
+            // offset beyond any plane - out-of-range buffer loads return zeros.  The loads are then on every path, and
+            // the compiler can wait for an older plane with a counted s_waitcnt vmcnt(N) that leaves these in flight
+            // (with the loads behind a branch it has to assume the path without them: vmcnt(0), see the text above)
+            const bool there = buf != nullptr && k >= 0 && k < a.lx;  // (uniform)
+            const int offset = wanted ? lane_bytes : kBufferOutOfRange;
 #pragma unroll
-            for (int al = 0; al < 4; ++al) out[al] = zero;
-            if (k >= 0 && k < a.lx) {  // (uniform)
-                __amdgpu_buffer_rsrc_t rsrc[4];
-#pragma unroll
-                for (int al = 0; al < 4; ++al)
-                    rsrc[al] = sweep_plane_rsrc(buf, ((size_t)al * nb + (size_t)k * a.plane) * RL * sizeof(double2), plane_bytes);
-                if (wanted) {
-#pragma unroll
-                    for (int al = 0; al < 4; ++al)
-                        out[al] = __builtin_bit_cast(double2, nt ? __builtin_amdgcn_raw_buffer_load_b128(rsrc[al], lane_bytes, 0, kAuxNt)
-                                                                 : __builtin_amdgcn_raw_buffer_load_b128(rsrc[al], lane_bytes, 0, 0));
-                }
+            for (int al = 0; al < 4; ++al) {
+                const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(buf, there ? ((size_t)al * nb + (size_t)k * a.plane) * RL * sizeof(double2) : 0,
+                                                                     there ? plane_bytes : 0);
+                out[al] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, offset, 0, 0));
             }
         } else if (wanted && k >= 0 && k < a.lx) {
             const size_t site = (size_t)k * a.plane + pw;
@@ -654,8 +653,7 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
                 const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(buf, ((size_t)al * nb + (size_t)act(k) * a.plane) * RL * sizeof(double2), plane_bytes);
-                if (nt_store) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[al]), rsrc, lane_bytes, 0, kAuxNt);
-                else __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[al]), rsrc, lane_bytes, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[al]), rsrc, lane_bytes, 0, 0);
             }
         } else {
 #pragma unroll
@@ -688,15 +686,16 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
             load_plane(t.cur, nt_cur, k, wanted, out);
         }
     };
-    auto load_ids = [&](int k) {
+    auto load_ids = [&](int k, bool wanted = true) {
         uint2 w = make_uint2(0xFFFFFFFFu, 0xFFu);
         k = ring(act(k));
         if constexpr (BUF) {
-            if (k >= 0 && k < a.lx) {  // (uniform)
-                const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(a.stencil, (size_t)k * a.plane * sizeof(uint2), a.plane * (int)sizeof(uint2));
-                if (ok1) w = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, pw * (int)sizeof(uint2), 0, 0));
-            }
-        } else if (ok1 && k >= 0 && k < a.lx) {
+            const bool there = k >= 0 && k < a.lx;  // (uniform)
+            const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(a.stencil, there ? (size_t)k * a.plane * sizeof(uint2) : 0,
+                                                                 there ? a.plane * (int)sizeof(uint2) : 0);
+            const uint2 got = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, ok1 && wanted ? pw * (int)sizeof(uint2) : kBufferOutOfRange, 0, 0));
+            if (ok1 && wanted && there) w = got;  // (a select: out-of-range loads return zeros, which would read "block 0")
+        } else if (ok1 && wanted && k >= 0 && k < a.lx) {
             w = a.stencil[(size_t)k * a.plane + pw];
         }
         return w;
@@ -785,13 +784,12 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
                 out[j] = zero;
                 // (plain loads: the halo slots of the neighbouring windows read the same records - 16 slots
                 // per 10 owned - and should find them in L2; a.stream bit 3 = non-temporal, for A/B runs)
-                if (wanted && k >= 0 && k < a.lx) {  // (uniform)
-                    const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(a.onsite, (size_t)k * a.plane * PIECES * sizeof(double2),
-                                                                         a.plane * PIECES * (int)sizeof(double2));
-                    const int piece_bytes = (pwe * PIECES + part) * (int)sizeof(double2);
-                    if (slot < SLOTS && (in_e || a.wrap_p))
-                        out[j] = __builtin_bit_cast(double2, (a.stream & 8) ? __builtin_amdgcn_raw_buffer_load_b128(rsrc, piece_bytes, 0, kAuxNt)
-                                                                            : __builtin_amdgcn_raw_buffer_load_b128(rsrc, piece_bytes, 0, 0));
+                {
+                    const bool there = wanted && k >= 0 && k < a.lx;  // (uniform)
+                    const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(a.onsite, there ? (size_t)k * a.plane * PIECES * sizeof(double2) : 0,
+                                                                         there ? a.plane * PIECES * (int)sizeof(double2) : 0);
+                    const int piece_bytes = slot < SLOTS && (in_e || a.wrap_p) ? (pwe * PIECES + part) * (int)sizeof(double2) : kBufferOutOfRange;
+                    out[j] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, piece_bytes, 0, 0));
                 }
             }
         }
@@ -833,7 +831,7 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
     // one iteration: `centre` holds plane k on entry and plane k+2 (in flight) on exit, `after` plane k+1
     auto iterate = [&](int k, double2 (&centre)[4], const double2 (&after)[4]) {
         const bool more = k < k_last;
-        const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFu);
+        const uint2 nx_ids = load_ids(k + 1, more);
         put_own(row_0, centre);
         wave_sync();
         cur_plane(k + 2, valid && more, centre);
