@@ -857,17 +857,20 @@ bool unit_run_wants_stencil(const bdg_system* sys, const int64_t* rows, int coun
 using RollKernel = void (*)(bdg::RollArgs);
 
 template <typename Mode>
-RollKernel roll_kernel_for(int lanes) {
-    return lanes == 2 ? bdg::cheb_roll3<Mode, 2> : lanes == 4 ? bdg::cheb_roll3<Mode, 4> : nullptr;
+RollKernel roll_kernel_for(int lanes, bool nt) {
+    if (lanes == 2) return nt ? bdg::cheb_roll3<Mode, 2, true> : bdg::cheb_roll3<Mode, 2, false>;
+    if (lanes == 4) return nt ? bdg::cheb_roll3<Mode, 4, true> : bdg::cheb_roll3<Mode, 4, false>;
+    return nullptr;
 }
 
-RollKernel roll_kernel(const ModeInfo& mode, int lanes) {
+// `nt`: non-temporal t_{n-1} loads and t_{n+1} stores (vector pairs beyond the Infinity Cache)
+RollKernel roll_kernel(const ModeInfo& mode, int lanes, bool nt = false) {
     switch (mode.id) {
-        case 1: return roll_kernel_for<RealMode>(lanes);
-        case 2: return roll_kernel_for<ComplexPHMode>(lanes);
-        case 3: return roll_kernel_for<RealPHMode>(lanes);
+        case 1: return roll_kernel_for<RealMode>(lanes, nt);
+        case 2: return roll_kernel_for<ComplexPHMode>(lanes, nt);
+        case 3: return roll_kernel_for<RealPHMode>(lanes, nt);
     }
-    return roll_kernel_for<ComplexMode>(lanes);
+    return roll_kernel_for<ComplexMode>(lanes, nt);
 }
 
 // Lanes per site of the rolling kernel: 4 (8 real vectors per launch, windows of 14 owned positions
@@ -890,6 +893,7 @@ int roll_lanes_for(const bdg_system* sys, int n_vectors, int per_lane) {
 
 struct RollPlan {
     RollKernel kernel = nullptr;
+    RollKernel kernel_nt = nullptr;  // the same with non-temporal t_{n-1} loads / t_{n+1} stores
     int lanes = bdg::kSweepLanes;
     int grid = 0;
     size_t lds_bytes = 0;
@@ -905,6 +909,7 @@ struct RollPlan {
 int make_roll_plan(bdg_system* sys, const ModeInfo& mode, int lanes, RollPlan* plan) {
     plan->lanes = lanes;
     plan->kernel = roll_kernel(mode, lanes);
+    plan->kernel_nt = roll_kernel(mode, lanes, true);
     if (!plan->kernel) return fail(BDG_EINVAL, "the rolling kernel has 2 or 4 lanes per site, not %d", lanes);
     const size_t table = (size_t)sys->n_unique * mode.stride * sizeof(double2);
     if (table > kDictLdsLimit) return fail(BDG_EINVAL, "block table too large for the rolling kernel");

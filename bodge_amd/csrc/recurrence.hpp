@@ -531,7 +531,8 @@ struct Batch {
                 ra.hi_site0 = (int)(ext_hi ? ext_hi_site0 : sys->stencil_hi_base);
                 ra.hi_ld = (int)(ext_hi ? ext_hi_ld : sys->ncols);
             }
-            rplan.kernel<<<rplan.grid, bdg::kBlockThreads, rplan.lds_bytes, st>>>(ra);
+            // (stream bit 0 / 1: t_{n-1} loads / t_{n+1} stores non-temporal - one compiled form with both since round 4)
+            (ra.stream ? rplan.kernel_nt : rplan.kernel)<<<rplan.grid, bdg::kBlockThreads, rplan.lds_bytes, st>>>(ra);
         } else {
             plan.kernel<<<plan.grid, bdg::kBlockThreads, plan.lds_bytes, st>>>(args);
         }

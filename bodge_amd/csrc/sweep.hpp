@@ -1297,7 +1297,11 @@ constexpr int roll_owned(int rl) { return kWave / rl - 2; }
 
 // (three waves per SIMD - 168 VGPRs - would fill the 2048 x 1.5 wave slots of a 100^3 launch better, but the
 // seven planes of rolling state and a plane of prefetch then spill 250-360 B per lane: round 3, not kept)
-template <typename Mode, int RL = kSweepLanes>
+// NT: non-temporal t_{n-1} loads and t_{n+1} stores (RollArgs.stream = 3: vector pairs beyond the Infinity Cache) - a
+// template parameter since round 4, because every global access is a raw buffer instruction whose cache policy is an
+// immediate, and because a run-time choice between two loads is a branch: see "Buffer addressing" above - loads behind
+// branches make the compiler wait with vmcnt(0), i.e. for the planes it has just asked for.
+template <typename Mode, int RL = kSweepLanes, bool NT = false>
 __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
     extern __shared__ double2 lds[];
     constexpr int SLOTS = kWave / RL;
@@ -1324,8 +1328,9 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
     double dot[4] = {0.0, 0.0, 0.0, 0.0};
     const double2 zero = make_double2(0.0, 0.0);
     const size_t nb = (size_t)a.ld;  // block rows per component plane of this handle's vector buffers
-    const bool nt_prev = a.stream & 1, nt_store = a.stream & 2;
-
+    constexpr int kAuxVec = NT ? kAuxNt : 0;
+    const int plane_bytes = a.plane * RL * (int)sizeof(double2);
+    const int ly = a.plane / a.lz;
     for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
         const int seg = u / a.n_cols, col = u - seg * a.n_cols;
         const int x0 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * seg) / a.n_segs);
@@ -1335,62 +1340,67 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
         const bool owned = valid && s >= 1 && s <= SLOTS - 2;
         const bool rev = a.reverse != 0;  // wave-uniform
         auto act = [&](int k) { return rev ? x0 + x1 - 1 - k : k; };
+        // the y-neighbours are asked for wherever the lattice has them (a bond that is not stored costs a load whose
+        // result nobody uses): deciding by the stencil word would make these loads wait for the word's
+        const int y = valid ? p / a.lz : 0;
+        const bool has_ym = owned && y >= 1, has_yp = owned && y <= ly - 2;
 
-        auto load_plane = [&](const double2* buf, bool nt, int k, int shift, bool wanted, double2 out[4]) {
-            k = act(k);
-            if (wanted && k >= 0 && k < a.lx) {
-                const size_t site = (size_t)k * a.plane + (p + shift);
+        // Every global access: a raw buffer instruction on the descriptor of ONE plane (base made from wave-uniform values),
+        // per-lane offset (position * RL + r) * 16 or an offset out of range - no branch around any load (cheb_sweep3).
+        auto plane_of = [&](const double2* buf, size_t ld, size_t row0, bool there, int offset, auto aux, double2 out[4]) {
 #pragma unroll
-                for (int al = 0; al < 4; ++al)
-                    out[al] = nt ? load_stream(buf + vslot(al, site, r, nb, RL)) : buf[vslot(al, site, r, nb, RL)];
-            } else {
-#pragma unroll
-                for (int al = 0; al < 4; ++al) out[al] = zero;
+            for (int al = 0; al < 4; ++al) {
+                const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(buf, there ? ((size_t)al * ld + row0) * RL * sizeof(double2) : 0,
+                                                                     there ? plane_bytes : 0);
+                out[al] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, offset, 0, decltype(aux)::value));
             }
+        };
+        auto load_plane = [&](const double2* buf, auto aux, int k, int shift, bool wanted, double2 out[4]) {
+            k = act(k);
+            plane_of(buf, nb, (size_t)k * a.plane, k >= 0 && k < a.lx, wanted ? ((p + shift) * RL + r) * (int)sizeof(double2) : kBufferOutOfRange, aux, out);
         };
         // t_n of the lane's own position in plane k; planes -1 and lx are the neighbouring slabs' (if any)
         auto load_cur = [&](int k, bool wanted, double2 out[4]) {
             k = act(k);
             const double2* buf = a.cur;
-            size_t site = (size_t)k * a.plane + p, ld = nb;
+            size_t row0 = (size_t)k * a.plane, ld = nb;
             bool there = k >= 0 && k < a.lx;
-            if (k == -1 && a.lo_buf) buf = a.lo_buf, site = (size_t)a.lo_site0 + p, ld = (size_t)a.lo_ld, there = true;
-            if (k == a.lx && a.hi_buf) buf = a.hi_buf, site = (size_t)a.hi_site0 + p, ld = (size_t)a.hi_ld, there = true;
-            if (wanted && there) {
-#pragma unroll
-                for (int al = 0; al < 4; ++al) out[al] = buf[vslot(al, site, r, ld, RL)];
-            } else {
-#pragma unroll
-                for (int al = 0; al < 4; ++al) out[al] = zero;
-            }
+            if (k == -1 && a.lo_buf) buf = a.lo_buf, row0 = (size_t)a.lo_site0, ld = (size_t)a.lo_ld, there = true;
+            if (k == a.lx && a.hi_buf) buf = a.hi_buf, row0 = (size_t)a.hi_site0, ld = (size_t)a.hi_ld, there = true;
+            plane_of(buf, ld, row0, there, wanted ? (p * RL + r) * (int)sizeof(double2) : kBufferOutOfRange, std::integral_constant<int, 0>{}, out);
         };
-        auto load_ids = [&](int k) {
+        auto load_ids = [&](int k, bool wanted) {
             uint2 w = make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
             k = act(k);
-            if (owned && k >= 0 && k < a.lx) w = a.stencil[(size_t)k * a.plane + p];
+            const bool there = k >= 0 && k < a.lx;
+            const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(a.stencil, there ? (size_t)k * a.plane * sizeof(uint2) : 0, there ? a.plane * (int)sizeof(uint2) : 0);
+            const uint2 got = __builtin_bit_cast(uint2, __builtin_amdgcn_raw_buffer_load_b64(rsrc, owned && wanted ? p * (int)sizeof(uint2) : kBufferOutOfRange, 0, 0));
+            if (owned && wanted && there) w = got;
             return w;
         };
         auto id_of = [](uint2 w, int slot) { return slot < 4 ? (w.x >> (8 * slot)) & 0xFFu : (w.y >> (8 * (slot - 4))) & 0xFFu; };
+        constexpr std::integral_constant<int, kAuxVec> aux_vec{};
+        constexpr std::integral_constant<int, 0> aux_plain{};
 
         // ---- prologue: t_n of planes x0-1, x0, x0+1; t_{n-1}, ids and y-neighbours of plane x0
         double2 cn_m[4], cn_0[4], cn_p[4], pv[4], ym[4], yp[4];
         load_cur(x0 - 1, valid, cn_m);
         load_cur(x0, valid, cn_0);
         load_cur(x0 + 1, valid, cn_p);
-        load_plane(a.prev, nt_prev, x0, 0, owned, pv);
-        uint2 ids = load_ids(x0);
-        load_plane(a.cur, false, x0, -a.lz, owned && id_of(ids, 1) != kNoBlock, ym);
-        load_plane(a.cur, false, x0, +a.lz, owned && id_of(ids, 5) != kNoBlock, yp);
+        load_plane(a.prev, aux_vec, x0, 0, owned, pv);
+        uint2 ids = load_ids(x0, true);
+        load_plane(a.cur, aux_plain, x0, -a.lz, has_ym, ym);
+        load_plane(a.cur, aux_plain, x0, +a.lz, has_yp, yp);
 
         for (int k = x0; k < x1; ++k) {
             // ---- prefetch for the next iteration
             double2 nx_cn[4], nx_pv[4], nx_ym[4], nx_yp[4];
             const bool more = k + 1 < x1;
             load_cur(k + 2, valid && more, nx_cn);
-            load_plane(a.prev, nt_prev, k + 1, 0, owned && more, nx_pv);
-            const uint2 nx_ids = more ? load_ids(k + 1) : make_uint2(0xFFFFFFFFu, 0xFFFFFFFFu);
-            load_plane(a.cur, false, k + 1, -a.lz, owned && more && id_of(nx_ids, 1) != kNoBlock, nx_ym);
-            load_plane(a.cur, false, k + 1, +a.lz, owned && more && id_of(nx_ids, 5) != kNoBlock, nx_yp);
+            load_plane(a.prev, aux_vec, k + 1, 0, owned && more, nx_pv);
+            const uint2 nx_ids = load_ids(k + 1, more);
+            load_plane(a.cur, aux_plain, k + 1, -a.lz, has_ym && more, nx_ym);
+            load_plane(a.cur, aux_plain, k + 1, +a.lz, has_yp && more, nx_yp);
 
 #pragma unroll
             for (int be = 0; be < 4; ++be) row_n[SHARE_SLOT(lane, be)] = cn_0[be];
@@ -1426,15 +1436,15 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
                 mac(5, yp);
                 if (rev) mac(6, cn_m);
                 else mac(6, cn_p);
-                const size_t site = (size_t)act(k) * a.plane + p;
 #pragma unroll
                 for (int al = 0; al < 4; ++al) {
                     double2 nx;
                     nx.x = fma(a.coef, acc[al].x, -pv[al].x);
                     nx.y = fma(a.coef, acc[al].y, -pv[al].y);
-                    if (a.discard) {
-                    } else if (nt_store) store_stream(a.prev + vslot(al, site, r, nb, RL), nx);
-                    else a.prev[vslot(al, site, r, nb, RL)] = nx;
+                    if (!a.discard) {
+                        const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(a.prev, ((size_t)al * nb + (size_t)act(k) * a.plane) * RL * sizeof(double2), plane_bytes);
+                        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, nx), rsrc, (p * RL + r) * (int)sizeof(double2), 0, kAuxVec);
+                    }
                     Mode::dots(dot, cn_0[al], nx);
                 }
             }

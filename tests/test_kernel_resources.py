@@ -58,22 +58,25 @@ def test_sweep_kernels_fit_two_waves_per_simd_without_spilling(resources):
                     row = _row(resources, f"cheb_sweep3<bdg::{mode}, {lanes}, {reverse}, {gen}, 0, 4>")
                     assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, reverse, gen, row)
         for lanes in (2, 4):
-            row = _row(resources, f"cheb_roll3<bdg::{mode}, {lanes}>")
-            assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, row)
+            for nt in ("false", "true"):  # (non-temporal t_{n-1} loads / t_{n+1} stores: a compiled form of its own since round 4)
+                row = _row(resources, f"cheb_roll3<bdg::{mode}, {lanes}, {nt}>")
+                assert row["scratch"] == 0 and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, nt, row)
 
 
 @pytest.mark.timeout(600)
 def test_streamed_onsite_sweep_keeps_two_waves_per_simd(resources):
-    """cheb_sweep3<..., OS, WAVES> carries the prefetched records on top of K7b's state.  It must keep two waves per SIMD;
-    the register allocator parks a few loop-invariant values in scratch (measured harmless next to ~30 global loads per
-    iteration), and that must not grow unnoticed.  Round 4: the forms with 2 lanes per site (three record pieces per lane in
-    flight instead of two) and the complex site records, in workgroups of seven waves (one per CU)."""
-    forms = [("RealPHMode", 4, 1, 4, 24), ("ComplexPHMode", 4, 1, 4, 64), ("RealPHMode", 4, 2, 4, 0),
-             ("RealPHMode", 2, 1, 4, 48), ("RealPHMode", 2, 1, 7, 48), ("ComplexPHMode", 2, 1, 7, 112), ("ComplexPHMode", 4, 2, 7, 32)]
+    """cheb_sweep3<..., OS, WAVES> carries the prefetched records on top of K7b's state.  It must keep two waves per SIMD and -
+    since round 4 - must not touch scratch at all: a reload of a spilled value waits with vmcnt(0), i.e. for every prefetched
+    plane in flight (that cost the complex form a quarter of its launch time until buffer addressing freed the registers;
+    DESIGN §4).  Also the forms with 2 lanes per site and the complex site records, in workgroups of seven waves."""
+    forms = [("RealPHMode", 4, 1, 4, 0), ("ComplexPHMode", 4, 1, 4, 0), ("RealPHMode", 4, 2, 4, 0),
+             ("RealPHMode", 2, 1, 4, 0), ("RealPHMode", 2, 1, 7, 0), ("ComplexPHMode", 2, 1, 7, 0), ("ComplexPHMode", 4, 2, 7, 0)]
     for mode, lanes, streamed, waves, limit in forms:
         for reverse, gen in (("false", "false"), ("true", "false"), ("false", "true")):
             row = _row(resources, f"cheb_sweep3<bdg::{mode}, {lanes}, {reverse}, {gen}, {streamed}, {waves}>")
-            assert row["scratch"] <= limit and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, streamed, waves, reverse, gen, row)
+            # (the form that makes the start block in registers runs the first sweep of a run only - 1 launch in 21: a few spills allowed)
+            allowed = 64 if gen == "true" else limit
+            assert row["scratch"] <= allowed and row["vgpr"] <= 256 and row["occupancy"] >= 2, (mode, lanes, streamed, waves, reverse, gen, row)
 
 
 @pytest.mark.timeout(600)
