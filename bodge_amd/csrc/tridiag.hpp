@@ -5,8 +5,11 @@
 // Why: free_energy's dense route (reference hamiltonian.py:282-321) and BASELINE config 5's check
 // ("eigenvalues vs numpy.linalg.eigh to 1e-10") need eigenvalues only.  The Jacobi kernels (dense.hpp)
 // stop at 4N = 4096 and rocSOLVER's 931 MB object takes minutes to arrive on a fresh machine; this
-// path has no such wait and no size limit short of the n^2 matrix.  Eigenvectors above the Jacobi
-// limit stay with rocSOLVER (back-transformation + tridiagonal eigenvectors are not built).
+// path has no such wait and no size limit short of the n^2 matrix.  Eigenvectors (round 3): inverse iteration
+// on the tridiagonal matrix and back-transformation through the stored reflectors, further down in this file
+// (`bdg_eigh_dense_above`: the positive half only); rocSOLVER serves `bdg_eigh_dense` when ALL eigenvectors of a
+// matrix above 2048 rows are asked for, and `BODGE_AMD_EIGH`.  Round 4: real matrices from 3000 / 5000 rows go
+// through a band instead (twostage.hpp), entered from `eig_tridiagonal_typed` below.
 //
 // Algorithm (LAPACK's zhetd2, lower variant, restated for a row-major matrix that is updated lazily):
 // the dense array the scatter kernels write is column-major H, read here as row-major B = H^T = conj(H),

@@ -256,8 +256,10 @@ class DeviceSolver:
         return values[:kept], vectors[:kept], found.value
 
     def eigh(self, vectors: bool = True):
-        """All eigenvalues ascending (and eigenvectors as columns): own Jacobi kernels up to 4N = 2048,
-        rocSOLVER above (dsyevd when imag(H) = 0, else zheevd)."""
+        """All eigenvalues ascending (and ALL eigenvectors as columns).  Eigenvalues alone: the library's own kernels
+        at every size (Jacobi up to 4N = 512, tridiagonalisation + bisection above, through a band from 5000 rows for
+        real matrices).  With vectors: own Jacobi kernels up to 4N = 2048, rocSOLVER above (dsyevd when imag(H) = 0,
+        else zheevd) - `eigh_above` is the route `diagonalize()` takes and needs no library."""
         self._lanczos_vectors = 0  # any other use of the handle ends a Lanczos run (library: lanczos_free)
         w = np.empty(self.dim)
         if not vectors:

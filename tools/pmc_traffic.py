@@ -26,7 +26,8 @@ import re
 def kernel_key(name: str) -> str:
     # cheb_sweep3<Mode, lanes, REV, GEN, OS>: both marching directions count as one kernel; the
     # start-block-generating first sweep of a run (GEN) reads no t_n and is not the typical launch
-    m = re.search(r"cheb_sweep3<bdg::(\w+), (\d), (?:true|false), (true|false), (\d)>", name)
+    # (round 4: a sixth parameter, the waves per workgroup)
+    m = re.search(r"cheb_sweep3<bdg::(\w+), (\d), (?:true|false), (true|false), (\d)(?:, \d)?>", name)
     if m:
         if m.group(3) == "true":
             return ""
@@ -34,7 +35,7 @@ def kernel_key(name: str) -> str:
     m = re.search(r"cheb_sweep<bdg::(\w+), (\d), (?:true|false)>", name)
     if m:
         return f"cheb_sweep<{m.group(1)},{m.group(2)}>"
-    m = re.search(r"cheb_roll3<bdg::(\w+), (\d)>", name)
+    m = re.search(r"cheb_roll3<bdg::(\w+), (\d)(?:, (?:true|false))?>", name)
     if m:
         return f"cheb_roll3<{m.group(1)},{m.group(2)}>"
     m = re.search(r"(cheb_step\w*)<bdg::(\w+), (\d+)", name)
