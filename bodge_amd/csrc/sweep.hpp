@@ -1173,7 +1173,10 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_march3(MarchArgs m) {
         task.discard = last ? m.discard_last : 0;
         const bool rev = (bool)((m.rev0 + level) & 1) != (bool)(m.base.zigzag & seg & 1);
         double dot1[4] = {0.0, 0.0, 0.0, 0.0}, dot2[4] = {0.0, 0.0, 0.0, 0.0}, dot3[4] = {0.0, 0.0, 0.0, 0.0};
-        if (start && m.gen) {
+#ifndef BDG_MARCH_GEN
+#define BDG_MARCH_GEN 1  // (0: the chunk kernel carries one unit body, runs need BODGE_AMD_SWEEP_GEN=0 - A/B builds)
+#endif
+        if (BDG_MARCH_GEN && start && m.gen) {
             const Sweep3Gen gen = sweep3_gen_keys<Mode>(m.base.gen_seed, grp.gen_first_id, grp.gen_active, lane % RL);
             sweep3_unit<Mode, RL, true, OS, true>(m.base, task, w, gen, lane, seg, col, rev, dot1, dot2, dot3);
         } else {
