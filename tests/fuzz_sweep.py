@@ -33,7 +33,7 @@ def _run(seed, n_cases, size, lanczos) -> int:
                 shape = (shape[0], 1, shape[1])
         lat = ba.CubicLattice(shape)
         s = ba.Hamiltonian(lat)
-        model = rng.choice(["uniform", "disorder", "texture", "complex", "periodic"])
+        model = rng.choice(["uniform", "disorder", "texture", "complex", "periodic", "bond_disorder", "bond_phases"])
         with s as (H, D):
             if model == "disorder":  # > 256 distinct real diagonal blocks: the sweep that streams the on-site blocks
                 H.set_sites(rng.normal(size=(lat.size, 1, 1)) * ba.σ0 + 0.1 * rng.normal(size=(lat.size, 1, 1)) * ba.σ3)
@@ -48,7 +48,22 @@ def _run(seed, n_cases, size, lanczos) -> int:
                 pairs = lat.bond_array(axis=0, coords=True)
                 phase = np.where(pairs[:, 1, 0] > pairs[:, 0, 0], np.exp(0.3j), np.exp(-0.3j))
                 H.set_bonds(-phase[:, None, None] * ba.σ0, axis=0)
-            if (model == "periodic" or (model in ("disorder", "texture") and rng.random() < 0.3)) and not three_d:
+            if model in ("bond_disorder", "bond_phases"):
+                # a different spin-diagonal hopping block on every bond (round 4: with a Peierls phase of its own on every bond,
+                # on top of a texture - complex site records); the on-site terms position dependent too
+                idx = lat.bond_array()
+                lo, hi = idx.min(axis=1), idx.max(axis=1)  # the same amplitude both ways
+                t = (0.8 + 0.4 * ((lo * 7919 + hi * 104729) % 1009) / 1009.0)[:, None, None]
+                dt = (0.1 * ((lo * 31 + hi * 17) % 101) / 101.0)[:, None, None]
+                if model == "bond_phases":
+                    θ = 2 * np.pi * ((lo * 271 + hi * 65537) % 997) / 997.0
+                    t = t * np.exp(1j * np.where(idx[:, 1] > idx[:, 0], θ, -θ))[:, None, None]
+                    th, ph = rng.uniform(0, np.pi, (lat.size, 1, 1)), rng.uniform(0, 2 * np.pi, (lat.size, 1, 1))
+                    H.set_sites(3.0 * ba.σ0 - 0.3 * (np.sin(th) * np.cos(ph) * ba.σ1 + np.sin(th) * np.sin(ph) * ba.σ2 + np.cos(th) * ba.σ3))
+                else:
+                    H.set_sites((3.0 + rng.uniform(-0.5, 0.5, lat.size))[:, None, None] * ba.σ0)
+                H.set_bonds(-t * ba.σ0 + dt * ba.σ3)
+            if (model == "periodic" or (model in ("disorder", "texture", "bond_disorder", "bond_phases") and rng.random() < 0.3)) and not three_d:
                 H.set_edges(-0.7 * ba.σ0, axis=0)
                 H.set_edges(-0.7 * ba.σ0, axis=1 if shape[1] > 1 else 2)
         indptr, indices, data = s.bsr_arrays()
