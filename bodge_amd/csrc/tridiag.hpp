@@ -293,18 +293,21 @@ __global__ __launch_bounds__(256) void td_fused_pass(T* __restrict__ a, int n, i
                     vc[i] = *reinterpret_cast<const double2*>(pend.v[i] + c);
                 }
                 const double2 vn = *reinterpret_cast<const double2*>(v_new + c);
+                // (rows past the end repeat the last one: their loads are safe and sit on every path - no branch around a load,
+                // so the compiler keeps the other rows' loads in flight while it waits for one (counted vmcnt); only stores are guarded)
+                double2 pair[ROWS];
 #pragma unroll
-                for (int k = 0; k < ROWS; ++k)
-                    if (k < live) {
-                        double2 pair = *reinterpret_cast<const double2*>(row[k] + c);
+                for (int k = 0; k < ROWS; ++k) pair[k] = *reinterpret_cast<const double2*>(row[k] + c);
 #pragma unroll
-                        for (int i = 0; i < P; ++i) {
-                            pair.x -= vr[k][i] * wc[i].x + wr[k][i] * vc[i].x;
-                            pair.y -= vr[k][i] * wc[i].y + wr[k][i] * vc[i].y;
-                        }
-                        if (P > 0) *reinterpret_cast<double2*>(row[k] + c) = pair;
-                        acc[k] = fma(pair.x, vn.x, fma(pair.y, vn.y, acc[k]));
+                for (int k = 0; k < ROWS; ++k) {
+#pragma unroll
+                    for (int i = 0; i < P; ++i) {
+                        pair[k].x -= vr[k][i] * wc[i].x + wr[k][i] * vc[i].x;
+                        pair[k].y -= vr[k][i] * wc[i].y + wr[k][i] * vc[i].y;
                     }
+                    if (P > 0 && k < live) *reinterpret_cast<double2*>(row[k] + c) = pair[k];
+                    acc[k] = fma(pair[k].x, vn.x, fma(pair[k].y, vn.y, acc[k]));
+                }
             }
         } else {
             for (int c = j + 1 + lane; c < n; c += kWave) {
@@ -312,15 +315,16 @@ __global__ __launch_bounds__(256) void td_fused_pass(T* __restrict__ a, int n, i
 #pragma unroll
                 for (int i = 0; i < P; ++i) wc[i] = td_conj(pend.w[i][c]), vc[i] = td_conj(pend.v[i][c]);
                 const T vn = v_new[c];
+                T value[ROWS];
 #pragma unroll
-                for (int k = 0; k < ROWS; ++k)
-                    if (k < live) {
-                        T value = row[k][c];
+                for (int k = 0; k < ROWS; ++k) value[k] = row[k][c];
 #pragma unroll
-                        for (int i = 0; i < P; ++i) value = td_sub(value, td_add(td_mul(vr[k][i], wc[i]), td_mul(wr[k][i], vc[i])));
-                        if (P > 0) row[k][c] = value;
-                        acc[k] = td_add(acc[k], td_mul(value, vn));
-                    }
+                for (int k = 0; k < ROWS; ++k) {
+#pragma unroll
+                    for (int i = 0; i < P; ++i) value[k] = td_sub(value[k], td_add(td_mul(vr[k][i], wc[i]), td_mul(wr[k][i], vc[i])));
+                    if (P > 0 && k < live) row[k][c] = value[k];
+                    acc[k] = td_add(acc[k], td_mul(value[k], vn));
+                }
             }
         }
 #pragma unroll
