@@ -349,6 +349,16 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
         if (int rc = sys->dict_diagonal.reserve((size_t)sys->n_unique)) return cleanup(rc);
         if (hipMemcpy(sys->dict_diagonal.ptr, diagonal.data(), sizeof(int) * diagonal.size(), hipMemcpyHostToDevice) != hipSuccess)
             return cleanup(fail(BDG_EDEVICE, "upload of the block dictionary failed"));
+        if (!onsite_streamed && max_row <= 7) {
+            const int words = max_row <= 3 ? 4 : 8;
+            std::vector<unsigned> ell((size_t)nb * words, 0xFFFFFFFFu);
+            for (int64_t i = 0; i < nb; ++i)
+                for (int64_t k = indptr[i]; k < indptr[i + 1]; ++k) ell[(size_t)i * words + (size_t)(k - indptr[i])] = (unsigned)ids[(size_t)k];
+            if (int rc = sys->dict_ell.reserve(ell.size())) return cleanup(rc);
+            if (hipMemcpy(sys->dict_ell.ptr, ell.data(), sizeof(unsigned) * ell.size(), hipMemcpyHostToDevice) != hipSuccess)
+                return cleanup(fail(BDG_EDEVICE, "upload of the block dictionary failed"));
+            sys->dict_ell_words = words;
+        }
         if (hipMemcpy(sys->dict_ids.ptr, ids.data(), sizeof(int) * ids.size(), hipMemcpyHostToDevice) != hipSuccess ||
             hipMemcpy(sys->dict_full.ptr, distinct.data(), sizeof(double) * distinct.size(),
                       hipMemcpyHostToDevice) != hipSuccess)
@@ -514,6 +524,7 @@ int bdg_destroy(bdg_system* sys) {
     for (auto& buf : sys->onsite) buf.release();
     for (auto& buf : sys->site_records) buf.release();
     sys->dict_ids.release();
+    sys->dict_ell.release();
     sys->dict_diagonal.release();
     sys->dict_full.release();
     sys->stencil.release();

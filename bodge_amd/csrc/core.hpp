@@ -204,6 +204,11 @@ struct bdg_system : StreamSet {
     DeviceBuffer<double2> site_records[2];
     int site_records_plane[2] = {0, 0};  // lattice plane size the records were built for
     DeviceBuffer<int> dict_ids;
+    // the same words in rows of fixed width (4 words for up to 3 blocks per row, 8 for up to 7; 0xFFFFFFFF = no block): the
+    // one-step dictionary kernel reads a row's words with one or two 16-byte loads instead of indptr -> words (a dependent
+    // round trip less per tile: small lattices are bound by that chain)
+    DeviceBuffer<unsigned> dict_ell;
+    int dict_ell_words = 0;
     DeviceBuffer<int> dict_diagonal;      // per distinct block: 1 = diagonal as a 4x4 matrix (stencil kernels)
     DeviceBuffer<double2> dict_full;      // n_unique x 16 complex entries
     DeviceBuffer<double2> dict_table[4];  // packed per storage mode, built on first use

@@ -212,6 +212,7 @@ struct StepArgs {
     double* partial;      // [gridDim.x][RL * kVec][2]
     const int* tile_order;  // optional permutation of workgroup tiles (nullptr = natural order)
     const int* dict_ids;    // dictionary form: per stored block, column | table index << 24
+    const unsigned* dict_ell;  // the same words in rows of 4 (max_row_blocks <= 3) or 8 words, 0xFFFFFFFF = no block (cheb_step_dict)
     const void* dict_table; // dictionary form: the distinct blocks, packed for the mode
     int n_unique;
     double coef;
@@ -898,16 +899,28 @@ __global__ __launch_bounds__(kBlockThreads, 4) void cheb_step_dict(StepArgs a) {
     };
     auto col_of = [](unsigned w) { return (size_t)(w & 0xFFFFFFu); };
     auto id_of = [](unsigned w) { return (int)(w >> 24); };
+    // (fixed-width rows: one or two 16-byte loads whose address depends on the row alone - no indptr round trip first;
+    // rows past the end read the last row and count as empty)
+    constexpr int ELLW = MAXB <= 3 ? 4 : 8;
     auto load_meta = [&](int row0, RowMeta& m) {
         const int i = row0 + s;
-        int kbeg = 0, kend = 0;
-        if (i < a.nb) {
-            kbeg = a.indptr[i];
-            kend = a.indptr[i + 1];
+        const uint4* src = reinterpret_cast<const uint4*>(a.dict_ell) + (size_t)min(i, a.nb - 1) * (ELLW / 4);
+        unsigned words[8];
+        const uint4 lo = src[0];
+        words[0] = lo.x, words[1] = lo.y, words[2] = lo.z, words[3] = lo.w;
+        if constexpr (ELLW == 8) {
+            const uint4 hi = src[1];
+            words[4] = hi.x, words[5] = hi.y, words[6] = hi.z, words[7] = hi.w;
+        } else {
+            words[4] = words[5] = words[6] = words[7] = 0xFFFFFFFFu;
         }
-        m.len = kend - kbeg;
+        m.len = 0;
 #pragma unroll
-        for (int q = 0; q < MAXB; ++q) m.word[q] = (q < m.len) ? (unsigned)a.dict_ids[kbeg + q] : 0u;
+        for (int q = 0; q < MAXB; ++q) {
+            const bool there = i < a.nb && words[q] != 0xFFFFFFFFu;
+            m.len += there ? 1 : 0;
+            m.word[q] = there ? words[q] : 0u;
+        }
     };
 
     double dot[4] = {0.0, 0.0, 0.0, 0.0};

@@ -329,6 +329,7 @@ int matrix_args(bdg_system* sys, const StepPlan& plan, bdg::StepArgs* args) {
     if (plan.dictionary) {
         if (int rc = ensure_dict_table(sys, plan.mode, &args->dict_table)) return rc;
         args->dict_ids = sys->dict_ids.ptr;
+        args->dict_ell = sys->dict_ell.ptr;
         args->n_unique = sys->n_unique;
     } else if (int rc = ensure_blocks(sys, plan.mode, &args->blocks)) {
         return rc;
