@@ -94,15 +94,22 @@ __host__ __device__ inline uint64_t vector_key(uint64_t seed, uint64_t vec_id) {
     return splitmix64(seed ^ splitmix64(vec_id));
 }
 
-__host__ __device__ inline double2 start_entry(uint64_t key, uint64_t element, int kind) {
-    const uint64_t h = splitmix64(key + element);
-    if (kind == 0) return make_double2((h >> 63) ? -1.0 : 1.0, 0.0);
-    switch (h >> 62) {
+// Entry `element` = 4 * site + component of the start vector `key`: ONE hash per site, whose top bits serve the four
+// components (±1: bit 63 - component; Z4: the two bits below 64 - 2 * component).  Round 4: a hash per element made the
+// sweep that generates t_0 in registers the slowest launch of a run (eight 64-bit hashes per lane and plane: 192 us
+// against 181 us for a sweep that moves twice the bytes) - a quarter of the hashes.
+__host__ __device__ inline uint64_t start_site_hash(uint64_t key, uint64_t site) { return splitmix64(key + site); }
+__host__ __device__ inline double2 start_component(uint64_t h, int component, int kind) {
+    if (kind == 0) return make_double2(((h >> (63 - component)) & 1) ? -1.0 : 1.0, 0.0);
+    switch ((h >> (62 - 2 * component)) & 3) {
         case 0: return make_double2(1.0, 0.0);
         case 1: return make_double2(0.0, 1.0);
         case 2: return make_double2(-1.0, 0.0);
         default: return make_double2(0.0, -1.0);
     }
+}
+__host__ __device__ inline double2 start_entry(uint64_t key, uint64_t element, int kind) {
+    return start_component(start_site_hash(key, element >> 2), (int)(element & 3), kind);
 }
 
 // Vector buffers hold `ncols` block rows: the first `nb` are the rows this handle owns

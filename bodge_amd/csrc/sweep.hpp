@@ -668,14 +668,16 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
         if constexpr (GEN) {
             k = ring(act(k));
             if (wanted && k >= 0 && k < a.lx) {
-                const uint64_t element = 4 * ((uint64_t)k * a.plane + pw);
+                const uint64_t site = (uint64_t)k * a.plane + pw;  // (one hash per site and vector: kernels.hpp start_entry)
+                const uint64_t h0 = start_site_hash(gen_key0, site);
+                [[maybe_unused]] const uint64_t h1 = Mode::kVec == 2 ? start_site_hash(gen_key1, site) : 0;
 #pragma unroll
                 for (int al = 0; al < 4; ++al) {
                     if constexpr (Mode::kVec == 2) {
-                        out[al].x = gen_on0 ? start_entry(gen_key0, element + al, 0).x : 0.0;
-                        out[al].y = gen_on1 ? start_entry(gen_key1, element + al, 0).x : 0.0;
+                        out[al].x = gen_on0 ? start_component(h0, al, 0).x : 0.0;
+                        out[al].y = gen_on1 ? start_component(h1, al, 0).x : 0.0;
                     } else {
-                        out[al] = gen_on0 ? start_entry(gen_key0, element + al, a.gen_kind) : zero;
+                        out[al] = gen_on0 ? start_component(h0, al, a.gen_kind) : zero;
                     }
                 }
             } else {

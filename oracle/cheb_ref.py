@@ -45,14 +45,17 @@ def vector_key(seed: int, vec_id: int) -> np.uint64:
 
 
 def random_vector(n: int, seed: int, vec_id: int, kind: int = VEC_RADEMACHER, row0: int = 0) -> np.ndarray:
-    """Counter-based start vector: element `row` depends only on (seed, vec_id, row)."""
+    """Counter-based start vector: element `row` = 4 * site + component depends only on (seed, vec_id, row) - one hash
+    per site, its top bits shared out to the four components (kernels.hpp `start_entry`)."""
     key = vector_key(seed, vec_id)
+    rows = np.arange(row0, row0 + n, dtype=np.uint64)
+    component = rows & np.uint64(3)
     with np.errstate(over="ignore"):
-        h = _splitmix64(key + np.arange(row0, row0 + n, dtype=np.uint64))
+        h = _splitmix64(key + (rows >> np.uint64(2)))
     if kind == VEC_RADEMACHER:
-        return np.where((h >> np.uint64(63)) == 0, 1.0, -1.0).astype(np.complex128)
+        return np.where((h >> (np.uint64(63) - component)) & np.uint64(1) == 0, 1.0, -1.0).astype(np.complex128)
     if kind == VEC_Z4:
-        return np.array([1, 1j, -1, -1j], dtype=np.complex128)[(h >> np.uint64(62)).astype(np.int64)]
+        return np.array([1, 1j, -1, -1j], dtype=np.complex128)[((h >> (np.uint64(62) - np.uint64(2) * component)) & np.uint64(3)).astype(np.int64)]
     raise ValueError("unknown vector kind")
 
 
