@@ -156,7 +156,9 @@ def test_stochastic_free_energy_is_stable_and_in_range(big, api):
     for first in (0, 8):
         mu = solver.moments_random(scale, 512, 8, seed=0, first_id=first) / 8
         f.append(chebyshev.free_energy_series(mu, scale, 0.5) / n_sites)
-    assert abs(f[0] - f[1]) < 2e-4  # ~ sigma / sqrt(R * 4N)
+    # (an 8-vector estimate of F/N scatters by 3.7-4.5e-4 over sixteen disjoint vector sets and two seeds -
+    # scratch/r4_stoch_spread.py; the difference of two by sqrt 2 more: four standard deviations)
+    assert abs(f[0] - f[1]) < 2.5e-3
     assert -3.20 < f[0] < -3.10     # golden 20x20+Zeeman: F(0.5)/400 = -3.1433 (finite-size edges)
 
 
