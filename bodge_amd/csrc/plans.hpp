@@ -660,6 +660,8 @@ int ensure_stencil(bdg_system* sys, int* kind) {
     return BDG_OK;
 }
 
+inline int64_t plane_sites(const bdg_system* sys) { return (int64_t)sys->shape[1] * sys->shape[2]; }
+
 // Should this batch run a stencil form, and which (see ensure_stencil)?  Whole square matrix (or a slab of a
 // same-process group), no per-column scalars; unit start vectors when their band of planes gets wide
 // (unit_run_wants_stencil).

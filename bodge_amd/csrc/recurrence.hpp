@@ -115,7 +115,10 @@ struct Batch {
             stencil_kind = 0;
         if (stencil_kind == 1) {
             const int lanes = sweep_lanes_for(sys, n_active, per_lane, start.kind == StartKind::Unit);
-            if (n_active <= lanes * per_lane) {
+            // (A/B builds in which the three-step sweep addresses the four components of a plane through one buffer descriptor: below 4 GB)
+            const bool addressable = !BDG_SWEEP_ONE_DESCRIPTOR ||
+                                     (size_t)3 * sys->ncols * lanes * sizeof(double2) + (size_t)plane_sites(sys) * lanes * sizeof(double2) < bdg::kSweepSpanLimit;
+            if (n_active <= lanes * per_lane && addressable) {
                 sweep = true;
                 rl = lanes;
             }

@@ -518,6 +518,11 @@ typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int sweep_u32x2 __attribute__((ext_vector_type(2)));
 constexpr int kRawBufferFlags = 0x00020000;  // raw buffer resource of gfx9 / CDNA: 32-bit data format, no swizzle
 constexpr int kAuxSc1 = 16;                  // cache-policy bits of the raw buffer builtins: sc1 = write-through
+constexpr int kBufferFar = (int)0xFFFFFFE0u;     // ... and one beyond any descriptor of up to 4 GB - 32 (the one-descriptor-per-plane form)
+constexpr size_t kSweepSpanLimit = 0xFFFFFF00u;  // bytes such a descriptor may span: 3 components of the whole buffer + a plane
+#ifndef BDG_SWEEP_ONE_DESCRIPTOR
+#define BDG_SWEEP_ONE_DESCRIPTOR 0  // (1: A/B builds - measured 6 % slower, see load_plane)
+#endif
 constexpr int kBufferOutOfRange = 0x7FFFFFF0;  // an offset no plane descriptor covers: such loads return zeros, such stores do nothing
 constexpr int kAuxNt = 2;                    // ... nt = non-temporal (what __builtin_nontemporal_load / _store set)
 
@@ -613,6 +618,8 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
     constexpr bool BUF = WT || (OS != 0 && (Mode::kVec == 1 || RL == 2)) || BDG_SWEEP_BUFFER_OPS;
     const int plane_bytes = a.plane * RL * (int)sizeof(double2);
     const int lane_bytes = (pw * RL + r) * (int)sizeof(double2);  // (stores: owned lanes only, where p == pw)
+    [[maybe_unused]] const unsigned comp_stride = (unsigned)(nb * RL * sizeof(double2));  // bytes from one component of a site to the next
+    [[maybe_unused]] const int span_bytes = (int)(3u * comp_stride + (unsigned)plane_bytes);  // (below 4 GB: kSweepSpanLimit, checked on the host)
     auto load_plane = [&](const double2* buf, bool nt, int k, bool wanted, double2 out[4]) {
         k = ring(act(k));
         if constexpr (BUF) {
@@ -621,6 +628,17 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
             // the compiler can wait for an older plane with a counted s_waitcnt vmcnt(N) that leaves these in flight
             // (with the loads behind a branch it has to assume the path without them: vmcnt(0), see the text above)
             const bool there = buf != nullptr && k >= 0 && k < a.lx;  // (uniform)
+#if BDG_SWEEP_ONE_DESCRIPTOR
+            // (A/B builds) one descriptor per buffer and plane: it starts at the plane of component 0 and reaches to the end of
+            // the same plane of component 3; a component is a constant added to the lane's offset - one vector add instead of
+            // a dozen scalar instructions per descriptor.  Measured SLOWER: headline 105.9-106.2 against 111.9-112.5 k
+            // vector-steps/s on one box, complex forms -5 % (profiles/r04_onsite_ab.log): the scalar unit has room, the
+            // vector unit has not.
+            const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(buf, there ? (size_t)k * a.plane * RL * sizeof(double2) : 0, there ? span_bytes : 0);
+#pragma unroll
+            for (int al = 0; al < 4; ++al)
+                out[al] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, wanted ? lane_bytes + al * (int)comp_stride : kBufferFar, 0, 0));
+#else
             const int offset = wanted ? lane_bytes : kBufferOutOfRange;
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
@@ -628,6 +646,7 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
                                                                      there ? plane_bytes : 0);
                 out[al] = __builtin_bit_cast(double2, __builtin_amdgcn_raw_buffer_load_b128(rsrc, offset, 0, 0));
             }
+#endif
         } else if (wanted && k >= 0 && k < a.lx) {
             const size_t site = (size_t)k * a.plane + pw;
 #pragma unroll
@@ -650,11 +669,18 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[al]), rsrc, lane_bytes, 0, kAuxSc1);
             }
         } else if constexpr (BUF) {
+#if BDG_SWEEP_ONE_DESCRIPTOR
+            const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(buf, (size_t)act(k) * a.plane * RL * sizeof(double2), span_bytes);
+#pragma unroll
+            for (int al = 0; al < 4; ++al)
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[al]), rsrc, lane_bytes + al * (int)comp_stride, 0, 0);
+#else
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
                 const __amdgpu_buffer_rsrc_t rsrc = sweep_plane_rsrc(buf, ((size_t)al * nb + (size_t)act(k) * a.plane) * RL * sizeof(double2), plane_bytes);
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v[al]), rsrc, lane_bytes, 0, 0);
             }
+#endif
         } else {
 #pragma unroll
             for (int al = 0; al < 4; ++al) {
