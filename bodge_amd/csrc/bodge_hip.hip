@@ -345,6 +345,13 @@ int bdg_create_slab(int device, int64_t nb, int64_t ncols, int64_t nnzb, const i
             for (int e = 0; e < 16; ++e)
                 if ((e >> 2) != (e & 3) && (distinct[(size_t)32 * d + 2 * e] != 0.0 || distinct[(size_t)32 * d + 2 * e + 1] != 0.0))
                     diagonal[(size_t)d] = 0;
+        // 2 = "singlet" block: A diagonal, B and C antidiagonal (on-site singlet pairing, hopping + d-wave pairing on a bond):
+        // the three-step sweep multiplies its eight non-zero entries only (kernels.hpp mac_singlet)
+        for (int d = 0; d < sys->n_unique; ++d) {
+            if (diagonal[(size_t)d]) continue;
+            auto zero = [&](int r, int c) { return distinct[(size_t)32 * d + 2 * (4 * r + c)] == 0.0 && distinct[(size_t)32 * d + 2 * (4 * r + c) + 1] == 0.0; };
+            if (zero(0, 1) && zero(1, 0) && zero(0, 2) && zero(1, 3) && zero(2, 0) && zero(3, 1) && zero(2, 3) && zero(3, 2)) diagonal[(size_t)d] = 2;
+        }
         if (knob::raw("BODGE_AMD_NO_DIAGONAL_BLOCKS")) std::fill(diagonal.begin(), diagonal.end(), 0);
         if (int rc = sys->dict_diagonal.reserve((size_t)sys->n_unique)) return cleanup(rc);
         if (hipMemcpy(sys->dict_diagonal.ptr, diagonal.data(), sizeof(int) * diagonal.size(), hipMemcpyHostToDevice) != hipSuccess)

@@ -209,7 +209,7 @@ struct bdg_system : StreamSet {
     // round trip less per tile: small lattices are bound by that chain)
     DeviceBuffer<unsigned> dict_ell;
     int dict_ell_words = 0;
-    DeviceBuffer<int> dict_diagonal;      // per distinct block: 1 = diagonal as a 4x4 matrix (stencil kernels)
+    DeviceBuffer<int> dict_diagonal;      // per distinct block: 1 = diagonal as a 4x4 matrix, 2 = "singlet" form (stencil kernels)
     DeviceBuffer<double2> dict_full;      // n_unique x 16 complex entries
     DeviceBuffer<double2> dict_table[4];  // packed per storage mode, built on first use
     // lattice-stencil form of the matrix (sweep.hpp): 0 = not examined, 1 = 5-point table built (planes

@@ -101,6 +101,8 @@ struct SweepArgs {
 // `onsite_streamed`: the words of the diagonal blocks carry no table id (the sweep reads those blocks
 // from the per-site stream); their slot is only marked present.  2 = the same for every block (bond blocks
 // streamed as well: pack_site_records).
+// Bits 13..17 of the second word (round 4): the block at offset o is a "singlet" block (`diagonal[id]` == 2: A diagonal, B and
+// C antidiagonal - kernels.hpp mac_singlet), read by cheb_sweep3 only.
 __global__ void build_stencil(const int* __restrict__ indptr, const int* __restrict__ words,
                               const int* __restrict__ diagonal, int nb, int plane, int onsite_streamed,
                               uint2* __restrict__ stencil, int* __restrict__ bad) {
@@ -136,7 +138,10 @@ __global__ void build_stencil(const int* __restrict__ indptr, const int* __restr
             else if (onsite_streamed == 2 || (onsite_streamed && slot == 2)) id[slot] = 0;  // (2: every block is streamed)
             else {
                 id[slot] = w >> 24;
-                if (diagonal[w >> 24]) mask |= 1u << slot;
+                if (diagonal[w >> 24] == 1) mask |= 1u << slot;
+                // (bond blocks only: for an on-site singlet block - the s-wave models - the saving and the extra test cancel,
+                // 110.2-111.1 against 110.9-111.4 k vector-steps/s; four d-wave bond blocks per site gain 5.5 %)
+                if (diagonal[w >> 24] == 2 && slot != 2) mask |= 32u << slot;
             }
         }
         if (!ok) atomicOr(bad, 1);
@@ -453,6 +458,9 @@ __global__ __launch_bounds__(kSweepThreads, 2) void cheb_sweep(SweepArgs a) {
 #ifndef BDG_OS_EXPERIMENT
 #define BDG_OS_EXPERIMENT 0
 #endif
+#ifndef BDG_SINGLET_BLOCKS
+#define BDG_SINGLET_BLOCKS 1  // (0: A/B builds that multiply "singlet" blocks as full blocks)
+#endif
 #ifndef BDG_COMPLEX_ONSITE_STRIDE
 #define BDG_COMPLEX_ONSITE_STRIDE 6  // (7 = ComplexPHMode::kOnsiteStride, the padded stride of round 3, for A/B builds)
 #endif
@@ -508,6 +516,7 @@ constexpr int sweep3_onsite_pieces() {
 struct Sweep3Lds {
     double2* table;
     double2* diag;
+    double2* singlet;  // compact copies of the "singlet" form of every block (Mode::kSingletSlots each; used where flagged)
     double2* row_0;
     double2* row_1;
     double2* row_2;
@@ -588,6 +597,7 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
     const int r = lane % RL;
     double2* const lds = w.table;
     double2* const diag = w.diag;
+    [[maybe_unused]] double2* const singlet = w.singlet;
     double2* const row_0 = w.row_0;
     double2* const row_1 = w.row_1;
     double2* const row_2 = w.row_2;
@@ -737,7 +747,10 @@ __device__ __forceinline__ void sweep3_unit(const SweepArgs& a, const Sweep3Task
 #else
         if ((w.y >> (8 + slot)) & 1u) Mode::mac_diag(acc, lds + id * STRIDE, x);
 #endif
-        else Mode::mac_row(acc, lds + id * STRIDE, x);
+        else if constexpr (Mode::kSingletSlots > 0 && BDG_SINGLET_BLOCKS) {
+            if ((w.y >> (13 + slot)) & 1u) Mode::mac_singlet(acc, singlet + id * Mode::kSingletSlots, x);
+            else Mode::mac_row(acc, lds + id * STRIDE, x);
+        } else Mode::mac_row(acc, lds + id * STRIDE, x);
     };
     auto own_of = [&](const double2* row, double2 out[4]) {
 #pragma unroll
@@ -967,15 +980,20 @@ __device__ inline Sweep3Lds sweep3_stage_lds(double2* lds, const SweepArgs& a, i
     // compact copies of the block diagonals behind the table: a block flagged diagonal (plain hopping: four of the
     // five blocks of a row in the s-wave models) then costs Mode::kDiagSlots 16-byte LDS reads instead of mac_diag's
     // (1 instead of 2 in real particle-hole arithmetic: a tenth of the kernel's LDS operations)
+    constexpr int SSL = Mode::kSingletSlots;
     Sweep3Lds w;
     w.table = lds;
     w.diag = lds + a.n_unique * STRIDE;
-    w.row_0 = w.diag + a.n_unique * DSL + wave * (3 * kWave * 4 + ring);
+    w.singlet = w.diag + a.n_unique * DSL;
+    w.row_0 = w.singlet + a.n_unique * SSL + wave * (3 * kWave * 4 + ring);
     w.row_1 = w.row_0 + kWave * 4;
     w.row_2 = w.row_1 + kWave * 4;
     w.os_ring = w.row_2 + kWave * 4;
     __syncthreads();
-    for (int id = threadIdx.x; id < a.n_unique; id += THREADS) Mode::pack_diag(w.diag + id * DSL, lds + id * STRIDE);
+    for (int id = threadIdx.x; id < a.n_unique; id += THREADS) {
+        Mode::pack_diag(w.diag + id * DSL, lds + id * STRIDE);
+        if constexpr (SSL > 0) Mode::pack_singlet(w.singlet + id * SSL, lds + id * STRIDE);
+    }
     __syncthreads();
     return w;
 }
@@ -1314,7 +1332,7 @@ __global__ void build_stencil3(const int* __restrict__ indptr, const int* __rest
             if (slot < 0 || (w >> 24) == kNoBlock) ok = false;
             else {
                 id[slot] = w >> 24;
-                if (diagonal[w >> 24]) id[7] |= 1u << slot;  // byte 7: which of the seven blocks are diagonal
+                if (diagonal[w >> 24] == 1) id[7] |= 1u << slot;  // byte 7: which of the seven blocks are diagonal
             }
         }
         if (!ok) atomicOr(bad, 1);
