@@ -425,7 +425,10 @@ struct ComplexPHMode {
     // z, Delta i sigma_2), hopping with d-wave pairing on the bond.  Half the entries of such a block are zero: the compact
     // copy holds A00, A11, B01, B10, C01, C10 and the product takes 8 complex multiply-adds instead of 16 - mac_row's
     // products on the non-zero entries, in mac_row's order (adding 0 * x changes no bit of a finite sum).
-    static constexpr int kSingletSlots = 6;
+    // Measured in complex arithmetic (profiles/r04_onsite_ab.log): having this path in the kernel costs the complex forms
+    // 5-6 % whether or not a block takes it (texture 42.0-42.4 against 44.4 k vector-steps/s, the headline matrix with complex
+    // vectors 49.7-50.0 against 53.0-53.5 k), so it is compiled for real arithmetic only: kSingletSlots = 0 switches it off.
+    static constexpr int kSingletSlots = 0;  // (6 = the compact copy below)
     __device__ static inline void pack_singlet(double2* d, const double2* blk) {
         d[0] = blk[0], d[1] = blk[3], d[2] = blk[5], d[3] = blk[6], d[4] = blk[9], d[5] = blk[10];
     }

@@ -497,10 +497,10 @@ SweepKernel sweep3_streamed_kernel(const ModeInfo& mode, int lanes, int waves, b
 // LDS of one workgroup of cheb_sweep3: table + compact diagonals + per wave three hand-over rows and (streamed forms)
 // the ring of three planes of records.
 size_t sweep3_lds_bytes(const bdg_system* sys, const ModeInfo& mode, int lanes, int waves) {
-    // table + compact diagonals + compact "singlet" copies (particle-hole modes: 6 complex / 3 real slots per block)
+    // table + compact diagonals + compact "singlet" copies (RealPHMode::kSingletSlots = 3 slots per block; the other modes none)
     size_t bytes = (size_t)sys->n_unique * mode.stride * sizeof(double2) +
                    (size_t)sys->n_unique * (mode.id == 0 ? 4 : mode.id == 3 ? 1 : 2) * sizeof(double2) +
-                   (size_t)sys->n_unique * (mode.id == 2 ? 6 : mode.id == 3 ? 3 : 0) * sizeof(double2);
+                   (size_t)sys->n_unique * (mode.id == 3 ? RealPHMode::kSingletSlots : 0) * sizeof(double2);
     size_t per_wave = (size_t)3 * bdg::kWave * 4 * sizeof(double2);
     if (sys->onsite_streamed) {
         const int stride = sys->bonds_streamed ? (mode.real ? bdg::sweep3_record_stride<RealPHMode, 2>() : bdg::sweep3_record_stride<ComplexPHMode, 2>())
