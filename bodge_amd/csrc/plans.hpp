@@ -905,9 +905,23 @@ struct RollPlan {
     bdg::RollArgs args{};
     int waves = 0;
     int whole_segs = 1;
+    int share = 1;  // lane groups of the call in flight together (set by the batch)
     int segments_for(int planes) const {
         if (planes >= args.lx) return whole_segs;
         return std::max(1, std::min(choose_segments(args.n_cols, planes, waves, 2, 4), planes / 4));
+    }
+    // Plane-steps per unit when the units are cut for equal length (RollArgs.chunk), 0 = whole-column segments: used when
+    // the segments leave more than a tenth of the wave slots empty or overfill them, and a run stays within two columns.
+    int chunk_for(int planes) const {
+        if (const char* env = knob::raw("BODGE_AMD_ROLL_CHUNKS"); env && env[0] == '0') return 0;
+        // (`share` lane groups of the call run side by side on as many streams: each launch gets that part of the wave slots -
+        // two launches cut for the whole device each were 3.5 % slower than whole-column segments)
+        const int slots = std::max(1, waves / std::max(1, share));
+        const int64_t total = (int64_t)args.n_cols * planes;
+        const int64_t units = (int64_t)args.n_cols * segments_for(planes) * std::max(1, share);
+        if (units >= (int64_t)(0.92 * waves) && units <= waves) return 0;
+        const int chunk = (int)((total + slots - 1) / slots);
+        return chunk >= 8 && chunk <= planes ? chunk : 0;
     }
 };
 
@@ -944,7 +958,7 @@ int make_roll_plan(bdg_system* sys, const ModeInfo& mode, int lanes, RollPlan* p
     a.x_hi = a.lx;
     plan->waves = waves;
     plan->whole_segs = a.n_segs;
-    const int64_t units = (int64_t)a.n_cols * a.n_segs;
+    const int64_t units = std::max<int64_t>((int64_t)a.n_cols * a.n_segs, plan->chunk_for(a.lx) > 0 ? waves : 0);
     const int grid = (int)std::min<int64_t>((int64_t)per_cu * sys->num_cus,
                                             (units + bdg::kWavesPerBlock - 1) / bdg::kWavesPerBlock);
     plan->grid = std::max(8, (grid + 7) / 8 * 8);

@@ -155,6 +155,7 @@ struct Batch {
             plan.dictionary = true;
             args = bdg::StepArgs{};
             if (int rc = make_roll_plan(sys, mode, rl, &rplan)) return rc;
+            rplan.share = stream_share;
         } else {
             if (int rc = make_plan(sys, rl, mode, &plan, col_scalars)) return rc;
             if (int rc = matrix_args(sys, plan, &args)) return rc;
@@ -517,10 +518,12 @@ struct Batch {
             ra.x_lo = 0;
             ra.x_hi = ra.lx;
             ra.n_segs = rplan.segments_for(ra.lx);
+            ra.chunk = rplan.chunk_for(ra.lx);
             if (plane_lo >= 0) {
                 ra.x_lo = std::max(0, plane_lo - (n + 1));
                 ra.x_hi = std::min(ra.lx, plane_hi + n + 2);
                 ra.n_segs = rplan.segments_for(ra.x_hi - ra.x_lo);
+                ra.chunk = rplan.chunk_for(ra.x_hi - ra.x_lo);
                 bytes_moved -= roll_bytes(sys, mode, rl) * (1.0 - (double)(ra.x_hi - ra.x_lo) / ra.lx);
             }
             ra.lo_buf = ra.hi_buf = nullptr;

@@ -1292,6 +1292,11 @@ struct RollArgs {
     int reverse;             // 1 = march every segment from its far end (launches alternate)
     int discard;             // 1 = t_{n+1} is not stored (last step of a run: only its dot products are wanted)
     int x_lo, x_hi;          // planes advanced by this launch (0, lx = all; unit start vectors: the band that can be non-zero)
+    // > 0: the units of the launch are runs of `chunk` plane-steps of the sequence (window 0: planes x_lo .. x_hi - 1, window 1:
+    // ..., column-major), cut wherever a run ends - mid-column too - so that every wave slot of the device gets the same
+    // number of planes (100^3: 715 windows x 100 planes on 2048 slots are 35 planes each; whole-column segments give 1430 units
+    // of 50 planes - 70 % of the slots - or 2145 of 33).  A unit that crosses a column boundary marches two pieces.
+    int chunk;
     // Row slabs (a stack of whole x-planes of a larger lattice, one handle per slab): the vector buffers
     // have `ld` block rows per component plane (own rows + halo rows), and t_n of the plane below plane 0 /
     // above plane lx-1 is read where the neighbouring slab keeps it - `lo_buf` / `hi_buf` point into that
@@ -1368,7 +1373,9 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
     double2* row_n = lds + a.n_unique * STRIDE + wave * (kWave * 4);  // t_n of plane k, all 16 slots
     __syncthreads();
 
-    const int n_units = a.n_cols * a.n_segs;
+    const int span = a.x_hi - a.x_lo;
+    const int64_t plane_steps = (int64_t)a.n_cols * span;
+    const int n_units = a.chunk > 0 ? (int)((plane_steps + a.chunk - 1) / a.chunk) : a.n_cols * a.n_segs;
     const int xcd = blockIdx.x & 7;
     const int u_lo = (int)(((int64_t)n_units * xcd) >> 3);
     const int u_hi = (int)(((int64_t)n_units * (xcd + 1)) >> 3);
@@ -1381,9 +1388,24 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
     const int plane_bytes = a.plane * RL * (int)sizeof(double2);
     const int ly = a.plane / a.lz;
     for (int u = u_lo + (int)(blockIdx.x >> 3) * kWavesPerBlock + wave; u < u_hi; u += waves_per_xcd) {
-        const int seg = u / a.n_cols, col = u - seg * a.n_cols;
-        const int x0 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * seg) / a.n_segs);
-        const int x1 = a.x_lo + (int)(((int64_t)(a.x_hi - a.x_lo) * (seg + 1)) / a.n_segs);
+      // the pieces of the unit: one (whole-column segments), or the parts of its run of plane-steps in up to two columns
+      int64_t g0 = a.chunk > 0 ? (int64_t)u * a.chunk : 0;
+      const int64_t g1 = a.chunk > 0 ? (g0 + a.chunk < plane_steps ? g0 + a.chunk : plane_steps) : 1;
+      while (g0 < g1) {
+        int col, x0, x1;
+        if (a.chunk > 0) {
+            col = (int)(g0 / span);
+            const int xa = (int)(g0 - (int64_t)col * span);
+            const int xb = (int)(xa + (g1 - g0) < span ? xa + (g1 - g0) : span);
+            x0 = a.x_lo + xa, x1 = a.x_lo + xb;
+            g0 += xb - xa;
+        } else {
+            const int seg = u / a.n_cols;
+            col = u - seg * a.n_cols;
+            x0 = a.x_lo + (int)(((int64_t)span * seg) / a.n_segs);
+            x1 = a.x_lo + (int)(((int64_t)span * (seg + 1)) / a.n_segs);
+            g0 = g1;
+        }
         const int p = col * OWNED - 1 + s;
         const bool valid = p >= 0 && p < a.plane;
         const bool owned = valid && s >= 1 && s <= SLOTS - 2;
@@ -1510,6 +1532,7 @@ __global__ __launch_bounds__(kBlockThreads, 2) void cheb_roll3(RollArgs a) {
             }
             ids = nx_ids;
         }
+      }
     }
 
     __syncthreads();
