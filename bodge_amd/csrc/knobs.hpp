@@ -17,6 +17,7 @@
 //     BODGE_AMD_SWEEP_LANES=1|2|4            lanes per site of the sweep kernels
 //     BODGE_AMD_STREAMED_SHARE=0             streamed forms (position-dependent blocks): segments cut for the whole device by every launch
 //                                            (default: shared between the lane groups side by side, as for the dictionary forms)
+//     BODGE_AMD_ROLL_CHUNKS=0                3-D rolling kernel: whole-column segments as units instead of runs of equal length
 //     BODGE_AMD_SWEEP_GEN=0                  write the random start block with the fill kernel instead of making it in the first sweep
 //     BODGE_AMD_MARCH=1|2|3                  cheb_march3 for the three-step sweeps of random-start runs (default 0: one cheb_sweep3 launch per
 //                                            sweep and lane group).  1 = all sweeps of a 63-step chunk in one launch, tasks claimed by ticket,
