@@ -4,8 +4,8 @@
 cd $GRAFT_REPO_ROOT
 LOG=gpurun_out/r04_fuzz.log
 {
-echo "== fuzz_sweep seed 401, 1200 cases"; FUZZ_SEED=401 FUZZ_CASES=1200 timeout -k 10 1000 python tests/fuzz_sweep.py 2>&1 | grep -v "^ok" | tail -8
-echo "== fuzz_sweep seed 402, 250 large cases"; FUZZ_SEED=402 FUZZ_CASES=250 FUZZ_SIZE=large timeout -k 10 1000 python tests/fuzz_sweep.py 2>&1 | grep -v "^ok" | tail -8
+echo "== fuzz_sweep seed 411, 3000 cases"; FUZZ_SEED=411 FUZZ_CASES=3000 timeout -k 10 1000 python tests/fuzz_sweep.py 2>&1 | grep -v "^ok" | tail -8
+echo "== fuzz_sweep seed 412, 500 large cases"; FUZZ_SEED=412 FUZZ_CASES=500 FUZZ_SIZE=large timeout -k 10 1000 python tests/fuzz_sweep.py 2>&1 | grep -v "^ok" | tail -8
 echo "== fuzz_dense seed 403, 120 cases, default routes"; FUZZ_SEED=403 FUZZ_CASES=120 timeout -k 10 900 python tests/fuzz_dense.py 2>&1 | grep -v "^ok" | tail -6
 echo "== fuzz_dense seed 404, 120 cases, two-stage forced"; FUZZ_SEED=404 FUZZ_CASES=120 FUZZ_STAGES=2 timeout -k 10 900 python tests/fuzz_dense.py 2>&1 | grep -v "^ok" | tail -6
 } > $LOG 2>&1
