@@ -98,10 +98,27 @@ __global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n,
                                                        T* __restrict__ taus, T* __restrict__ pend_dots) {
     __shared__ T scratch[16 * (2 * kTdDefer + 1)];
     __shared__ T row_v[kTdDefer], row_w[kTdDefer];
+    __shared__ T alpha_slot;
     T zero;
     td_set(zero, 0.0, 0.0);
     const int np = pend.count;          // pairs pending while q was formed
     const int now = j > 0 ? np + 1 : 0;  // ... and once (v_{j-1}, w_{j-1}) has joined them
+    // Round 4: the step is a chain of dependent round trips through L2 (it is one workgroup with a few entries per thread:
+    // 25 us per column, 72 of the 92 ms of an n = 3600 solve).  While a thread's share of a vector fits kTdKeep registers
+    // (n - j <= kTdKeep x 1024) what it has written stays in registers instead of being read back, row j of the matrix -
+    // which depends on nothing this kernel computes - is asked for first of all, and alpha reaches the other threads through
+    // LDS with the reduction's barrier instead of by a load of its own.
+    constexpr bool kKeepable = sizeof(T) == sizeof(double);  // (complex entries: the kept values spill - 68-132 B of scratch; real only)
+    constexpr int kTdKeep = kKeepable ? 4 : 1;
+    const bool keep = kKeepable && n - j <= kTdKeep * (int)blockDim.x;  // (uniform)
+    T row_keep[kTdKeep];
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < kTdKeep; ++k) {
+            const int c = j + 2 + (int)threadIdx.x + k * (int)blockDim.x;
+            row_keep[k] = c < n ? a[(size_t)j * n + c] : zero;
+        }
+    }
     if (j > 0) {
         // (i) q_true = q - sum_i [ v_i (w_i^H v) + w_i (v_i^H v) ];  p = tau q_true;  w = p - (tau / 2) (p^H v) v   over rows j .. n-1
         const T tau = scal->tau;
@@ -112,23 +129,43 @@ __global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n,
         T* w_out = pend.w[np];
         T* v_out = pend.v[np];
         T dot = zero;
-        for (int r = j + threadIdx.x; r < n; r += blockDim.x) {
+        T p_keep[kTdKeep], v_keep[kTdKeep];
+        int slot = 0;
+        for (int r = j + threadIdx.x; r < n; r += blockDim.x, ++slot) {
             T qt = q[r];
 #pragma unroll
             for (int i = 0; i < kTdDefer; ++i)
                 if (i < np) qt = td_sub(qt, td_add(td_mul(pend.v[i][r], dots[2 * i]), td_mul(pend.w[i][r], dots[2 * i + 1])));
             const T p = td_mul(tau, qt);
-            w_out[r] = p;  // (finished below)
-            dot = td_add(dot, td_mul(td_conj(p), v_unf[r]));
+            const T x = v_unf[r];
+            if (keep) {
+#pragma unroll
+                for (int k = 0; k < kTdKeep; ++k)
+                    if (k == slot) p_keep[k] = p, v_keep[k] = x;
+            } else {
+                w_out[r] = p;  // (finished below)
+            }
+            dot = td_add(dot, td_mul(td_conj(p), x));
         }
         dot = td_block_sum(dot, scratch);
         T half_tau;
         td_set(half_tau, -0.5 * td_re(tau), -0.5 * td_im(tau));
         const T alpha2 = td_mul(half_tau, dot);
-        for (int r = j + threadIdx.x; r < n; r += blockDim.x) {
-            const T x = v_unf[r];
-            w_out[r] = td_add(w_out[r], td_mul(alpha2, x));
-            v_out[r] = x;
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < kTdKeep; ++k) {
+                const int r = j + (int)threadIdx.x + k * (int)blockDim.x;
+                if (r < n) {
+                    w_out[r] = td_add(p_keep[k], td_mul(alpha2, v_keep[k]));
+                    v_out[r] = v_keep[k];
+                }
+            }
+        } else {
+            for (int r = j + threadIdx.x; r < n; r += blockDim.x) {
+                const T x = v_unf[r];
+                w_out[r] = td_add(w_out[r], td_mul(alpha2, x));
+                v_out[r] = x;
+            }
         }
         __syncthreads();
     }
@@ -154,8 +191,17 @@ __global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n,
 #pragma unroll
     for (int k = 0; k < 2 * kTdDefer + 1; ++k) sums[k] = zero;
     double norm2 = 0.0;
-    for (int c = j + 2 + threadIdx.x; c < n; c += blockDim.x) {
-        T value = a[(size_t)j * n + c];
+    T x_keep[kTdKeep];
+    int xslot = 0;
+    for (int c = j + 2 + threadIdx.x; c < n; c += blockDim.x, ++xslot) {
+        T value = zero;
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < kTdKeep; ++k)
+                if (k == xslot) value = row_keep[k];
+        } else {
+            value = a[(size_t)j * n + c];
+        }
         T wc[kTdDefer], vc[kTdDefer];
 #pragma unroll
         for (int i = 0; i < kTdDefer; ++i)
@@ -165,7 +211,13 @@ __global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n,
                 value = td_sub(value, td_add(td_mul(row_v[i], wc[i]), td_mul(row_w[i], vc[i])));
             }
         const T x = td_conj(value);
-        v_new[c] = x;  // (scaled below)
+        if (keep) {
+#pragma unroll
+            for (int k = 0; k < kTdKeep; ++k)
+                if (k == xslot) x_keep[k] = x;
+        } else {
+            v_new[c] = x;  // (scaled below)
+        }
         norm2 += td_abs2(x);
 #pragma unroll
         for (int i = 0; i < kTdDefer; ++i)
@@ -175,6 +227,7 @@ __global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n,
             }
     }
     td_set(sums[2 * kTdDefer], norm2, 0.0);
+    if (threadIdx.x == 0) alpha_slot = td_conj(entry(j + 1));  // (read by everyone after the barriers of the reduction below)
     {   // wave sums of the 2 `now` + 1 values in use, one row of `scratch` per wave; every thread adds up |x|^2, thread k
         // (below) the k-th dot product: fixed order, bit reproducible
         constexpr int N = 2 * kTdDefer + 1;
@@ -193,7 +246,7 @@ __global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n,
         for (int w = 0; w < (int)blockDim.x / kWave; ++w) total += td_re(scratch[w * N + N - 1]);
         norm2 = total;
     }
-    const T alpha = td_conj(entry(j + 1));
+    const T alpha = alpha_slot;
     if (norm2 == 0.0 && td_im(alpha) == 0.0) {  // nothing to annihilate: H = I
         if (threadIdx.x == 0) {
             e[j] = td_re(alpha);
@@ -204,7 +257,10 @@ __global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n,
         if ((int)threadIdx.x < 2 * now)  // v = e_{j+1}; tau = 0 makes the next w vanish whatever these are
             pend_dots[threadIdx.x] = td_conj((threadIdx.x & 1) ? pend.v[threadIdx.x >> 1][j + 1] : pend.w[threadIdx.x >> 1][j + 1]);
         __syncthreads();  // (every thread has read row j by now)
-        for (int c = j + 2 + threadIdx.x; c < n; c += blockDim.x) a[(size_t)j * n + c] = zero;
+        for (int c = j + 2 + threadIdx.x; c < n; c += blockDim.x) {
+            a[(size_t)j * n + c] = zero;
+            v_new[c] = zero;  // (x, all zeros here, may have stayed in registers)
+        }
         return;
     }
     const double ar = td_re(alpha), ai = td_im(alpha);
@@ -214,10 +270,22 @@ __global__ __launch_bounds__(1024) void td_vector_step(T* __restrict__ a, int n,
     T scale;
     td_set(scale, sr / den, -si / den);
     __syncthreads();  // (v_new written above by the same threads that rescale it: same index set, no hazard; keep order explicit)
-    for (int c = j + 2 + threadIdx.x; c < n; c += blockDim.x) {
-        const T scaled = td_mul(v_new[c], scale);
-        v_new[c] = scaled;
-        a[(size_t)j * n + c] = scaled;  // (row j: every thread read its entries before the barrier above)
+    if (keep) {
+#pragma unroll
+        for (int k = 0; k < kTdKeep; ++k) {
+            const int c = j + 2 + (int)threadIdx.x + k * (int)blockDim.x;
+            if (c < n) {
+                const T scaled = td_mul(x_keep[k], scale);
+                v_new[c] = scaled;
+                a[(size_t)j * n + c] = scaled;
+            }
+        }
+    } else {
+        for (int c = j + 2 + threadIdx.x; c < n; c += blockDim.x) {
+            const T scaled = td_mul(v_new[c], scale);
+            v_new[c] = scaled;
+            a[(size_t)j * n + c] = scaled;  // (row j: every thread read its entries before the barrier above)
+        }
     }
     if (threadIdx.x == 0) {
         e[j] = beta;
